@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py — interpolated frames/s of the RIFE 4.7 2x hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of a synthetic 1080p frame-pair stream that is
+already resident in HBM: for each of B new frames  clamp/pad/encode (vfi_rife_load_frame)  and for
+each of the B frame pairs one interpolation at t=0.5 (vfi_rife_interpolate) — B new frames per step,
+outputs written to HBM.  N>1: every rank runs its own stream (weak scaling, pairs are independent)
+and the new frames are all-gathered over RCCL/xGMI, overlapped with the next step.
+
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline     — dominant kernel (block3 ResConv 3x3, 64->64 ch @272x480, fp32 MFMA): algorithmic FLOP
+                 per launch / average launch duration measured with HIP events on the launch stream
+                 (library-side tracing, second pass of the same K steps); peak = 157.3 TFLOP/s.
+  cpu_baseline — the oracle (torch-CPU restatement, bit-exact vs the reference in the build container)
+                 timed on this host's cores on a bounded sample (N=1, rank 0 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip table
+
+
+def cpu_baseline(sd, H, W, budget_s=25.0):
+    """Oracle on the host cores: 1 warm-up + up to 3 timed 1080p forwards (bounded by budget_s)."""
+    from cfi_amd import synth
+    from oracle import rife_oracle
+
+    frames = synth.smooth_frames(2, H, W, seed=2, shift=4.0)
+    x = frames.permute(0, 3, 1, 2)
+    ts = torch.tensor([0.5]).view(1, 1, 1, 1)
+    times = []
+    t_begin = time.time()
+    with torch.inference_mode():
+        for i in range(4):
+            t0 = time.time()
+            rife_oracle.ifnet47_forward(sd, x[0:1], x[1:2], ts)
+            dt = time.time() - t0
+            if i > 0:
+                times.append(dt)
+            if time.time() - t_begin > budget_s and times:
+                break
+    times.sort()
+    med = times[len(times) // 2]
+    return {
+        "value": round(1.0 / med, 4),
+        "unit": "interpolated frames/s",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"{len(times)} timed + 1 warm-up forwards of oracle.rife_oracle.ifnet47_forward (torch-CPU fp32, "
+                  f"bit-exact vs reference IFNet('4.7') in the build container), 1 pair {H}x{W}, median {med:.3f} s/frame",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("VFI_BENCH_BATCH", "8")), help="frame pairs per step per GPU")
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather of new frames")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) | gloo (plumbing test on one GPU)")
+    args = ap.parse_args()
+
+    import __graft_entry__ as ge
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    ndev = torch.cuda.device_count()
+    torch.cuda.set_device(local_rank % ndev)
+    dev = torch.device("cuda", local_rank % ndev)
+
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(args.backend, rank=rank, world_size=world,
+                                device_id=dev if args.backend == "nccl" else None)
+    if rank == 0:
+        ge.build()  # no-op when the in-tree libvfi_hip.so is current
+    if world > 1:
+        dist.barrier()
+    ge.load_package()
+    from cfi_amd import _lib, synth
+    from cfi_amd.dist import broadcast_state_dict
+    from cfi_amd.rife import RifeEngine
+    from cfi_amd.rife_spec import rife47_shapes
+
+    B, H, W, K, Wm = args.batch, args.height, args.width, args.steps, args.warmup
+    sd = synth.rife47_synth_state_dict(1234) if rank == 0 or world == 1 else None
+    if world > 1:  # weights live on rank 0 and are broadcast once over RCCL (21.3 MB)
+        sd = broadcast_state_dict(sd, rife47_shapes(), dev if args.backend == "nccl" else "cpu")
+    eng = RifeEngine(sd, "4.7", device=dev)
+    n_slots = B + 1
+    eng.configure(H, W, B, max(n_slots, 2), 1.0)
+
+    # synthetic stream, resident in HBM before timing: B+1 distinct raw frames [H,W,3] fp32
+    base = synth.smooth_frames(3, H, W, seed=100 + rank, shift=4.0).to(dev)
+    noise = torch.rand((B + 1, 1, 1, 3), device=dev) * 0.05
+    raw = (base[torch.arange(B + 1) % 3] * 0.95 + noise).contiguous()
+    outs = [torch.empty((B, H, W, 3), dtype=torch.float32, device=dev) for _ in range(2)]
+    gathered = [torch.empty((world * B, H, W, 3), dtype=torch.float32, device=dev) for _ in range(2)] \
+        if world > 1 and not args.no_gather and args.backend == "nccl" else None
+    pending = [None, None]
+    slot0 = list(range(B))
+    slot1 = list(range(1, B + 1))
+    ts = [0.5] * B
+    eng.load_frame(0, raw[0])
+
+    def step(i):
+        k = i & 1
+        if pending[k] is not None:
+            pending[k].wait()  # the buffer's previous all-gather must be done before it is overwritten
+            pending[k] = None
+        # frame 0 of this step's stream is the last frame of the previous step in a real clip; here the
+        # slot contents are re-used and B NEW frames are prepared + encoded per step.
+        for j in range(1, B + 1):
+            eng.load_frame(j, raw[j])
+        eng.interpolate(slot0, slot1, ts, outs[k])
+        if world > 1 and not args.no_gather:
+            if gathered is not None:
+                pending[k] = dist.all_gather_into_tensor(gathered[k], outs[k], async_op=True)
+            else:  # gloo plumbing mode: stage through the host
+                lst = [torch.empty((B, H, W, 3)) for _ in range(world)]
+                dist.all_gather(lst, outs[k].cpu())
+
+    def drain():
+        for k in range(2):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
+        torch.cuda.synchronize()
+
+    def timed(nsteps):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(nsteps):
+            step(i)
+        drain()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    for i in range(Wm):
+        step(i)
+    drain()
+    elapsed = timed(K)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline leg: same K steps with per-kernel HIP events recorded on the launch stream
+    lib = _lib.load()
+    lib.vfi_trace_reset()
+    lib.vfi_trace_enable(1)
+    traced = timed(K)
+    lib.vfi_trace_enable(0)
+    rep = _lib.trace_report()
+    lib.vfi_trace_reset()
+
+    if rank == 0:
+        conv_flop, _ = eng.work_per_task()
+        hp, wp = -(-H // 64) * 64, -(-W // 64) * 64
+        dom = "resconv_c64"
+        calls, ms = rep.get(dom, (0, 0.0))
+        flop_per_launch = 2.0 * B * (hp // 4) * (wp // 4) * 64 * 64 * 9
+        avg_ms = ms / calls if calls else float("nan")
+        achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12 if calls else float("nan")
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom)
+            except Exception:
+                traffic = None
+        total_ms = sum(v[1] for v in rep.values())
+        kernels = {k: {"calls": v[0], "ms": round(v[1], 3), "share": round(v[1] / total_ms, 4)} for k, v in rep.items()}
+        res = {
+            "metric": "interpolated frames/sec/GPU @1080p RIFE4.7 2x" if world == 1 else
+                      "interpolated frames/sec @1080p RIFE4.7 2x (whole job)",
+            "value": round(world * B * K / elapsed, 3),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": Wm,
+            "ms_per_step": round(elapsed / K * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"RIFE 4.7 2x, {H}x{W} synthetic frame-pair stream, {B} pairs/step/GPU resident in HBM "
+                            f"(BASELINE.json configs[1]); seeded random-init weights",
+                "pairs_per_step_per_gpu": B,
+                "per_gpu_frames_per_s": round(B * K / elapsed, 3),
+                "new_frame_collective": "none" if world == 1 or args.no_gather else
+                                        ("all_gather(RCCL), overlapped" if gathered is not None else "all_gather(gloo, host)"),
+                "target_frames_per_s_per_gpu": 30,
+            },
+            "roofline": {
+                "kernel": "conv_mfma_kernel<s1,3x3> as resconv_c64 (block3 ResConv 64->64 @%dx%d, batch %d)" % (hp // 4, wp // 4, B),
+                "bound": "mfma",
+                "achieved": round(achieved, 3),
+                "peak": PEAK_FP32_MFMA_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                "traffic": traffic,
+                "launches": calls,
+                "avg_launch_ms": round(avg_ms, 4),
+                "flop_per_launch": flop_per_launch,
+                "traced_ms_per_step": round(traced / K * 1e3, 3),
+            },
+            "conv_tflops_whole_net": round(conv_flop * B * K / elapsed / 1e12, 3),
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(sd, H, W)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

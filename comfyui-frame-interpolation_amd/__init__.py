@@ -1,0 +1,39 @@
+"""MI355X-native drop-in for the RIFE / FILM / M2M nodes of ComfyUI-Frame-Interpolation.
+
+ComfyUI imports this directory as a custom-node package and reads
+``NODE_CLASS_MAPPINGS`` (reference: /root/reference/__init__.py:24-48).  The node
+classes are imported lazily so that tooling which only needs the checkpoint spec or the
+scheduler does not require the HIP library to be built.
+"""
+
+_LAZY = {
+    "RIFE_VFI": ("rife", "RIFE_VFI"),
+    "MakeInterpolationStateList": ("schedule", "MakeInterpolationStateList"),
+    "InterpolationStateList": ("schedule", "InterpolationStateList"),
+}
+
+
+def __getattr__(name):
+    if name in _LAZY:
+        import importlib
+
+        mod, attr = _LAZY[name]
+        return getattr(importlib.import_module(f"{__name__}.{mod}"), attr)
+    if name == "NODE_CLASS_MAPPINGS":
+        return _node_class_mappings()
+    raise AttributeError(name)
+
+
+def _node_class_mappings():
+    from .rife import RIFE_VFI
+    from .schedule import MakeInterpolationStateList
+
+    return {
+        "RIFE VFI": RIFE_VFI,
+        "Make Interpolation State List": MakeInterpolationStateList,
+    }
+
+
+NODE_DISPLAY_NAME_MAPPINGS = {
+    "RIFE VFI": "RIFE VFI (MI355X HIP; rife47 / rife49)",
+}

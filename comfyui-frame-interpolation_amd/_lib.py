@@ -1,0 +1,84 @@
+"""ctypes binding of libvfi_hip.so (include/vfi_hip.h).
+
+There is deliberately no fallback: if the library is missing or a call fails, a
+``RuntimeError`` is raised — the product path never routes through torch ops or the oracle.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvfi_hip.so")
+
+_lib = None
+
+c_float_p = C.POINTER(C.c_float)
+c_int_p = C.POINTER(C.c_int)
+
+# name -> (restype, argtypes); mirrors include/vfi_hip.h one to one
+PROTOTYPES = {
+    "vfi_init": (C.c_int, [C.c_int]),
+    "vfi_last_error": (C.c_char_p, []),
+    "vfi_device_info": (C.c_int, [C.c_char_p, C.c_int, c_int_p]),
+    "vfi_trace_enable": (C.c_int, [C.c_int]),
+    "vfi_trace_reset": (C.c_int, []),
+    "vfi_trace_report": (C.c_int, [C.c_char_p, C.c_int]),
+    "vfi_warp_border": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vfi_conv3x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
+    "vfi_conv3x3_naive": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "vfi_deconv4x4_ps2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_void_p]),
+    "vfi_rife_create": (C.c_void_p, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int]),
+    "vfi_rife_destroy": (None, [C.c_void_p]),
+    "vfi_rife_configure": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]),
+    "vfi_rife_load_frame": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "vfi_rife_interpolate": (C.c_int, [C.c_void_p, C.c_int, c_int_p, c_int_p, c_float_p, C.c_void_p, C.c_void_p]),
+    "vfi_rife_debug_keep": (C.c_int, [C.c_void_p, C.c_int]),
+    "vfi_rife_debug_read": (C.c_int64, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64]),
+    "vfi_rife_work": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+}
+
+
+def load():
+    """Load the shared library (building nothing: run ``__graft_entry__.build()`` first)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python __graft_entry__.py build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the VFI hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return (load().vfi_last_error() or b"").decode(errors="replace")
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (code {rc}): {last_error()}")
+
+
+def stream_ptr():
+    """hipStream_t of torch's current stream, so library launches order with torch copies."""
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def trace_report():
+    buf = C.create_string_buffer(1 << 16)
+    check(load().vfi_trace_report(buf, len(buf)), "vfi_trace_report")
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, calls, ms = line.split()
+        out[name] = (int(calls), float(ms))
+    return out

@@ -1,0 +1,64 @@
+"""Checkpoint location / download with the reference's directory contract.
+
+Behaviour mirrored from vfi_utils.py:84-137: a checkpoint lives at
+``<package>/<ckpts_path>/<model_type>/<ckpt_name>`` (``ckpts_path`` from config.yaml); if it is
+not there every base URL and then the per-file mirrors are tried in order, and one combined
+exception is raised when all fail.
+"""
+import os
+import traceback
+
+import yaml
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+BASE_MODEL_DOWNLOAD_URLS = [
+    "https://github.com/styler00dollar/VSGAN-tensorrt-docker/releases/download/models/",
+    "https://github.com/Fannovel16/ComfyUI-Frame-Interpolation/releases/download/models/",
+    "https://github.com/dajes/frame-interpolation-pytorch/releases/download/v1.0.0/",
+]
+CKPT_FALLBACK_URLS = {
+    "rife47.pth": [
+        "https://huggingface.co/marduk191/rife/resolve/main/rife47.pth",
+        "https://huggingface.co/wavespeed/misc/resolve/main/rife/rife47.pth",
+        "https://huggingface.co/MachineDelusions/RIFE/resolve/main/rife47.pth",
+    ],
+    "rife49.pth": [
+        "https://huggingface.co/marduk191/rife/resolve/main/rife49.pth",
+        "https://huggingface.co/hfmaster/models-moved/resolve/main/rife/rife49.pth",
+        "https://huggingface.co/MachineDelusions/RIFE/resolve/main/rife49.pth",
+    ],
+}
+
+
+def load_config():
+    path = os.path.join(_HERE, "config.yaml")
+    if not os.path.exists(path):
+        raise Exception("config.yaml file is necessary next to the node package")
+    with open(path, "r") as f:
+        return yaml.load(f, Loader=yaml.FullLoader)
+
+
+def get_ckpt_container_path(model_type):
+    return os.path.abspath(os.path.join(_HERE, load_config()["ckpts_path"], model_type))
+
+
+def load_file_from_github_release(model_type, ckpt_name):
+    model_dir = get_ckpt_container_path(model_type)
+    cached = os.path.join(model_dir, ckpt_name)
+    if os.path.exists(cached):
+        return cached
+    from torch.hub import download_url_to_file
+
+    os.makedirs(model_dir, exist_ok=True)
+    urls = [base + ckpt_name for base in BASE_MODEL_DOWNLOAD_URLS] + CKPT_FALLBACK_URLS.get(ckpt_name, [])
+    errors = []
+    for url in urls:
+        try:
+            print(f'Downloading: "{url}" to {cached}\n')
+            download_url_to_file(url, cached, hash_prefix=None, progress=True)
+            return cached
+        except Exception:
+            errors.append(f"Error when downloading from: {url}\n\n{traceback.format_exc()}")
+    raise Exception(f"Tried all urls to download {ckpt_name} but no success. Below is the error log:\n\n"
+                    + "\n\n".join(errors))

@@ -1,0 +1,63 @@
+"""Ahead-of-time build of libvfi_hip.so for gfx950 (MI355X).  No JIT, no torch extension:
+
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC csrc/*.hip -o libvfi_hip.so
+
+hipcc cross-compiles without a GPU present; the .so is kept in-tree (git-ignored) so it travels
+with the repository snapshot to the GPU box.
+"""
+import glob
+import hashlib
+import os
+import subprocess
+import sys
+
+CSRC = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(CSRC)
+LIB = os.path.join(PKG, "libvfi_hip.so")
+STAMP = LIB + ".stamp"
+ARCH = "gfx950"
+
+
+def _sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _digest():
+    h = hashlib.sha256()
+    files = _sources() + sorted(glob.glob(os.path.join(CSRC, "*.h")))
+    files.append(os.path.join(PKG, "..", "include", "vfi_hip.h"))
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(f.encode())
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def build_lib(force=False, verbose=True):
+    d = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read().strip() == d:
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    procs = []
+    for src in _sources():
+        obj = os.path.join(CSRC, os.path.basename(src)[:-4] + ".o")
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((subprocess.Popen(cmd), src))
+        objs.append(obj)
+    for p, src in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {src}")
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(d + "\n")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(force="--force" in sys.argv))

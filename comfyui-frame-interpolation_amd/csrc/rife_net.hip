@@ -1,0 +1,404 @@
+// RIFE 4.7 / 4.9 network on the device: weight residency, workspace, launch sequence.
+//
+// Replaces IFNet.forward (vfi_models/rife/rife_arch.py:465-732, arch "4.7") behind the C ABI of
+// include/vfi_hip.h.  Per task (one new frame) the sequence is, for the 4 IFBlocks:
+//   stage_in  (cat + warp + down-resize fused)           -> X
+//   conv0.0, conv0.1 (3x3 stride 2, LeakyReLU)           -> A0, A1      [MFMA]
+//   8 x ResConv (3x3, *beta + x, LeakyReLU)              -> A1 <-> A2   [MFMA]
+//   lastconv (ConvTranspose 4x4 s2, 4 parity groups)     -> T           [MFMA]
+//   flow_up (PixelShuffle + up-resize + flow/mask update) or, for the last block, final_blend.
+#include <cstring>
+
+#include "../../include/vfi_hip.h"
+#include "rife_ops.h"
+
+using namespace vfi;
+
+namespace {
+
+struct DevBuf {
+    float* p = nullptr;
+    size_t n = 0;
+    int ensure(size_t count) {
+        if (count <= n) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+        VFI_CHECK_HIP(hipMalloc((void**)&p, count * sizeof(float)));
+        n = count;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+int upload(DevBuf& b, const std::vector<float>& h) {
+    if (b.ensure(h.size())) return -1;
+    VFI_CHECK_HIP(hipMemcpy(b.p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+struct ConvLayer {
+    DevBuf w, bias, beta;
+    int Cin = 0, Cin_p = 0, Cout = 0, Cout_p = 0;
+};
+
+const int kBlockC[4] = {192, 128, 96, 64};
+const int kBlockIn[4] = {15, 20, 20, 20};
+
+}  // namespace
+
+struct vfi_rife {
+    ConvLayer conv00[4], conv01[4], res[4][8], last[4];
+    DevBuf enc_w0, enc_b0, enc_w1, enc_b1;
+    // geometry
+    int H = 0, W = 0, Hp = 0, Wp = 0, max_batch = 0, n_slots = 0;
+    int scales[4] = {8, 4, 2, 1};
+    // workspace
+    DevBuf Ppool, E, F, M, X, A0, A1, A2, T;
+    DevBuf Fdbg[4], Xdbg[4];
+    bool keep = false;
+    int last_B = 0;
+    size_t pack_stride() const { return (size_t)Hp * Wp * 8; }
+};
+
+static int make_conv3x3(ConvLayer& L, const float* w, const float* b, const float* beta, int Cout, int Cin,
+                        int Cin_p) {
+    L.Cin = Cin;
+    L.Cin_p = Cin_p;
+    L.Cout = Cout;
+    L.Cout_p = round_up(Cout, 32);
+    std::vector<float> wp, bp;
+    pack_conv3x3(w, b, Cout, Cin, Cin_p, L.Cout_p, wp, bp);
+    if (upload(L.w, wp) || upload(L.bias, bp)) return -1;
+    if (beta) {
+        std::vector<float> be(L.Cout_p, 1.f);
+        for (int i = 0; i < Cout; ++i) be[i] = beta[i];
+        if (upload(L.beta, be)) return -1;
+    }
+    return 0;
+}
+
+extern "C" {
+
+vfi_rife_t* vfi_rife_create(int arch_ver_x10, const float* const* tensors, const int64_t* numels, int n_tensors) {
+    if (arch_ver_x10 != 47) {
+        set_error("vfi_rife_create: architecture %d.%d not implemented (4.7 = rife47/rife49 only)", arch_ver_x10 / 10,
+                  arch_ver_x10 % 10);
+        return nullptr;
+    }
+    if (n_tensors != 124) {
+        set_error("vfi_rife_create: expected 124 state_dict tensors for arch 4.7, got %d", n_tensors);
+        return nullptr;
+    }
+    vfi_rife* net = new vfi_rife();
+    int k = 0;
+    auto next = [&](int64_t want) -> const float* {
+        if (k >= n_tensors || numels[k] != want) {
+            set_error("vfi_rife_create: tensor %d has %lld elements, expected %lld", k,
+                      (long long)(k < n_tensors ? numels[k] : -1), (long long)want);
+            return nullptr;
+        }
+        return tensors[k++];
+    };
+    bool ok = true;
+    for (int b = 0; b < 4 && ok; ++b) {
+        const int c = kBlockC[b], cin = kBlockIn[b];
+        const int cin_p = round_up(cin, 8);
+        const float* w = next((int64_t)(c / 2) * cin * 9);
+        const float* bi = w ? next(c / 2) : nullptr;
+        ok = ok && bi && !make_conv3x3(net->conv00[b], w, bi, nullptr, c / 2, cin, cin_p);
+        if (!ok) break;
+        w = next((int64_t)c * (c / 2) * 9);
+        bi = w ? next(c) : nullptr;
+        ok = ok && bi && !make_conv3x3(net->conv01[b], w, bi, nullptr, c, c / 2, c / 2);
+        for (int i = 0; i < 8 && ok; ++i) {
+            const float* beta = next(c);
+            w = beta ? next((int64_t)c * c * 9) : nullptr;
+            bi = w ? next(c) : nullptr;
+            ok = ok && bi && !make_conv3x3(net->res[b][i], w, bi, beta, c, c, c);
+        }
+        if (!ok) break;
+        w = next((int64_t)c * 24 * 16);
+        bi = w ? next(24) : nullptr;
+        ok = ok && bi;
+        if (ok) {
+            ConvLayer& L = net->last[b];
+            L.Cin = L.Cin_p = c;
+            L.Cout = 24;
+            L.Cout_p = 32;
+            std::vector<float> wp, bp;
+            pack_deconv4x4(w, bi, c, 24, c, 32, wp, bp);
+            ok = !upload(L.w, wp) && !upload(L.bias, bp);
+        }
+    }
+    if (ok) {
+        const float* w0 = next(16 * 3 * 9);
+        const float* b0 = w0 ? next(16) : nullptr;
+        const float* w1 = b0 ? next(16 * 4 * 16) : nullptr;
+        const float* b1 = w1 ? next(4) : nullptr;
+        ok = b1 != nullptr;
+        if (ok) {
+            std::vector<float> p0(9 * 48), p1(16 * 64);
+            for (int co = 0; co < 16; ++co)
+                for (int ci = 0; ci < 3; ++ci)
+                    for (int t = 0; t < 9; ++t) p0[t * 48 + ci * 16 + co] = w0[(co * 3 + ci) * 9 + t];
+            for (int ci = 0; ci < 16; ++ci)
+                for (int co = 0; co < 4; ++co)
+                    for (int t = 0; t < 16; ++t) p1[(t * 16 + ci) * 4 + co] = w1[(ci * 4 + co) * 16 + t];
+            std::vector<float> vb0(b0, b0 + 16), vb1(b1, b1 + 4);
+            ok = !upload(net->enc_w0, p0) && !upload(net->enc_b0, vb0) && !upload(net->enc_w1, p1) &&
+                 !upload(net->enc_b1, vb1);
+        }
+    }
+    if (!ok) {
+        vfi_rife_destroy(net);
+        return nullptr;
+    }
+    return net;
+}
+
+void vfi_rife_destroy(vfi_rife_t* net) {
+    if (!net) return;
+    for (int b = 0; b < 4; ++b) {
+        for (ConvLayer* L : {&net->conv00[b], &net->conv01[b], &net->last[b]}) {
+            L->w.release();
+            L->bias.release();
+            L->beta.release();
+        }
+        for (int i = 0; i < 8; ++i) {
+            net->res[b][i].w.release();
+            net->res[b][i].bias.release();
+            net->res[b][i].beta.release();
+        }
+        net->Fdbg[b].release();
+        net->Xdbg[b].release();
+    }
+    for (DevBuf* d : {&net->enc_w0, &net->enc_b0, &net->enc_w1, &net->enc_b1, &net->Ppool, &net->E, &net->F, &net->M,
+                      &net->X, &net->A0, &net->A1, &net->A2, &net->T})
+        d->release();
+    delete net;
+}
+
+int vfi_rife_configure(vfi_rife_t* net, int H, int W, int max_batch, int n_slots, float scale_factor) {
+    VFI_REQUIRE(net, "vfi_rife_configure: null handle");
+    VFI_REQUIRE(H > 0 && W > 0 && max_batch >= 1 && max_batch <= kMaxTasks && n_slots >= 2,
+                "vfi_rife_configure: bad arguments H=%d W=%d max_batch=%d (1..%d) n_slots=%d", H, W, max_batch,
+                kMaxTasks, n_slots);
+    // scale_list = [8,4,2,1] / scale_factor (rife/__init__.py:157-160); integer scales only for now
+    const float base[4] = {8.f, 4.f, 2.f, 1.f};
+    int sc[4];
+    for (int i = 0; i < 4; ++i) {
+        const float s = base[i] / scale_factor;
+        sc[i] = (int)s;
+        VFI_REQUIRE((float)sc[i] == s && (sc[i] == 1 || sc[i] % 2 == 0),
+                    "vfi_rife_configure: scale_factor %g gives non-integer block scale %g (supported: 1.0, 0.5)",
+                    scale_factor, s);
+    }
+    const int Hp = round_up(H, 64), Wp = round_up(W, 64);
+    for (int i = 0; i < 4; ++i)
+        VFI_REQUIRE(Hp % (4 * sc[i]) == 0 && Wp % (4 * sc[i]) == 0,
+                    "vfi_rife_configure: padded size %dx%d not divisible by 4*scale %d (the reference fails here too, "
+                    "SURVEY.md App. C6)", Hp, Wp, sc[i]);
+    net->H = H;
+    net->W = W;
+    net->Hp = Hp;
+    net->Wp = Wp;
+    net->max_batch = max_batch;
+    net->n_slots = n_slots;
+    memcpy(net->scales, sc, sizeof(sc));
+    const size_t full = (size_t)Hp * Wp, B = max_batch;
+    size_t x = 0, a0 = 0, a1 = 0, t = 0;
+    for (int i = 0; i < 4; ++i) {
+        const size_t px = full / ((size_t)sc[i] * sc[i]);
+        const size_t cx = i == 0 ? 16 : 24;
+        x = std::max(x, px * cx);
+        a0 = std::max(a0, px / 4 * (kBlockC[i] / 2));
+        a1 = std::max(a1, px / 16 * kBlockC[i]);
+        t = std::max(t, px / 16 * 128);
+    }
+    if (net->Ppool.ensure(full * 8 * n_slots) || net->E.ensure(full / 4 * 16) || net->F.ensure(B * full * 4) ||
+        net->M.ensure(B * full) || net->X.ensure(B * x) || net->A0.ensure(B * a0) || net->A1.ensure(B * a1) ||
+        net->A2.ensure(B * a1) || net->T.ensure(B * t))
+        return -1;
+    return 0;
+}
+
+int vfi_rife_load_frame(vfi_rife_t* net, int slot, const float* frame_dev, int C, void* stream) {
+    VFI_REQUIRE(net && net->Hp > 0, "vfi_rife_load_frame: network not configured");
+    VFI_REQUIRE(slot >= 0 && slot < net->n_slots && C >= 3, "vfi_rife_load_frame: bad slot %d / channels %d", slot, C);
+    return prep_frame_launch(frame_dev, net->Ppool.p + (size_t)slot * net->pack_stride(), net->E.p, net->enc_w0.p,
+                             net->enc_b0.p, net->enc_w1.p, net->enc_b1.p, net->H, net->W, C, net->Hp, net->Wp,
+                             (hipStream_t)stream);
+}
+
+static void fill_args(ConvArgs& a, const ConvLayer& L, const float* in, int in_cs, float* out, int out_cs, int N,
+                      int Hin, int Win, int stride) {
+    memset(&a, 0, sizeof(a));
+    a.in = in;
+    a.w = L.w.p;
+    a.bias = L.bias.p;
+    a.out = out;
+    a.N = N;
+    a.Hin = Hin;
+    a.Win = Win;
+    a.in_cs = in_cs;
+    a.Hout = Hin / stride;
+    a.Wout = Win / stride;
+    a.out_cs = out_cs;
+    a.Cin_p = L.Cin_p;
+    a.Cout_p = L.Cout_p;
+    a.Cout = L.Cout;
+}
+
+int vfi_rife_interpolate(vfi_rife_t* net, int B, const int* slot0, const int* slot1, const float* timestep,
+                         float* out_dev, void* stream) {
+    VFI_REQUIRE(net && net->Hp > 0, "vfi_rife_interpolate: network not configured");
+    VFI_REQUIRE(B >= 1 && B <= net->max_batch, "vfi_rife_interpolate: batch %d outside 1..%d", B, net->max_batch);
+    hipStream_t st = (hipStream_t)stream;
+    RifeTasks tasks;
+    memset(&tasks, 0, sizeof(tasks));
+    for (int b = 0; b < B; ++b) {
+        VFI_REQUIRE(slot0[b] >= 0 && slot0[b] < net->n_slots && slot1[b] >= 0 && slot1[b] < net->n_slots,
+                    "vfi_rife_interpolate: task %d uses slots %d,%d outside 0..%d", b, slot0[b], slot1[b],
+                    net->n_slots - 1);
+        tasks.slot0[b] = slot0[b];
+        tasks.slot1[b] = slot1[b];
+        tasks.t[b] = timestep[b];
+    }
+    const int Hp = net->Hp, Wp = net->Wp;
+    static const char* kResName[4] = {"resconv_c192", "resconv_c128", "resconv_c96", "resconv_c64"};
+    static const char* kC00Name[4] = {"conv0a_b0", "conv0a_b1", "conv0a_b2", "conv0a_b3"};
+    static const char* kC01Name[4] = {"conv0b_b0", "conv0b_b1", "conv0b_b2", "conv0b_b3"};
+    static const char* kLastName[4] = {"lastconv_b0", "lastconv_b1", "lastconv_b2", "lastconv_b3"};
+    for (int i = 0; i < 4; ++i) {
+        const int s = net->scales[i];
+        const int Hs = Hp / s, Ws = Wp / s;
+        const int c = kBlockC[i];
+        const int CX = i == 0 ? 16 : 24;
+        if (stage_in_launch(net->Ppool.p, net->pack_stride(), tasks, B, net->F.p, net->M.p, net->X.p, Hp, Wp, s, CX,
+                            i > 0, st))
+            return -1;
+        if (net->keep) {
+            const size_t n = (size_t)B * Hs * Ws * CX;
+            if (net->Xdbg[i].ensure(n)) return -1;
+            VFI_CHECK_HIP(hipMemcpyAsync(net->Xdbg[i].p, net->X.p, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+        }
+        ConvArgs a;
+        // conv0.0: 3x3 stride 2 + LeakyReLU(0.2)
+        fill_args(a, net->conv00[i], net->X.p, CX, net->A0.p, c / 2, B, Hs, Ws, 2);
+        conv3x3_taps(a);
+        a.act = 1;
+        a.slope = 0.2f;
+        if (conv_launch(a, 2, false, -1, st, kC00Name[i])) return -1;
+        // conv0.1
+        fill_args(a, net->conv01[i], net->A0.p, c / 2, net->A1.p, c, B, Hs / 2, Ws / 2, 2);
+        conv3x3_taps(a);
+        a.act = 1;
+        a.slope = 0.2f;
+        if (conv_launch(a, 2, false, -1, st, kC01Name[i])) return -1;
+        // 8 x ResConv: lrelu(conv(x)*beta + x)
+        float* cur = net->A1.p;
+        float* nxt = net->A2.p;
+        for (int r = 0; r < 8; ++r) {
+            fill_args(a, net->res[i][r], cur, c, nxt, c, B, Hs / 4, Ws / 4, 1);
+            conv3x3_taps(a);
+            a.beta = net->res[i][r].beta.p;
+            a.res = cur;
+            a.res_cs = c;
+            a.act = 1;
+            a.slope = 0.2f;
+            if (conv_launch(a, 1, false, -1, st, kResName[i])) return -1;
+            std::swap(cur, nxt);
+        }
+        // lastconv: ConvTranspose2d(c,24,4,2,1) as 4 parity groups -> T[.,4,32]
+        fill_args(a, net->last[i], cur, c, net->T.p, 128, B, Hs / 4, Ws / 4, 1);
+        deconv4x4_taps(a);
+        if (conv_launch(a, 1, true, -1, st, kLastName[i])) return -1;
+        if (i < 3) {
+            if (flow_up_launch(net->T.p, net->F.p, net->M.p, B, Hp, Wp, s, i > 0, st)) return -1;
+            if (net->keep) {
+                const size_t n = (size_t)B * Hp * Wp * 4;
+                if (net->Fdbg[i].ensure(n)) return -1;
+                VFI_CHECK_HIP(hipMemcpyAsync(net->Fdbg[i].p, net->F.p, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+            }
+        } else {
+            float* fd = nullptr;
+            if (net->keep) {
+                const size_t n = (size_t)B * Hp * Wp * 4;
+                if (net->Fdbg[i].ensure(n)) return -1;
+                VFI_CHECK_HIP(hipMemsetAsync(net->Fdbg[i].p, 0, n * sizeof(float), st));
+                fd = net->Fdbg[i].p;
+            }
+            if (final_blend_launch(net->Ppool.p, net->pack_stride(), tasks, B, net->T.p, net->F.p, out_dev, fd, net->H,
+                                   net->W, Hp, Wp, s, st))
+                return -1;
+        }
+    }
+    net->last_B = B;
+    return 0;
+}
+
+int vfi_rife_debug_keep(vfi_rife_t* net, int on) {
+    VFI_REQUIRE(net, "null handle");
+    net->keep = on != 0;
+    return 0;
+}
+
+int64_t vfi_rife_debug_read(vfi_rife_t* net, int what, int stage, float* host_buf, int64_t cap) {
+    if (!net) {
+        set_error("null handle");
+        return -1;
+    }
+    const float* src = nullptr;
+    size_t n = 0;
+    if (what == 0 && stage >= 0 && stage < 4) {
+        src = net->Fdbg[stage].p;
+        n = (size_t)net->last_B * net->Hp * net->Wp * 4;
+    } else if (what == 1 && stage >= 0 && stage < 4) {
+        const int s = net->scales[stage];
+        src = net->Xdbg[stage].p;
+        n = (size_t)net->last_B * (net->Hp / s) * (net->Wp / s) * (stage == 0 ? 16 : 24);
+    } else if (what == 2 && stage >= 0 && stage < net->n_slots) {
+        src = net->Ppool.p + (size_t)stage * net->pack_stride();
+        n = net->pack_stride();
+    }
+    if (!src || (int64_t)n > cap) {
+        set_error("vfi_rife_debug_read: nothing kept for what=%d stage=%d (or buffer too small: need %lld)", what, stage,
+                  (long long)n);
+        return -1;
+    }
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host_buf, src, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
+        set_error("vfi_rife_debug_read: copy failed");
+        return -1;
+    }
+    return (int64_t)n;
+}
+
+int vfi_rife_work(vfi_rife_t* net, double* conv_flop_per_task, double* hbm_bytes_per_task) {
+    VFI_REQUIRE(net && net->Hp > 0, "vfi_rife_work: network not configured");
+    const double full = (double)net->Hp * net->Wp;
+    double mac = 0;
+    for (int i = 0; i < 4; ++i) {
+        const double px = full / ((double)net->scales[i] * net->scales[i]);
+        const double c = kBlockC[i];
+        mac += px / 4 * (c / 2) * kBlockIn[i] * 9;   // conv0.0
+        mac += px / 16 * c * (c / 2) * 9;            // conv0.1
+        mac += 8 * px / 16 * c * c * 9;              // ResConv x8
+        mac += px / 16 * c * 24 * 16;                // ConvTranspose2d: in_numel * Cout * k*k
+    }
+    // encode, both frames of the pair (the reference recomputes it per task; rife_arch.py:501-503)
+    mac += 2 * (full / 4 * 16 * 3 * 9 + full / 4 * 16 * 4 * 16);
+    if (conv_flop_per_task) *conv_flop_per_task = 2 * mac;
+    if (hbm_bytes_per_task) {
+        // 14 warps (8 of C=3, 6 of C=4): (2C+2)*4 B per pixel; 11 resizes in+out
+        const double warps = (8 * (2 * 3 + 2) + 6 * (2 * 4 + 2)) * 4.0 * full;
+        *hbm_bytes_per_task = warps;
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,24 @@
+// Launchers of the non-convolution RIFE kernels (rife_ops.hip).
+#pragma once
+#include "vfi_common.h"
+
+namespace vfi {
+
+constexpr int kMaxTasks = 16;  // tasks per launch (kernel-argument table)
+struct RifeTasks {
+    int slot0[kMaxTasks];
+    int slot1[kMaxTasks];
+    float t[kMaxTasks];
+};
+
+int warp_border_launch(const float* in, const float* flow, float* out, int N, int H, int W, int C, hipStream_t s);
+int prep_frame_launch(const float* src, float* P, float* E, const float* w0, const float* b0, const float* w1,
+                      const float* b1, int H, int W, int C, int Hp, int Wp, hipStream_t s);
+int stage_in_launch(const float* Ppool, size_t pack_stride, const RifeTasks& tasks, int B, const float* F,
+                    const float* M, float* X, int Hp, int Wp, int s, int CX, bool has_flow, hipStream_t st);
+int flow_up_launch(const float* T, float* F, float* M, int B, int Hp, int Wp, int s, bool has_prev, hipStream_t st);
+int final_blend_launch(const float* Ppool, size_t pack_stride, const RifeTasks& tasks, int B, const float* T,
+                       const float* F, float* out, float* Fdbg, int H, int W, int Hp, int Wp, int s, hipStream_t st);
+int t_to_nhwc_launch(const float* T, float* out, int N, int Hq, int Wq, int C4, hipStream_t st);
+
+}  // namespace vfi

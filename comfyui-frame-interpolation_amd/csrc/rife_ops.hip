@@ -1,0 +1,495 @@
+// HBM-bound kernels of the RIFE 4.7 hot loop (everything that is not a trunk convolution).
+//
+// Layouts (all fp32, NHWC):
+//   frame pack  P[slot] : [Hp][Wp][8]   ch0-2 = clamp(rgb,0,1) zero-padded to x64, ch3 = 0,
+//                                        ch4-7 = encode(img)  -> one 32-byte read per warp tap
+//                                        serves both the image warp and the feature warp.
+//   flow        F       : [B][Hp][Wp][4] (F01 -> frame0, F23 -> frame1), mask M : [B][Hp][Wp]
+//   stage input X       : [B][Hs][Ws][CX] channel order of the reference's torch.cat
+//   block output T      : [B][Hs/4][Ws/4][4 parity classes][32]  (ConvTranspose2d parity class
+//                         (py,px), channel co of 24; PixelShuffle is resolved when T is read)
+//
+// Reference semantics restated (vfi_models/rife/rife_arch.py): warp :31-70; IFBlock's
+// F.interpolate calls :238-248,263-266; input torch.cat :543-548,629-644; flow/mask update
+// :645,698-699; final blend :721-723,732; encode :414-416.
+#include "rife_ops.h"
+
+namespace vfi {
+
+// ---------------------------------------------------------------------------------------
+// bilinear backward warp in the reference's fp32 expression order
+// ---------------------------------------------------------------------------------------
+struct WarpGeo {
+    int W, H;
+    float stepx, stepy;    // 2/(W-1), 2/(H-1): torch.linspace step
+    float halfw, halfh;    // (W-1)/2, (H-1)/2
+};
+__host__ __device__ static inline WarpGeo make_warp_geo(int W, int H) {
+    WarpGeo g;
+    g.W = W;
+    g.H = H;
+    g.stepx = 2.0f / (float)(W - 1);
+    g.stepy = 2.0f / (float)(H - 1);
+    g.halfw = (float)((W - 1.0) / 2.0);
+    g.halfh = (float)((H - 1.0) / 2.0);
+    return g;
+}
+
+struct Tap4 {
+    int o00, o01, o10, o11;   // pixel indices (y*W+x) of the 4 taps
+    float nw, ne, sw, se;
+};
+
+// torch.linspace(-1,1,n)[i]: start + step*i below the midpoint, end - step*(n-1-i) above it.
+__device__ static inline float lin11(int i, int n, float step) {
+    return i < n / 2 ? __fadd_rn(-1.0f, __fmul_rn(step, (float)i))
+                     : __fsub_rn(1.0f, __fmul_rn(step, (float)(n - 1 - i)));
+}
+
+// grid = base + flow/((size-1)/2); grid_sample(align_corners=True, border):
+//   ix = (g+1)*((size-1)/2), clipped to [0,size-1]; corner weights (1-tx)(1-ty) ...
+__device__ static inline Tap4 warp_taps(const WarpGeo& g, int X, int Y, float fx, float fy) {
+    const float nx = __fadd_rn(lin11(X, g.W, g.stepx), __fdiv_rn(fx, g.halfw));
+    const float ny = __fadd_rn(lin11(Y, g.H, g.stepy), __fdiv_rn(fy, g.halfh));
+    float px = __fmul_rn(__fadd_rn(nx, 1.0f), g.halfw);
+    float py = __fmul_rn(__fadd_rn(ny, 1.0f), g.halfh);
+    px = fminf((float)(g.W - 1), fmaxf(px, 0.0f));
+    py = fminf((float)(g.H - 1), fmaxf(py, 0.0f));
+    const float x0f = floorf(px), y0f = floorf(py);
+    const float w = __fsub_rn(px, x0f), e = __fsub_rn(1.0f, w);
+    const float n = __fsub_rn(py, y0f), s = __fsub_rn(1.0f, n);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const int x1 = x0 + (x0 < g.W - 1 ? 1 : 0), y1 = y0 + (y0 < g.H - 1 ? 1 : 0);
+    Tap4 t;
+    t.o00 = y0 * g.W + x0;
+    t.o01 = y0 * g.W + x1;
+    t.o10 = y1 * g.W + x0;
+    t.o11 = y1 * g.W + x1;
+    t.nw = __fmul_rn(s, e);
+    t.ne = __fmul_rn(s, w);
+    t.sw = __fmul_rn(n, e);
+    t.se = __fmul_rn(n, w);
+    return t;
+}
+
+__device__ static inline float4 lerp4(const float4 a, const float4 b, const float4 c, const float4 d,
+                                      const Tap4& t) {
+    float4 r;
+    r.x = a.x * t.nw + b.x * t.ne + c.x * t.sw + d.x * t.se;
+    r.y = a.y * t.nw + b.y * t.ne + c.y * t.sw + d.y * t.se;
+    r.z = a.z * t.nw + b.z * t.ne + c.z * t.sw + d.z * t.se;
+    r.w = a.w * t.nw + b.w * t.ne + c.w * t.sw + d.w * t.se;
+    return r;
+}
+
+// Sample the 8-channel frame pack: lo = channels 0-3 (rgb,0), hi = channels 4-7 (features).
+template <bool WANT_HI>
+__device__ static inline void sample_pack(const float* __restrict__ P, const Tap4& t, float4& lo, float4& hi) {
+    const float4* p00 = (const float4*)(P + (size_t)t.o00 * 8);
+    const float4* p01 = (const float4*)(P + (size_t)t.o01 * 8);
+    const float4* p10 = (const float4*)(P + (size_t)t.o10 * 8);
+    const float4* p11 = (const float4*)(P + (size_t)t.o11 * 8);
+    lo = lerp4(p00[0], p01[0], p10[0], p11[0], t);
+    if (WANT_HI) hi = lerp4(p00[1], p01[1], p10[1], p11[1], t);
+}
+
+// generic NHWC warp (C arbitrary) — parity-test entry point and building block for other nodes
+__global__ void warp_border_kernel(const float* __restrict__ in, const float* __restrict__ flow,
+                                   float* __restrict__ out, int N, int H, int W, int C) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)N * H * W) return;
+    const int X = idx % W;
+    const int Y = (idx / W) % H;
+    const int n = idx / ((long)W * H);
+    const WarpGeo g = make_warp_geo(W, H);
+    const float2 f = ((const float2*)flow)[idx];
+    const Tap4 t = warp_taps(g, X, Y, f.x, f.y);
+    const float* base = in + (size_t)n * H * W * C;
+    float* o = out + (size_t)idx * C;
+    for (int c = 0; c < C; ++c)
+        o[c] = base[(size_t)t.o00 * C + c] * t.nw + base[(size_t)t.o01 * C + c] * t.ne +
+               base[(size_t)t.o10 * C + c] * t.sw + base[(size_t)t.o11 * C + c] * t.se;
+}
+
+int warp_border_launch(const float* in, const float* flow, float* out, int N, int H, int W, int C,
+                       hipStream_t s) {
+    const long total = (long)N * H * W;
+    TraceScope ts("warp_border", s);
+    hipLaunchKernelGGL(warp_border_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, flow,
+                       out, N, H, W, C);
+    VFI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// frame preparation: clamp, drop alpha, zero-pad to x64            rife_arch.py:476-484
+// ---------------------------------------------------------------------------------------
+__global__ void prep_frame_kernel(const float* __restrict__ src, float* __restrict__ P, int H, int W, int C,
+                                  int Hp, int Wp) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Hp * Wp) return;
+    const int X = idx % Wp, Y = idx / Wp;
+    float4 v = {0.f, 0.f, 0.f, 0.f};
+    if (Y < H && X < W) {
+        const float* s = src + ((size_t)Y * W + X) * C;
+        v.x = fminf(fmaxf(s[0], 0.f), 1.f);
+        v.y = fminf(fmaxf(s[1], 0.f), 1.f);
+        v.z = fminf(fmaxf(s[2], 0.f), 1.f);
+    }
+    *(float4*)(P + (size_t)idx * 8) = v;
+}
+
+// encode.0: Conv2d(3,16,3,stride 2,pad 1), no activation.   weights [tap][ci][co] (uniform -> SGPRs)
+__global__ void encode_conv_kernel(const float* __restrict__ P, const float* __restrict__ w,
+                                   const float* __restrict__ bias, float* __restrict__ E, int Hp, int Wp) {
+    const int He = Hp / 2, We = Wp / 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= He * We) return;
+    const int x = idx % We, y = idx / We;
+    float acc[16];
+#pragma unroll
+    for (int co = 0; co < 16; ++co) acc[co] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = 2 * y - 1 + ky;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = 2 * x - 1 + kx;
+            float4 v = {0.f, 0.f, 0.f, 0.f};
+            if (iy >= 0 && iy < Hp && ix >= 0 && ix < Wp) v = *(const float4*)(P + ((size_t)iy * Wp + ix) * 8);
+            const float* wt = w + (ky * 3 + kx) * 48;
+#pragma unroll
+            for (int co = 0; co < 16; ++co)
+                acc[co] = fmaf(v.z, wt[32 + co], fmaf(v.y, wt[16 + co], fmaf(v.x, wt[co], acc[co])));
+        }
+    }
+    float4* o = (float4*)(E + (size_t)idx * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        o[q] = make_float4(acc[4 * q] + bias[4 * q], acc[4 * q + 1] + bias[4 * q + 1], acc[4 * q + 2] + bias[4 * q + 2],
+                           acc[4 * q + 3] + bias[4 * q + 3]);
+}
+
+// encode.1: ConvTranspose2d(16,4,4,stride 2,pad 1), no activation; one thread = one E pixel = a 2x2
+// output quad (all 4 parities).  weights [ky][kx][ci][co(4)]; result goes to pack channels 4-7.
+__global__ void encode_deconv_kernel(const float* __restrict__ E, const float* __restrict__ w,
+                                     const float* __restrict__ bias, float* __restrict__ P, int Hp, int Wp) {
+    const int He = Hp / 2, We = Wp / 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= He * We) return;
+    const int x = idx % We, y = idx / We;
+    float acc[4][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int co = 0; co < 4; ++co) acc[g][co] = bias[co];
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int iy = y + dy;
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int ix = x + dx;
+            const bool ok = iy >= 0 && iy < He && ix >= 0 && ix < We;
+            const float4* e = (const float4*)(E + ((size_t)(ok ? iy : y) * We + (ok ? ix : x)) * 16);
+            float ev[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 t = e[q];
+                if (!ok) t = make_float4(0.f, 0.f, 0.f, 0.f);
+                ev[4 * q] = t.x;
+                ev[4 * q + 1] = t.y;
+                ev[4 * q + 2] = t.z;
+                ev[4 * q + 3] = t.w;
+            }
+            // parity (py,px) uses input offset dy in {py-1, py} with ky = py + 1 - 2*dy
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                if (dy < py - 1 || dy > py) continue;
+                const int ky = py + 1 - 2 * dy;
+#pragma unroll
+                for (int px = 0; px < 2; ++px) {
+                    if (dx < px - 1 || dx > px) continue;
+                    const int kx = px + 1 - 2 * dx;
+                    const float* wt = w + (ky * 4 + kx) * 64;
+#pragma unroll
+                    for (int ci = 0; ci < 16; ++ci)
+#pragma unroll
+                        for (int co = 0; co < 4; ++co)
+                            acc[py * 2 + px][co] = fmaf(ev[ci], wt[ci * 4 + co], acc[py * 2 + px][co]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int Y = 2 * y + (g >> 1), X = 2 * x + (g & 1);
+        *(float4*)(P + ((size_t)Y * Wp + X) * 8 + 4) = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
+    }
+}
+
+int prep_frame_launch(const float* src, float* P, float* E, const float* w0, const float* b0, const float* w1,
+                      const float* b1, int H, int W, int C, int Hp, int Wp, hipStream_t s) {
+    {
+        TraceScope ts("prep_frame", s);
+        hipLaunchKernelGGL(prep_frame_kernel, dim3(cdiv(Hp * Wp, 256)), dim3(256), 0, s, src, P, H, W, C, Hp, Wp);
+        VFI_CHECK_HIP(hipGetLastError());
+    }
+    {
+        TraceScope ts("encode_conv", s);
+        hipLaunchKernelGGL(encode_conv_kernel, dim3(cdiv(Hp / 2 * (Wp / 2), 128)), dim3(128), 0, s, P, w0, b0, E, Hp, Wp);
+        VFI_CHECK_HIP(hipGetLastError());
+    }
+    {
+        TraceScope ts("encode_deconv", s);
+        hipLaunchKernelGGL(encode_deconv_kernel, dim3(cdiv(Hp / 2 * (Wp / 2), 128)), dim3(128), 0, s, E, w1, b1, P, Hp, Wp);
+        VFI_CHECK_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// stage input: torch.cat(...) + F.interpolate(x, 1/s) (+ interpolate(flow)/s) fused.
+// Down-resizing by an even integer s with align_corners=False samples exactly the centre 2x2 of
+// every s x s cell with weights 1/2, so only those pixels are warped at all.
+// ---------------------------------------------------------------------------------------
+template <bool HAS_FLOW, int NP>
+__global__ __launch_bounds__(128) void stage_in_kernel(const float* __restrict__ Ppool, size_t pack_stride,
+                                                       RifeTasks tasks, const float* __restrict__ F,
+                                                       const float* __restrict__ M, float* __restrict__ Xo, int Hp,
+                                                       int Wp, int s, int CX) {
+    const int Hs = Hp / s, Ws = Wp / s;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Hs * Ws) return;
+    const int b = blockIdx.y;
+    const int xl = idx % Ws, yl = idx / Ws;
+    const float* P0 = Ppool + (size_t)tasks.slot0[b] * pack_stride;
+    const float* P1 = Ppool + (size_t)tasks.slot1[b] * pack_stride;
+    const float tstep = tasks.t[b];
+    const WarpGeo g = make_warp_geo(Wp, Hp);
+    const int off = NP == 1 ? 0 : s / 2 - 1;
+    const float inv_s = 1.0f / (float)s;
+    constexpr int NC = HAS_FLOW ? 20 : 15;
+
+    // torch upsample_bilinear2d order: wy0*(wx0*a + wx1*b) + wy1*(wx0*c + wx1*d), all weights 0.5
+    float r[24], row[NC], o[NC];
+#pragma unroll
+    for (int c = 0; c < 24; ++c) r[c] = 0.f;
+#pragma unroll 1
+    for (int k = 0; k < NP * NP; ++k) {  // rolled on purpose: keeps the gather's register footprint small
+        const int dy = k / NP, dx = k % NP;
+        {
+            const int Y = yl * s + off + dy, X = xl * s + off + dx;
+            const size_t p = (size_t)Y * Wp + X;
+            float4 a_lo, a_hi, b_lo, b_hi;
+            if (HAS_FLOW) {
+                const size_t pb = (size_t)b * Hp * Wp + p;
+                const float4 f = ((const float4*)F)[pb];
+                const Tap4 t0 = warp_taps(g, X, Y, f.x, f.y);
+                const Tap4 t1 = warp_taps(g, X, Y, f.z, f.w);
+                sample_pack<true>(P0, t0, a_lo, a_hi);
+                sample_pack<true>(P1, t1, b_lo, b_hi);
+                o[NC - 5] = M[pb];
+                o[NC - 4] = f.x;
+                o[NC - 3] = f.y;
+                o[NC - 2] = f.z;
+                o[NC - 1] = f.w;
+            } else {
+                const float4* q0 = (const float4*)(P0 + p * 8);
+                const float4* q1 = (const float4*)(P1 + p * 8);
+                a_lo = q0[0];
+                a_hi = q0[1];
+                b_lo = q1[0];
+                b_hi = q1[1];
+            }
+            o[0] = a_lo.x; o[1] = a_lo.y; o[2] = a_lo.z;
+            o[3] = b_lo.x; o[4] = b_lo.y; o[5] = b_lo.z;
+            o[6] = a_hi.x; o[7] = a_hi.y; o[8] = a_hi.z; o[9] = a_hi.w;
+            o[10] = b_hi.x; o[11] = b_hi.y; o[12] = b_hi.z; o[13] = b_hi.w;
+            o[14] = tstep;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) row[c] = dx == 0 ? o[c] : __fadd_rn(0.5f * row[c], 0.5f * o[c]);
+        }
+        if (dx == NP - 1) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) r[c] = dy == 0 ? row[c] : __fadd_rn(0.5f * r[c], 0.5f * row[c]);
+        }
+    }
+    if (HAS_FLOW) {
+#pragma unroll
+        for (int c = 16; c < 20; ++c) r[c] = r[c] * inv_s;  // interpolate(flow) * 1.0 / scale
+    }
+    float4* op = (float4*)(Xo + ((size_t)b * Hs * Ws + idx) * CX);
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+        if (q < CX / 4) op[q] = make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
+}
+
+int stage_in_launch(const float* Ppool, size_t pack_stride, const RifeTasks& tasks, int B, const float* F,
+                    const float* M, float* X, int Hp, int Wp, int s, int CX, bool has_flow, hipStream_t st) {
+    const int Hs = Hp / s, Ws = Wp / s;
+    VFI_REQUIRE(s == 1 || s % 2 == 0, "stage_in: scale %d must be 1 or even", s);
+    VFI_REQUIRE(CX % 4 == 0 && CX >= (has_flow ? 20 : 16) && CX <= 24, "stage_in: bad CX %d", CX);
+    dim3 grid(cdiv(Hs * Ws, 128), B);
+    TraceScope ts(has_flow ? "stage_in_warp" : "stage_in0", st);
+#define VFI_SI(HF, NPV) \
+    hipLaunchKernelGGL((stage_in_kernel<HF, NPV>), grid, dim3(128), 0, st, Ppool, pack_stride, tasks, F, M, X, Hp, Wp, s, CX)
+    if (has_flow) {
+        if (s == 1) VFI_SI(true, 1); else VFI_SI(true, 2);
+    } else {
+        if (s == 1) VFI_SI(false, 1); else VFI_SI(false, 2);
+    }
+#undef VFI_SI
+    VFI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// block output -> full resolution:  tmp = interpolate(PixelShuffle(deconv), x s);
+// flow (+)= tmp[:, :4]*s; mask = tmp[:, 4:5]                       rife_arch.py:262-276,645,698
+// ---------------------------------------------------------------------------------------
+// channel c of the pixel-shuffled tensor at (Yt,Xt), read from the parity-class layout
+__device__ static inline float t_read(const float* __restrict__ Tb, int Wq, int Yt, int Xt, int c) {
+    const int y = Yt >> 2, x = Xt >> 2;
+    const int cls = (Yt >> 1 & 1) * 2 + (Xt >> 1 & 1);
+    const int co = c * 4 + (Yt & 1) * 2 + (Xt & 1);
+    return Tb[((size_t)(y * Wq + x) * 4 + cls) * 32 + co];
+}
+
+struct Bil {
+    int i0, i1;
+    float w0, w1;
+};
+// torch area_pixel_compute_source_index(align_corners=False) + guard_index_and_lambda
+__device__ static inline Bil bil_index(int d, float rscale, int in_size) {
+    float src = __fsub_rn(__fmul_rn(rscale, __fadd_rn((float)d, 0.5f)), 0.5f);
+    if (src < 0.f) src = 0.f;
+    int i0 = (int)floorf(src);
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    float l = __fsub_rn(src, (float)i0);
+    l = fminf(fmaxf(l, 0.f), 1.f);
+    Bil b;
+    b.i0 = i0;
+    b.i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    b.w1 = l;
+    b.w0 = __fsub_rn(1.0f, l);
+    return b;
+}
+
+template <int NCH>
+__device__ static inline void t_upsample(const float* __restrict__ Tb, int Hs, int Ws, int s, int Y, int X,
+                                         float (&val)[NCH]) {
+    const int Wq = Ws / 4;
+    if (s == 1) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) val[c] = t_read(Tb, Wq, Y, X, c);
+        return;
+    }
+    const float rs = 1.0f / (float)s;
+    const Bil by = bil_index(Y, rs, Hs), bx = bil_index(X, rs, Ws);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const float a = t_read(Tb, Wq, by.i0, bx.i0, c), b = t_read(Tb, Wq, by.i0, bx.i1, c);
+        const float cc = t_read(Tb, Wq, by.i1, bx.i0, c), d = t_read(Tb, Wq, by.i1, bx.i1, c);
+        val[c] = __fadd_rn(__fmul_rn(by.w0, __fadd_rn(__fmul_rn(bx.w0, a), __fmul_rn(bx.w1, b))),
+                           __fmul_rn(by.w1, __fadd_rn(__fmul_rn(bx.w0, cc), __fmul_rn(bx.w1, d))));
+    }
+}
+
+template <bool HAS_PREV>
+__global__ void flow_up_kernel(const float* __restrict__ T, float* __restrict__ F, float* __restrict__ M, int Hp,
+                               int Wp, int s) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Hp * Wp) return;
+    const int b = blockIdx.y;
+    const int X = idx % Wp, Y = idx / Wp;
+    const int Hs = Hp / s, Ws = Wp / s;
+    const float* Tb = T + (size_t)b * (Hs / 4) * (Ws / 4) * 128;
+    float val[5];
+    t_upsample<5>(Tb, Hs, Ws, s, Y, X, val);
+    const size_t pb = (size_t)b * Hp * Wp + idx;
+    const float fs = (float)s;
+    float4 f = make_float4(val[0] * fs, val[1] * fs, val[2] * fs, val[3] * fs);
+    if (HAS_PREV) {
+        const float4 o = ((const float4*)F)[pb];
+        f = make_float4(o.x + f.x, o.y + f.y, o.z + f.z, o.w + f.w);
+    }
+    ((float4*)F)[pb] = f;
+    M[pb] = val[4];
+}
+
+int flow_up_launch(const float* T, float* F, float* M, int B, int Hp, int Wp, int s, bool has_prev,
+                   hipStream_t st) {
+    dim3 grid(cdiv(Hp * Wp, 256), B);
+    TraceScope ts("flow_up", st);
+    if (has_prev)
+        hipLaunchKernelGGL(flow_up_kernel<true>, grid, dim3(256), 0, st, T, F, M, Hp, Wp, s);
+    else
+        hipLaunchKernelGGL(flow_up_kernel<false>, grid, dim3(256), 0, st, T, F, M, Hp, Wp, s);
+    VFI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// last stage fused with the output: flow += tmp*s, mask = tmp[4], warp both images,
+// sigmoid blend, crop to HxW, node-level clamp(0,1)            rife_arch.py:703-704,721-723,732
+//                                                               rife/__init__.py:207
+// ---------------------------------------------------------------------------------------
+__global__ void final_blend_kernel(const float* __restrict__ Ppool, size_t pack_stride, RifeTasks tasks,
+                                   const float* __restrict__ T, const float* __restrict__ F, float* __restrict__ out,
+                                   float* __restrict__ Fdbg, int H, int W, int Hp, int Wp, int s) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * W) return;
+    const int b = blockIdx.y;
+    const int X = idx % W, Y = idx / W;
+    const int Hs = Hp / s, Ws = Wp / s;
+    const float* Tb = T + (size_t)b * (Hs / 4) * (Ws / 4) * 128;
+    float val[5];
+    t_upsample<5>(Tb, Hs, Ws, s, Y, X, val);
+    const size_t pb = (size_t)b * Hp * Wp + (size_t)Y * Wp + X;
+    const float fs = (float)s;
+    const float4 o = ((const float4*)F)[pb];
+    const float4 f = make_float4(o.x + val[0] * fs, o.y + val[1] * fs, o.z + val[2] * fs, o.w + val[3] * fs);
+    if (Fdbg) ((float4*)Fdbg)[pb] = f;
+    const WarpGeo g = make_warp_geo(Wp, Hp);
+    const Tap4 t0 = warp_taps(g, X, Y, f.x, f.y);
+    const Tap4 t1 = warp_taps(g, X, Y, f.z, f.w);
+    float4 a, bb, unused;
+    sample_pack<false>(Ppool + (size_t)tasks.slot0[b] * pack_stride, t0, a, unused);
+    sample_pack<false>(Ppool + (size_t)tasks.slot1[b] * pack_stride, t1, bb, unused);
+    const float m = 1.0f / (1.0f + expf(-val[4]));
+    const float om = 1.0f - m;
+    float* op = out + ((size_t)b * H * W + idx) * 3;
+    op[0] = fminf(fmaxf(a.x * m + bb.x * om, 0.f), 1.f);
+    op[1] = fminf(fmaxf(a.y * m + bb.y * om, 0.f), 1.f);
+    op[2] = fminf(fmaxf(a.z * m + bb.z * om, 0.f), 1.f);
+}
+
+int final_blend_launch(const float* Ppool, size_t pack_stride, const RifeTasks& tasks, int B, const float* T,
+                       const float* F, float* out, float* Fdbg, int H, int W, int Hp, int Wp, int s,
+                       hipStream_t st) {
+    dim3 grid(cdiv(H * W, 256), B);
+    TraceScope ts("final_blend", st);
+    hipLaunchKernelGGL(final_blend_kernel, grid, dim3(256), 0, st, Ppool, pack_stride, tasks, T, F, out, Fdbg, H, W,
+                       Hp, Wp, s);
+    VFI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// deconv+PixelShuffle result in plain NHWC [N,4H,4W,C4] from the parity-class layout (test entry)
+__global__ void t_to_nhwc_kernel(const float* __restrict__ T, float* __restrict__ out, int N, int Hq, int Wq, int C4) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Hs = Hq * 4, Ws = Wq * 4;
+    if (idx >= (long)N * Hs * Ws) return;
+    const int X = idx % Ws, Y = (idx / Ws) % Hs;
+    const int n = idx / ((long)Hs * Ws);
+    const float* Tb = T + (size_t)n * Hq * Wq * 128;
+    for (int c = 0; c < C4; ++c) out[idx * C4 + c] = t_read(Tb, Wq, Y, X, c);
+}
+int t_to_nhwc_launch(const float* T, float* out, int N, int Hq, int Wq, int C4, hipStream_t st) {
+    const long total = (long)N * Hq * 4 * Wq * 4;
+    hipLaunchKernelGGL(t_to_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, T, out, N, Hq, Wq, C4);
+    VFI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace vfi

@@ -1,0 +1,125 @@
+// Error string, device selection and per-kernel event tracing for libvfi_hip.so.
+#include "vfi_common.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+
+#include "../../include/vfi_hip.h"
+
+namespace vfi {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char* get_error() { return g_err; }
+
+struct TraceRec {
+    const char* name;
+    hipEvent_t e0, e1;
+};
+static bool g_trace = false;
+static std::vector<TraceRec> g_recs;
+static std::vector<hipEvent_t> g_free_events;
+
+static hipEvent_t get_event() {
+    if (!g_free_events.empty()) {
+        hipEvent_t e = g_free_events.back();
+        g_free_events.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+bool trace_on() { return g_trace; }
+void trace_begin(const char* name, hipStream_t s) {
+    TraceRec r;
+    r.name = name;
+    r.e0 = get_event();
+    r.e1 = get_event();
+    (void)hipEventRecord(r.e0, s);
+    g_recs.push_back(r);
+}
+void trace_end(hipStream_t s) {
+    if (!g_recs.empty()) (void)hipEventRecord(g_recs.back().e1, s);
+}
+
+}  // namespace vfi
+
+using namespace vfi;
+
+extern "C" {
+
+int vfi_init(int device) {
+    int n = 0;
+    VFI_CHECK_HIP(hipGetDeviceCount(&n));
+    VFI_REQUIRE(device >= 0 && device < n, "vfi_init: device %d out of range (%d visible)", device, n);
+    VFI_CHECK_HIP(hipSetDevice(device));
+    return 0;
+}
+
+const char* vfi_last_error(void) { return get_error(); }
+
+int vfi_device_info(char* arch_buf, int arch_buf_len, int* n_cus) {
+    int dev = 0;
+    VFI_CHECK_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t p;
+    VFI_CHECK_HIP(hipGetDeviceProperties(&p, dev));
+    if (arch_buf && arch_buf_len > 0) {
+        strncpy(arch_buf, p.gcnArchName, arch_buf_len - 1);
+        arch_buf[arch_buf_len - 1] = 0;
+    }
+    if (n_cus) *n_cus = p.multiProcessorCount;
+    return 0;
+}
+
+int vfi_trace_enable(int on) {
+    g_trace = on != 0;
+    return 0;
+}
+
+int vfi_trace_reset(void) {
+    for (auto& r : g_recs) {
+        g_free_events.push_back(r.e0);
+        g_free_events.push_back(r.e1);
+    }
+    g_recs.clear();
+    return 0;
+}
+
+int vfi_trace_report(char* buf, int buf_len) {
+    std::map<std::string, std::pair<int, double>> agg;
+    std::vector<std::string> order;
+    for (auto& r : g_recs) {
+        VFI_CHECK_HIP(hipEventSynchronize(r.e1));
+        float ms = 0.f;
+        VFI_CHECK_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
+        auto it = agg.find(r.name);
+        if (it == agg.end()) {
+            agg[r.name] = {1, (double)ms};
+            order.push_back(r.name);
+        } else {
+            it->second.first += 1;
+            it->second.second += ms;
+        }
+    }
+    std::string out;
+    char line[256];
+    for (auto& k : order) {
+        snprintf(line, sizeof(line), "%s %d %.6f\n", k.c_str(), agg[k].first, agg[k].second);
+        out += line;
+    }
+    VFI_REQUIRE((int)out.size() + 1 <= buf_len, "vfi_trace_report: buffer too small (%d needed)", (int)out.size() + 1);
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,94 @@
+// Internal helpers shared by the HIP translation units of libvfi_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+namespace vfi {
+
+void set_error(const char* fmt, ...);
+const char* get_error();
+
+#define VFI_CHECK_HIP(expr)                                                                   \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            ::vfi::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                             __LINE__);                                                       \
+            return -1;                                                                        \
+        }                                                                                     \
+    } while (0)
+
+#define VFI_REQUIRE(cond, ...)          \
+    do {                                \
+        if (!(cond)) {                  \
+            ::vfi::set_error(__VA_ARGS__); \
+            return -2;                  \
+        }                               \
+    } while (0)
+
+// ---- per-kernel event tracing ---------------------------------------------------------
+bool trace_on();
+void trace_begin(const char* name, hipStream_t s);
+void trace_end(hipStream_t s);
+
+struct TraceScope {
+    hipStream_t s;
+    bool on;
+    TraceScope(const char* name, hipStream_t st) : s(st), on(trace_on()) {
+        if (on) trace_begin(name, s);
+    }
+    ~TraceScope() {
+        if (on) trace_end(s);
+    }
+};
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
+
+// ---- convolution on the fp32 matrix cores -----------------------------------------------
+// A convolution "group" is a set of taps sharing one weight block; a plain 3x3 conv has one
+// group of 9 taps, the 4x4/stride-2 transposed conv has 4 groups (output parities) of 4 taps.
+struct ConvArgs {
+    const float* in;    // [N,Hin,Win,in_cs] (channels >= Cin_p readable, zero beyond Cin)
+    const float* w;     // packed [group][tap][Cin_p/8][Cout_p][8]
+    const float* bias;  // [group][Cout_p]
+    const float* beta;  // [Cout_p] or nullptr       y = act((conv+bias)*beta + res)
+    const float* res;   // [N,Hout,Wout,res_cs] or nullptr
+    float* out;         // [N,Hout,Wout,out_cs]; group g writes channels [g*Cout_p, g*Cout_p+Cout)
+    int N, Hin, Win, in_cs;
+    int Hout, Wout, out_cs, res_cs;
+    int Cin_p, Cout_p, Cout;
+    int ntaps;
+    int act;      // 0 none, 1 leaky relu
+    float slope;
+    int tiles_x, tiles_y;  // output tiles per image (filled by the launcher)
+    int tap_y0, tap_x0;    // origin of the tap rectangle (3x3: -1,-1), ignored for grouped
+};
+
+struct ConvVariant {
+    const char* name;
+    int stride, taps, mt, nt, wm, wn, ck, grouped;
+};
+int conv_num_variants();
+const ConvVariant& conv_variant(int i);
+// Launch; variant < 0 selects by heuristic.  grouped convs must use a grouped variant.
+int conv_pick_variant(const ConvArgs& a, int stride, bool grouped);
+int conv_launch(const ConvArgs& a, int stride, bool grouped, int variant, hipStream_t s,
+                const char* trace_name);
+
+// Host-side weight packing.  w_oihw: [Cout][Cin][3][3] -> packed (1 group, 9 taps).
+void pack_conv3x3(const float* w_oihw, const float* bias, int Cout, int Cin, int Cin_p,
+                  int Cout_p, std::vector<float>& wp, std::vector<float>& bp);
+// w_iohw: [Cin][Cout][4][4] (ConvTranspose2d, stride 2, pad 1) -> 4 groups x 4 taps, Cout_p = 32k.
+void pack_deconv4x4(const float* w_iohw, const float* bias, int Cin, int Cout, int Cin_p,
+                    int Cout_p, std::vector<float>& wp, std::vector<float>& bp);
+void conv3x3_taps(ConvArgs& a);
+void deconv4x4_taps(ConvArgs& a);
+
+int conv_naive_launch(const float* in, const float* w_oihw_dev, const float* bias_dev,
+                      const float* beta_dev, float* out, int N, int H, int W, int Cin, int in_cs,
+                      int Cout, int stride, int act, float slope, hipStream_t s);
+
+}  // namespace vfi

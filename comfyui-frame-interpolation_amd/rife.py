@@ -1,0 +1,238 @@
+"""RIFE VFI node — host-side mirror of the reference's ``RIFE_VFI`` over the HIP library.
+
+Same class shape, widgets, call signature, output ordering and dtype as
+vfi_models/rife/__init__.py:34-239 of the reference; the per-task hot loop
+(``IFNet.forward`` + clamp) runs in libvfi_hip.so.  torch is used for what the prompt calls
+plumbing: host<->device copies, the stream, and (multi-GPU) torch.distributed.
+
+Differences that do not change results:
+  * ``encode`` is evaluated once per input frame and cached on the device, not once per task;
+  * ``fast_mode`` / ``ensemble`` are accepted and ignored — for arch 4.7 the reference's own call
+    binds them to parameters that are inert (positional mis-binding, rife/__init__.py:200-207);
+  * ``torch_compile`` is ignored (kernels are ahead-of-time compiled), ``dtype`` other than
+    float32 warns and computes in float32 (the parity contract is fp32, |d| <= 1e-3).
+"""
+import ctypes as C
+import pathlib
+import typing
+import warnings
+
+import torch
+from packaging import version
+
+from . import _lib
+from .ckpt import load_file_from_github_release
+from .dist import all_gather_frames, world
+from .rife_spec import CKPT_NAME_VER_DICT, SUPPORTED_ARCH, check_state_dict, rife47_keys
+from .schedule import InterpolationStateList, rife_output_plan, rife_task_list, shard_tasks
+
+MODEL_TYPE = "rife"
+DTYPE_OPTIONS = ["float32", "float16", "bfloat16"]
+MAX_LIB_BATCH = 16  # kMaxTasks in csrc/rife_ops.h
+
+
+class RifeEngine:
+    """Device-resident RIFE 4.7 network + frame cache behind the C ABI."""
+
+    def __init__(self, state_dict, arch_ver="4.7", device=None):
+        if arch_ver not in SUPPORTED_ARCH:
+            raise NotImplementedError(
+                f"RIFE architecture {arch_ver} is not implemented on the HIP path yet (supported: {SUPPORTED_ARCH})")
+        if not torch.cuda.is_available():
+            raise RuntimeError("RIFE VFI (HIP): no GPU visible; this node has no CPU fallback")
+        self.lib = _lib.load()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        _lib.check(self.lib.vfi_init(self.device.index or 0), "vfi_init")
+        check_state_dict(state_dict)
+        keys = rife47_keys()
+        tensors = [state_dict[k].detach().to("cpu", torch.float32).contiguous() for k in keys]
+        ptrs = (C.c_void_p * len(keys))(*[t.data_ptr() for t in tensors])
+        numels = (C.c_int64 * len(keys))(*[t.numel() for t in tensors])
+        self.handle = self.lib.vfi_rife_create(47, ptrs, numels, len(keys))
+        if not self.handle:
+            raise RuntimeError("vfi_rife_create failed: " + _lib.last_error())
+        self.cfg = None
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.vfi_rife_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def configure(self, H, W, max_batch=1, n_slots=4, scale_factor=1.0):
+        cfg = (H, W, max_batch, n_slots, float(scale_factor))
+        if cfg != self.cfg:
+            torch.cuda.synchronize(self.device)
+            _lib.check(self.lib.vfi_rife_configure(self.handle, H, W, max_batch, n_slots, float(scale_factor)),
+                       "vfi_rife_configure")
+            self.cfg = cfg
+
+    def load_frame(self, slot, frame_dev):
+        """frame_dev: [H,W,C] fp32 device tensor (C >= 3)."""
+        assert frame_dev.is_cuda and frame_dev.dtype == torch.float32 and frame_dev.is_contiguous()
+        assert tuple(frame_dev.shape[:2]) == self.cfg[:2], (frame_dev.shape, self.cfg)
+        _lib.check(self.lib.vfi_rife_load_frame(self.handle, slot, frame_dev.data_ptr(), frame_dev.shape[2],
+                                                _lib.stream_ptr()), "vfi_rife_load_frame")
+
+    def interpolate(self, slot0, slot1, timesteps, out_dev):
+        """out_dev[b] = clamp(IFNet(frame[slot0[b]], frame[slot1[b]], t[b]), 0, 1);  out_dev [B,H,W,3]."""
+        B = len(timesteps)
+        assert out_dev.is_cuda and out_dev.dtype == torch.float32 and out_dev.is_contiguous()
+        assert tuple(out_dev.shape) == (B, self.cfg[0], self.cfg[1], 3)
+        s0 = (C.c_int * B)(*slot0)
+        s1 = (C.c_int * B)(*slot1)
+        ts = (C.c_float * B)(*[float(t) for t in timesteps])
+        _lib.check(self.lib.vfi_rife_interpolate(self.handle, B, s0, s1, ts, out_dev.data_ptr(), _lib.stream_ptr()),
+                   "vfi_rife_interpolate")
+
+    def work_per_task(self):
+        fl, by = C.c_double(), C.c_double()
+        _lib.check(self.lib.vfi_rife_work(self.handle, C.byref(fl), C.byref(by)), "vfi_rife_work")
+        return fl.value, by.value
+
+    # -- test taps -----------------------------------------------------------------------
+    def debug_keep(self, on=True):
+        _lib.check(self.lib.vfi_rife_debug_keep(self.handle, int(on)), "vfi_rife_debug_keep")
+
+    def debug_read(self, what, stage, numel):
+        buf = torch.empty(numel, dtype=torch.float32)
+        n = self.lib.vfi_rife_debug_read(self.handle, what, stage, buf.data_ptr(), numel)
+        if n < 0:
+            raise RuntimeError("vfi_rife_debug_read: " + _lib.last_error())
+        return buf[:n]
+
+
+class _FrameSlots:
+    """Device frame cache: frame index -> slot, evicting frames no longer needed."""
+
+    def __init__(self, engine, frames_cpu, n_slots):
+        self.engine, self.frames, self.n_slots = engine, frames_cpu, n_slots
+        self.slot_of = {}
+        self.free = list(range(n_slots))
+
+    def ensure(self, needed):
+        needed = list(dict.fromkeys(needed))
+        missing = [f for f in needed if f not in self.slot_of]
+        if len(missing) > len(self.free):  # recycle slots of frames this batch does not use
+            for f in [f for f in self.slot_of if f not in needed]:
+                self.free.append(self.slot_of.pop(f))
+        if len(missing) > len(self.free):
+            raise RuntimeError("frame cache too small for this batch")
+        for f in missing:
+            slot = self.free.pop()
+            # same stream as the library's launches, so slot reuse is ordered behind earlier readers
+            dev = self.frames[f].to(self.engine.device, dtype=torch.float32).contiguous()
+            self.engine.load_frame(slot, dev)
+            self.slot_of[f] = slot
+        return self.slot_of
+
+
+# (ckpt_name) -> RifeEngine; the reference caches by (ckpt, dtype, torch_compile), rife/__init__.py:31
+_model_cache: typing.Dict[typing.Tuple, RifeEngine] = {}
+
+
+def run_tasks(engine, frames_cpu, tasks, batch_size, scale_factor=1.0, out_device=False):
+    """Interpolate ``tasks`` = [(pair, t), ...] over CPU frames [N,H,W,C]; returns [len(tasks),H,W,3]
+    (CPU tensor, or device tensor when ``out_device``)."""
+    n, H, W, _ = frames_cpu.shape
+    bs = max(1, min(int(batch_size), MAX_LIB_BATCH))
+    n_slots = 2 * bs + 2
+    engine.configure(H, W, bs, n_slots, scale_factor)
+    slots = _FrameSlots(engine, frames_cpu, n_slots)
+    dev = engine.device
+    out = torch.empty((len(tasks), H, W, 3), dtype=torch.float32, device=dev if out_device else "cpu")
+    pos = 0
+    while pos < len(tasks):
+        bt = tasks[pos:pos + bs]
+        need = []
+        for p, _ in bt:
+            need += [p, p + 1]
+        m = slots.ensure(need)
+        buf = out[pos:pos + len(bt)] if out_device else torch.empty((len(bt), H, W, 3), dtype=torch.float32, device=dev)
+        engine.interpolate([m[p] for p, _ in bt], [m[p + 1] for p, _ in bt], [t for _, t in bt], buf)
+        if not out_device:
+            out[pos:pos + len(bt)] = buf.cpu()
+        pos += len(bt)
+    return out
+
+
+class RIFE_VFI:
+    @classmethod
+    def INPUT_TYPES(s):
+        return {
+            "required": {
+                "ckpt_name": (
+                    sorted(list(CKPT_NAME_VER_DICT.keys()),
+                           key=lambda ckpt_name: version.parse(CKPT_NAME_VER_DICT[ckpt_name])),
+                    {"default": "rife49.pth"},
+                ),
+                "frames": ("IMAGE",),
+                "clear_cache_after_n_frames": ("INT", {"default": 10, "min": 1, "max": 1000}),
+                "multiplier": ("INT", {"default": 2, "min": 1}),
+                "fast_mode": ("BOOLEAN", {"default": True}),
+                "ensemble": ("BOOLEAN", {"default": True}),
+                "scale_factor": ([0.25, 0.5, 1.0, 2.0, 4.0], {"default": 1.0}),
+                "dtype": (DTYPE_OPTIONS, {"default": "float32"}),
+                "torch_compile": ("BOOLEAN", {"default": False,
+                                              "tooltip": "Ignored on the HIP path: kernels are compiled ahead of time."}),
+                "batch_size": ("INT", {"default": 1, "min": 1, "max": 64,
+                                       "tooltip": "Number of interpolation tasks per GPU call."}),
+            },
+            "optional": {"optional_interpolation_states": ("INTERPOLATION_STATES",)},
+        }
+
+    RETURN_TYPES = ("IMAGE",)
+    FUNCTION = "vfi"
+    CATEGORY = "ComfyUI-Frame-Interpolation/VFI"
+
+    def vfi(
+        self,
+        ckpt_name: typing.AnyStr,
+        frames: torch.Tensor,
+        clear_cache_after_n_frames: int = 10,
+        multiplier: typing.SupportsInt = 2,
+        fast_mode: bool = False,
+        ensemble: bool = False,
+        scale_factor: float = 1.0,
+        dtype: str = "float32",
+        torch_compile: bool = False,
+        batch_size: int = 1,
+        optional_interpolation_states: InterpolationStateList = None,
+        **kwargs,
+    ):
+        arch_ver = CKPT_NAME_VER_DICT[ckpt_name]
+        if dtype not in DTYPE_OPTIONS:
+            raise KeyError(dtype)
+        if dtype != "float32":
+            warnings.warn(f"RIFE VFI (HIP): dtype={dtype} requested; this path computes in float32.")
+        cache_key = (ckpt_name,)
+        if cache_key not in _model_cache:
+            model_path = load_file_from_github_release(MODEL_TYPE, ckpt_name)
+            sd = torch.load(model_path, map_location="cpu", weights_only=False)
+            _model_cache[cache_key] = RifeEngine(sd, arch_ver)
+            print(f"Comfy-VFI: Loaded and cached model {ckpt_name} (HIP, float32)")
+        engine = _model_cache[cache_key]
+
+        frames = frames[..., :3]  # preprocess_frames: drop alpha; layout stays NHWC on this path
+        n = len(frames)
+        _, tasks = rife_task_list(n, multiplier, optional_interpolation_states)
+        rank, ws = world()
+        if ws > 1:
+            lo, hi = shard_tasks(tasks, rank, ws)
+            counts = [shard_tasks(tasks, r, ws)[1] - shard_tasks(tasks, r, ws)[0] for r in range(ws)]
+            local = run_tasks(engine, frames, tasks[lo:hi], batch_size, scale_factor, out_device=True)
+            new_frames = all_gather_frames(local, counts).cpu()
+        else:
+            new_frames = run_tasks(engine, frames, tasks, batch_size, scale_factor)
+
+        plan = rife_output_plan(n, tasks)
+        out = torch.empty((len(plan),) + tuple(frames.shape[1:]), dtype=torch.float32)
+        for i, (kind, idx) in enumerate(plan):
+            out[i] = frames[idx] if kind == "src" else new_frames[idx]
+        print(f"Comfy-VFI done! {len(plan)} frames generated")
+        return (out,)

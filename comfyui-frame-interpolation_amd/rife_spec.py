@@ -1,0 +1,72 @@
+"""Checkpoint layout of the RIFE "4.7" architecture family (rife47.pth / rife49.pth).
+
+This is the contract between a reference checkpoint (a plain ``state_dict``
+pickle, loaded by ``torch.load`` in vfi_models/rife/__init__.py:131-132) and the
+HIP library: the tensors are handed to ``vfi_rife_create`` in exactly the order
+returned by :func:`rife47_keys`, each in the reference's own memory layout
+(Conv2d ``[Cout,Cin,kh,kw]``, ConvTranspose2d ``[Cin,Cout,kh,kw]``).
+
+Shapes follow vfi_models/rife/rife_arch.py:409-416 (IFNet.__init__, arch "4.7")
+and :176-218 (IFBlock.__init__); the key order is torch's ``state_dict`` order
+for those modules (own parameters before children, so ``beta`` precedes
+``conv.weight``).
+"""
+from collections import OrderedDict
+
+# rife/__init__.py:10-20 — checkpoint file name -> architecture version.
+CKPT_NAME_VER_DICT = {
+    "rife47.pth": "4.7",
+    "rife49.pth": "4.7",
+    "rife417.pth": "4.17",
+    "rife426.pth": "4.26",
+    "sudo_rife4_269.662_testV1_scale1.pth": "4.0",
+}
+# architectures the HIP path implements so far
+SUPPORTED_ARCH = ("4.7",)
+
+# (in_planes, c) per IFBlock, rife_arch.py:410-413
+RIFE47_BLOCKS = ((7 + 8, 192), (8 + 4 + 8, 128), (8 + 4 + 8, 96), (8 + 4 + 8, 64))
+N_RESCONV = 8
+LASTCONV_OUT = 4 * 6  # ConvTranspose2d(c, 4*6, 4, 2, 1) + PixelShuffle(2), rife_arch.py:215-218
+
+
+def rife47_shapes():
+    """OrderedDict key -> shape, in reference ``state_dict`` order (124 tensors)."""
+    d = OrderedDict()
+    for b, (cin, c) in enumerate(RIFE47_BLOCKS):
+        p = f"block{b}."
+        d[p + "conv0.0.0.weight"] = (c // 2, cin, 3, 3)
+        d[p + "conv0.0.0.bias"] = (c // 2,)
+        d[p + "conv0.1.0.weight"] = (c, c // 2, 3, 3)
+        d[p + "conv0.1.0.bias"] = (c,)
+        for i in range(N_RESCONV):
+            q = p + f"convblock.{i}."
+            d[q + "beta"] = (1, c, 1, 1)
+            d[q + "conv.weight"] = (c, c, 3, 3)
+            d[q + "conv.bias"] = (c,)
+        d[p + "lastconv.0.weight"] = (c, LASTCONV_OUT, 4, 4)
+        d[p + "lastconv.0.bias"] = (LASTCONV_OUT,)
+    d["encode.0.weight"] = (16, 3, 3, 3)
+    d["encode.0.bias"] = (16,)
+    d["encode.1.weight"] = (16, 4, 4, 4)
+    d["encode.1.bias"] = (4,)
+    return d
+
+
+def rife47_keys():
+    return list(rife47_shapes().keys())
+
+
+def check_state_dict(sd):
+    """Strict key/shape check, same failure mode as ``load_state_dict(strict=True)``."""
+    want = rife47_shapes()
+    missing = [k for k in want if k not in sd]
+    unexpected = [k for k in sd if k not in want]
+    if missing or unexpected:
+        raise RuntimeError(
+            "Error(s) in loading state_dict for IFNet(4.7): "
+            f"Missing key(s): {missing}. Unexpected key(s): {unexpected}.")
+    for k, shp in want.items():
+        if tuple(sd[k].shape) != tuple(shp):
+            raise RuntimeError(
+                f"size mismatch for {k}: checkpoint {tuple(sd[k].shape)} vs model {tuple(shp)}")

@@ -1,0 +1,77 @@
+"""Deterministic synthetic checkpoints and frames (no network, no checkpoints on disk).
+
+Used by tests, ``bench.py`` and ``__graft_entry__.smoke()``.  Every tensor is
+drawn from its own generator seeded by ``(seed, crc32(key))`` so the values do
+not depend on module construction order: the same dict can be produced on the
+GPU box (no reference there) and loaded into the reference ``IFNet`` here
+(``load_state_dict(strict=True)``) when golden vectors are generated.
+
+Magnitudes mirror torch's default Conv2d / ConvTranspose2d init
+(U(-1/sqrt(fan_in), 1/sqrt(fan_in)), fan_in taken over dims 1.. of the weight),
+which the survey measured to give |flow| of a few pixels per stage — enough to
+exercise the warp path.
+"""
+import zlib
+import math
+import torch
+
+from .rife_spec import rife47_shapes
+
+
+def _gen(seed, key):
+    g = torch.Generator(device="cpu")
+    g.manual_seed((int(seed) * 1000003 + zlib.crc32(key.encode())) & 0x7FFFFFFF)
+    return g
+
+
+def synth_state_dict(shapes, seed=1234):
+    sd = {}
+    last_fan_in = 1
+    for k, shp in shapes.items():
+        g = _gen(seed, k)
+        if k.endswith("beta"):
+            t = 1.0 + 0.25 * (torch.rand(shp, generator=g) * 2 - 1)
+        elif k.endswith("weight"):
+            fan_in = 1
+            for d in shp[1:]:
+                fan_in *= d
+            last_fan_in = fan_in
+            b = 1.0 / math.sqrt(fan_in)
+            t = (torch.rand(shp, generator=g) * 2 - 1) * b
+        else:  # bias
+            b = 1.0 / math.sqrt(last_fan_in)
+            t = (torch.rand(shp, generator=g) * 2 - 1) * b
+        sd[k] = t.to(torch.float32).contiguous()
+    return sd
+
+
+def rife47_synth_state_dict(seed=1234):
+    return synth_state_dict(rife47_shapes(), seed)
+
+
+def smooth_frames(n, h, w, seed=0, shift=3.0, c=3):
+    """[n,h,w,c] f32 in [0,1]: low-pass noise drifting ``shift`` px/frame (ComfyUI IMAGE layout)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    pad = int(abs(shift) * n) + 8
+    hh, ww = h + 2 * pad, w + 2 * pad
+    base = torch.rand(1, c, hh // 8 + 2, ww // 8 + 2, generator=g)
+    base = torch.nn.functional.interpolate(base, size=(hh, ww), mode="bicubic", align_corners=False)
+    fine = torch.rand(1, c, hh, ww, generator=g) * 0.15
+    img = (base * 0.85 + fine).clamp(0, 1)
+    out = []
+    for i in range(n):
+        dx = shift * i
+        ix = int(math.floor(dx))
+        fx = dx - ix
+        a = img[0, :, pad + ix // 2 : pad + ix // 2 + h, pad + ix : pad + ix + w]
+        b = img[0, :, pad + ix // 2 : pad + ix // 2 + h, pad + ix + 1 : pad + ix + 1 + w]
+        out.append(((1 - fx) * a + fx * b).permute(1, 2, 0))
+    return torch.stack(out).contiguous().to(torch.float32)
+
+
+def noise_frames(n, h, w, seed=0, c=3):
+    """[n,h,w,c] f32 i.i.d. U[0,1) — BASELINE.md's worst-case-gradient input."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    return torch.rand(n, h, w, c, generator=g, dtype=torch.float32)

@@ -1,0 +1,120 @@
+/*
+ * vfi_hip.h — C ABI of libvfi_hip.so, the MI355X (gfx950) frame-interpolation hot path.
+ *
+ * Drop-in boundary: this is what the reference's Python node layer would bind (ctypes) in
+ * place of its torch.nn / cupy / taichi calls.  Plain pointers and sizes only — no torch
+ * types.  All tensors are fp32.  "dev" pointers are device (HBM) addresses, e.g.
+ * torch.Tensor.data_ptr() of a CUDA/HIP tensor; `stream` is a hipStream_t passed as void*
+ * (NULL = the default stream).  Every function returns 0 on success, non-zero on error with
+ * a message available from vfi_last_error().  Launches are asynchronous on `stream`.
+ *
+ * Layout convention: images and activations are NHWC ("channels last"), which is also the
+ * layout of ComfyUI's IMAGE type ([N,H,W,C], reference vfi_utils.py:139-143) — the
+ * reference's NHWC->NCHW einops views disappear on this path.
+ *
+ * Each entry point cites the reference code it replaces (paths relative to the reference
+ * checkout, /root/reference in the build container).
+ */
+#ifndef VFI_HIP_H
+#define VFI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- library ------------------------------------------------------------------------- */
+
+/* Select the HIP device for the calling thread/process (one process per GPU).
+ * Replaces comfy.model_management.get_torch_device() use at vfi_models/rife/__init__.py:121. */
+int vfi_init(int device);
+const char* vfi_last_error(void);
+/* "gfx950" etc. of the active device, plus CU count. */
+int vfi_device_info(char* arch_buf, int arch_buf_len, int* n_cus);
+
+/* Per-kernel event tracing (bench.py roofline leg).  When enabled, every kernel launch made
+ * by the library is bracketed by hipEventRecord on its stream.  vfi_trace_report() waits for
+ * the recorded events and writes one line per kernel name: "<name> <calls> <total_ms>\n". */
+int vfi_trace_enable(int on);
+int vfi_trace_reset(void);
+int vfi_trace_report(char* buf, int buf_len);
+
+/* ---- single-op entry points (parity tests, reuse by other nodes) ----------------------- */
+
+/* RIFE backward warp: bilinear, padding_mode="border", align_corners=True, in the reference's
+ * fp32 expression order (normalise -> grid_sample un-normalise round trip).
+ * Replaces warp() at vfi_models/rife/rife_arch.py:31-70.
+ *   in   [N,H,W,C]   flow [N,H,W,2] (x,y displacement in pixels)   out [N,H,W,C] */
+int vfi_warp_border(const float* in_dev, const float* flow_dev, float* out_dev,
+                    int N, int H, int W, int C, void* stream);
+
+/* Generic NHWC convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32).
+ * Replaces torch.nn.Conv2d(k=3,pad=1,stride=1|2) (+ LeakyReLU / ResConv epilogue):
+ *   vfi_models/rife/rife_arch.py:73-107 (conv), :20-28 (ResConv).
+ *   weight: reference layout [Cout,Cin,3,3] (host pointer, repacked internally per call —
+ *           test/utility entry; the model handles pre-pack at vfi_rife_create).
+ *   in  [N,H,W,Cin]  out [N,Ho,Wo,Cout]   Ho = (H+2-3)/stride+1
+ *   beta (host, [Cout]) may be NULL; if given: y = lrelu(conv*beta + in) (requires Cin==Cout, stride 1)
+ *   act: 0 none, 1 LeakyReLU(slope)
+ *   variant: -1 = heuristic, >=0 selects a tile configuration (see csrc/conv_mfma.hip). */
+int vfi_conv3x3(const float* in_dev, const float* weight_host, const float* bias_host,
+                const float* beta_host, float* out_dev, int N, int H, int W, int Cin, int Cout,
+                int stride, int act, float slope, int variant, void* stream);
+
+/* Same contract, straightforward one-thread-per-output FMA kernel (cross-check of the MFMA path). */
+int vfi_conv3x3_naive(const float* in_dev, const float* weight_host, const float* bias_host,
+                      const float* beta_host, float* out_dev, int N, int H, int W, int Cin,
+                      int Cout, int stride, int act, float slope, void* stream);
+
+/* ConvTranspose2d(Cin, Cout, 4, stride 2, pad 1) followed by PixelShuffle(2), output NHWC
+ * [N,4H,4W,Cout/4].  Replaces IFBlock.lastconv, vfi_models/rife/rife_arch.py:215-218.
+ *   weight: reference layout [Cin,Cout,4,4] (host). */
+int vfi_deconv4x4_ps2(const float* in_dev, const float* weight_host, const float* bias_host,
+                      float* out_dev, int N, int H, int W, int Cin, int Cout, void* stream);
+
+/* ---- RIFE 4.7 / 4.9 model --------------------------------------------------------------- */
+
+typedef struct vfi_rife vfi_rife_t;
+
+/* Build the device-resident network from a reference checkpoint.
+ * `tensors[i]` are host pointers to the state_dict tensors in the key order of
+ * rife_spec.rife47_keys() (== torch state_dict order of IFNet("4.7")), each in the
+ * reference's own layout; `numels[i]` their element counts (checked).
+ * Replaces IFNet(arch_ver).load_state_dict(torch.load(path)) + .to(device),
+ * vfi_models/rife/__init__.py:129-135. */
+vfi_rife_t* vfi_rife_create(int arch_ver_x10 /* 47 */, const float* const* tensors,
+                            const int64_t* numels, int n_tensors);
+void vfi_rife_destroy(vfi_rife_t* net);
+
+/* (Re)size the workspace: frames of H x W (unpadded), up to `max_batch` tasks per forward and
+ * `n_slots` cached frames.  scale_factor as in the node widget (scale_list = [8,4,2,1]/sf,
+ * vfi_models/rife/__init__.py:157-160); only values giving integer scales are accepted. */
+int vfi_rife_configure(vfi_rife_t* net, int H, int W, int max_batch, int n_slots, float scale_factor);
+
+/* Upload-side half of IFNet.forward for ONE input frame: clamp to [0,1], zero-pad to x64
+ * (rife_arch.py:476-484) and `encode` (rife_arch.py:414-416,501-503) into frame slot `slot`.
+ * frame_dev: [H,W,C] fp32, C>=3 (alpha dropped, vfi_utils.py:139-140).
+ * The result depends only on the frame, so it is computed once per frame and shared by both
+ * adjacent pairs and all timesteps. */
+int vfi_rife_load_frame(vfi_rife_t* net, int slot, const float* frame_dev, int C, void* stream);
+
+/* The per-task hot loop: out[b] = clamp(IFNet(frame[slot0[b]], frame[slot1[b]], t[b]), 0, 1)
+ * for b < B.  Replaces the model call + clamp at vfi_models/rife/__init__.py:200-207 and
+ * IFNet.forward (rife_arch.py:465-732, arch "4.7").   out_dev: [B,H,W,3]. */
+int vfi_rife_interpolate(vfi_rife_t* net, int B, const int* slot0, const int* slot1,
+                         const float* timestep, float* out_dev, void* stream);
+
+/* Debug taps for parity tests: copy internal tensors of the LAST interpolate call to host.
+ * what: 0 = flow after stage `stage` [B,Hp,Wp,4];  1 = stage input X [B,Hs,Ws,Cx] of `stage`;
+ *       2 = frame slot pack [Hp,Wp,8] (stage = slot).  Returns number of floats written or <0. */
+int64_t vfi_rife_debug_read(vfi_rife_t* net, int what, int stage, float* host_buf, int64_t cap);
+int vfi_rife_debug_keep(vfi_rife_t* net, int on);
+
+/* Work done by one interpolate call for roofline accounting (algorithmic, per task). */
+int vfi_rife_work(vfi_rife_t* net, double* conv_flop_per_task, double* hbm_bytes_per_task);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VFI_HIP_H */

@@ -1,0 +1,125 @@
+"""-m gpu: single-kernel parity, HIP (through the C ABI) vs the oracle's torch-CPU ops.
+
+Tolerances: the warp reproduces the reference's fp32 expression order (<= 2e-6 abs on [0,1]
+data); convolutions differ from oneDNN only in fp32 summation order (<= 2e-5 relative to the
+output scale).  Both are far inside the path's |d| <= 1e-3 contract."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import describe_diff, hptr, nchw, nhwc, ptr
+from oracle import rife_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib(hip_lib):
+    from cfi_amd import _lib
+
+    assert torch.cuda.is_available()
+    _lib.check(hip_lib.vfi_init(0), "vfi_init")
+    return hip_lib
+
+
+def _check(lib, rc, what):
+    from cfi_amd import _lib
+
+    _lib.check(rc, what)
+
+
+@pytest.mark.parametrize("shape,mag", [((2, 4, 40, 56), 30.0), ((1, 3, 128, 192), 6.0), ((1, 8, 67, 93), 200.0)])
+def test_warp_vs_oracle(lib, shape, mag):
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(h * w)
+    x = torch.rand(n, c, h, w, generator=g)
+    fl = (torch.rand(n, 2, h, w, generator=g) - 0.5) * mag
+    want = nhwc(rife_oracle.warp(x, fl))
+    xd, fd = nhwc(x).cuda(), nhwc(fl).cuda()
+    out = torch.empty_like(xd)
+    _check(lib, lib.vfi_warp_border(ptr(xd), ptr(fd), ptr(out), n, h, w, c, None), "vfi_warp_border")
+    torch.cuda.synchronize()
+    got = out.cpu()
+    assert (got - want).abs().max().item() <= 2e-6, describe_diff(got, want, "warp")
+
+
+def test_warp_vs_reference_golden(lib, golden_dir):
+    import os
+
+    g = np.load(os.path.join(golden_dir, "rife_warp.npz"))
+    x, fl, y = torch.from_numpy(g["x"]), torch.from_numpy(g["flow"]), torch.from_numpy(g["y"])
+    n, c, h, w = x.shape
+    xd, fd = nhwc(x).cuda(), nhwc(fl).cuda()
+    out = torch.empty_like(xd)
+    _check(lib, lib.vfi_warp_border(ptr(xd), ptr(fd), ptr(out), n, h, w, c, None), "vfi_warp_border")
+    got = out.cpu()
+    assert (got - nhwc(y)).abs().max().item() <= 2e-6, describe_diff(got, nhwc(y), "warp golden")
+
+
+def _conv_case(lib, n, h, w, cin, cout, stride, res, variant, seed=0, naive=False):
+    g = torch.Generator().manual_seed(seed + cin * 131 + cout)
+    x = torch.rand(n, cin, h, w, generator=g) * 2 - 1
+    wt = (torch.rand(cout, cin, 3, 3, generator=g) * 2 - 1) / (cin * 9) ** 0.5
+    b = torch.rand(cout, generator=g) - 0.5
+    beta = (0.5 + torch.rand(cout, generator=g)) if res else None
+    y = F.conv2d(x, wt, b, stride, 1)
+    if res:
+        y = y * beta.view(1, -1, 1, 1) + x
+    want = nhwc(F.leaky_relu(y, 0.2))
+    xd = nhwc(x).cuda()
+    out = torch.full(want.shape, float("nan"), device="cuda")
+    if naive:
+        rc = lib.vfi_conv3x3_naive(ptr(xd), hptr(wt), hptr(b), hptr(beta), ptr(out), n, h, w, cin, cout, stride, 1, 0.2, None)
+    else:
+        rc = lib.vfi_conv3x3(ptr(xd), hptr(wt), hptr(b), hptr(beta), ptr(out), n, h, w, cin, cout, stride, 1, 0.2, variant, None)
+    _check(lib, rc, "vfi_conv3x3")
+    torch.cuda.synchronize()
+    got = out.cpu()
+    tol = 2e-5 * max(1.0, want.abs().max().item())
+    assert not torch.isnan(got).any(), "NaN / unwritten outputs: " + describe_diff(torch.nan_to_num(got, nan=1e9), want, "conv")
+    assert (got - want).abs().max().item() <= tol, describe_diff(got, want, f"conv cin={cin} cout={cout} s={stride} v={variant}")
+
+
+# (variant, cin, cout): every tile configuration of csrc/conv_mfma.hip at least once
+S1 = [(0, 64, 64), (1, 96, 96), (2, 64, 128), (3, 96, 192), (4, 32, 32), (5, 16, 32), (6, 64, 64), (7, 128, 128)]
+S2 = [(8, 24, 64), (9, 16, 96), (10, 24, 32), (11, 32, 64), (8, 24, 48)]
+
+
+@pytest.mark.parametrize("variant,cin,cout", S1)
+def test_conv3x3_s1_variants(lib, variant, cin, cout):
+    # 37x45: ragged against every tile shape; residual path only where Cin == Cout
+    _conv_case(lib, 2, 37, 45, cin, cout, 1, cin == cout, variant)
+
+
+@pytest.mark.parametrize("variant,cin,cout", S2)
+def test_conv3x3_s2_variants(lib, variant, cin, cout):
+    _conv_case(lib, 2, 38, 50, cin, cout, 2, False, variant)
+
+
+@pytest.mark.parametrize("cin,cout,stride", [(64, 64, 1), (192, 192, 1), (20, 32, 2), (48, 96, 2)])
+def test_conv3x3_heuristic_and_naive(lib, cin, cout, stride):
+    _conv_case(lib, 1, 34, 60, cin, cout, stride, stride == 1, -1)
+    _conv_case(lib, 1, 34, 60, cin, cout, stride, stride == 1, -1, naive=True)
+
+
+def test_conv3x3_tiny_and_exact_tile(lib):
+    _conv_case(lib, 1, 4, 8, 16, 32, 1, False, 4)      # one sub-tile exactly
+    _conv_case(lib, 1, 1, 1, 16, 32, 1, False, 4)      # single pixel
+    _conv_case(lib, 3, 16, 16, 64, 64, 1, True, 0)     # exactly one 16x16 tile per image
+
+
+@pytest.mark.parametrize("cin,h,w", [(64, 17, 30), (192, 9, 15), (96, 34, 60)])
+def test_deconv4x4_pixelshuffle(lib, cin, h, w):
+    g = torch.Generator().manual_seed(cin)
+    x = torch.rand(2, cin, h, w, generator=g) * 2 - 1
+    wt = (torch.rand(cin, 24, 4, 4, generator=g) * 2 - 1) / (cin * 4) ** 0.5
+    b = torch.rand(24, generator=g) - 0.5
+    want = nhwc(F.pixel_shuffle(F.conv_transpose2d(x, wt, b, 2, 1), 2))
+    xd = nhwc(x).cuda()
+    out = torch.full(want.shape, float("nan"), device="cuda")
+    _check(lib, lib.vfi_deconv4x4_ps2(ptr(xd), hptr(wt), hptr(b), ptr(out), 2, h, w, cin, 24, None), "vfi_deconv4x4_ps2")
+    got = out.cpu()
+    assert not torch.isnan(got).any()
+    tol = 2e-5 * max(1.0, want.abs().max().item())
+    assert (got - want).abs().max().item() <= tol, describe_diff(got, want, "deconv+ps")

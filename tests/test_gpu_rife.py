@@ -1,0 +1,178 @@
+"""-m gpu: RIFE 4.7 hot path on the MI355X vs the oracle (and vs outputs of the real reference in
+tests/golden).  Contract (BASELINE.json north_star): per-pixel fp32 |d| <= 1e-3."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import describe_diff
+from cfi_amd import synth
+from cfi_amd.schedule import InterpolationStateList
+from oracle import rife_oracle
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return synth.rife47_synth_state_dict(1234)
+
+
+@pytest.fixture(scope="module")
+def engine(hip_lib, sd):
+    from cfi_amd.rife import RifeEngine
+
+    torch.cuda.set_device(0)
+    e = RifeEngine(sd, "4.7")
+    yield e
+    e.close()
+
+
+def _oracle_mid(sd, frames, tasks):
+    x = frames[..., :3].permute(0, 3, 1, 2)
+    f0 = torch.cat([x[p:p + 1] for p, _ in tasks]).float()
+    f1 = torch.cat([x[p + 1:p + 2] for p, _ in tasks]).float()
+    ts = torch.tensor([t for _, t in tasks]).view(-1, 1, 1, 1)
+    with torch.inference_mode():
+        out, aux = rife_oracle.ifnet47_forward(sd, f0, f1, ts, (8, 4, 2, 1), return_aux=True)
+    return out.clamp(0, 1).permute(0, 2, 3, 1).contiguous(), aux
+
+
+@pytest.mark.parametrize("h,w", [(64, 64), (100, 150), (270, 480)])
+def test_stage_by_stage_against_oracle(engine, sd, h, w):
+    """Localises a failure: frame packs, every stage's flow, then the output."""
+    from cfi_amd.rife import run_tasks
+
+    frames = synth.smooth_frames(2, h, w, seed=h, shift=2.5)
+    tasks = [(0, 0.5), (0, 0.25)]
+    engine.debug_keep(True)
+    try:
+        got = run_tasks(engine, frames, tasks, batch_size=2)
+        hp, wp = -(-h // 64) * 64, -(-w // 64) * 64
+        want, aux = _oracle_mid(sd, frames, tasks)
+        # encode / frame pack of the first loaded frame
+        x = frames[..., :3].permute(0, 3, 1, 2)
+        msgs = []
+        ok = True
+        for st in range(4):
+            fl = engine.debug_read(0, st, 2 * hp * wp * 4).view(2, hp, wp, 4)
+            wf = aux[st][0].permute(0, 2, 3, 1)
+            d = (fl - wf).abs().max().item()
+            msgs.append(describe_diff(fl, wf, f"flow after block{st}"))
+            ok &= d <= 2e-3
+        d = (got - want).abs().max().item()
+        msgs.append(describe_diff(got, want, "output"))
+        assert ok and d <= TOL, "\n".join(msgs)
+    finally:
+        engine.debug_keep(False)
+
+
+def test_frame_pack_against_oracle(engine, sd):
+    """prep (clamp/pad) + encode conv/deconv vs oracle.encode."""
+    from cfi_amd.rife import run_tasks
+
+    h, w = 70, 90
+    frames = synth.smooth_frames(2, h, w, seed=1, shift=1.0) * 1.2 - 0.1   # exercises the clamp
+    run_tasks(engine, frames, [(0, 0.5)], batch_size=1)
+    hp, wp = 128, 128
+    img = torch.nn.functional.pad(frames[..., :3].permute(0, 3, 1, 2).clamp(0, 1), (0, wp - w, 0, hp - h))
+    with torch.inference_mode():
+        feat = rife_oracle.encode(sd, img)
+    found = 0
+    for slot in range(4):
+        pk = engine.debug_read(2, slot, hp * wp * 8).view(hp, wp, 8)
+        for k in range(2):
+            if (pk[..., :3] - img[k].permute(1, 2, 0)).abs().max().item() == 0.0:
+                found += 1
+                d = (pk[..., 4:8] - feat[k].permute(1, 2, 0)).abs().max().item()
+                assert d <= 2e-5, describe_diff(pk[..., 4:8], feat[k].permute(1, 2, 0), "encode features")
+                assert pk[..., 3].abs().max().item() == 0.0
+    assert found == 2, "frame packs not found / image channels not bit-exact"
+
+
+def test_against_reference_golden(engine, sd, golden_dir):
+    from cfi_amd.rife import run_tasks
+
+    g = np.load(os.path.join(golden_dir, "rife47_net_anime.npz"))
+    frames = torch.from_numpy(g["frames"])
+    tasks = [(0, float(t)) for t in g["timesteps"]]
+    got = run_tasks(engine, frames, tasks, batch_size=2)
+    want = torch.from_numpy(g["out"]).clamp(0, 1)
+    assert (got - want).abs().max().item() <= TOL, describe_diff(got, want, "vs reference golden")
+
+
+def test_batch_invariance_and_determinism(engine, sd):
+    """Per-task results do not depend on how tasks are batched (the reference: bit-identical)."""
+    from cfi_amd.rife import run_tasks
+
+    frames = synth.smooth_frames(4, 128, 192, seed=4, shift=3.0)
+    tasks = [(0, 0.5), (1, 0.5), (2, 0.5), (1, 0.25), (0, 0.75)]
+    a = run_tasks(engine, frames, tasks, batch_size=1)
+    b = run_tasks(engine, frames, tasks, batch_size=4)
+    c = run_tasks(engine, frames, tasks, batch_size=4)
+    assert torch.equal(b, c), "run-to-run non-determinism"
+    assert (a - b).abs().max().item() <= 1e-5, describe_diff(a, b, "batch 1 vs batch 4")
+
+
+def test_full_size_1080p(engine, sd):
+    """BASELINE.json configs[1] size (padded 1088x1920), one pair, against the oracle."""
+    from cfi_amd.rife import run_tasks
+
+    frames = synth.smooth_frames(2, 1080, 1920, seed=2, shift=4.0)
+    tasks = [(0, 0.5)]
+    got = run_tasks(engine, frames, tasks, batch_size=1)
+    want, _ = _oracle_mid(sd, frames, tasks)
+    assert got.shape == (1, 1080, 1920, 3)
+    assert (got - want).abs().max().item() <= TOL, describe_diff(got, want, "1080p")
+
+
+def test_full_size_noise_worst_case(engine, sd):
+    """i.i.d. noise frames: the worst-case-gradient input of BASELINE.md."""
+    from cfi_amd.rife import run_tasks
+
+    frames = synth.noise_frames(2, 540, 960, seed=0)
+    got = run_tasks(engine, frames, [(0, 0.5)], batch_size=1)
+    want, _ = _oracle_mid(sd, frames, [(0, 0.5)])
+    assert (got - want).abs().max().item() <= TOL, describe_diff(got, want, "noise 540p")
+
+
+NODE_CASES = {
+    "m2": dict(multiplier=2),
+    "m3_bs2": dict(multiplier=3, batch_size=2),
+    "mlist": dict(multiplier=[3, 0, 1]),
+    "m2_skip12": dict(multiplier=2, optional_interpolation_states=InterpolationStateList([1, 2], True)),
+    "m2_keep12": dict(multiplier=2, optional_interpolation_states=InterpolationStateList([1, 2], False)),
+}
+
+
+@pytest.mark.parametrize("name", list(NODE_CASES))
+def test_node_against_reference_golden(hip_lib, sd, golden_dir, name, tmp_path, monkeypatch):
+    """RIFE_VFI.vfi — same call as the reference's node — vs outputs of the reference node."""
+    import cfi_amd.rife as R
+
+    pth = tmp_path / "rife47.pth"
+    torch.save(sd, pth)
+    monkeypatch.setattr(R, "load_file_from_github_release", lambda model_type, ckpt: str(pth))
+    g = np.load(os.path.join(golden_dir, "rife47_node.npz"))
+    frames = torch.from_numpy(g["frames"])
+    before = frames.clone()
+    (out,) = R.RIFE_VFI().vfi("rife47.pth", frames, **NODE_CASES[name])
+    want = torch.from_numpy(g[name])
+    assert torch.equal(frames, before), "input tensor was mutated"
+    assert out.dtype == torch.float32 and out.device.type == "cpu" and out.shape == want.shape
+    assert (out - want).abs().max().item() <= TOL, describe_diff(out, want, name)
+    # pass-through frames are bit-exact copies of the inputs (alpha dropped)
+    same = (out == want).reshape(out.shape[0], -1).all(1)
+    srcs = [i for i in range(out.shape[0]) if any(torch.equal(want[i], frames[j, ..., :3]) for j in range(len(frames)))]
+    assert all(bool(same[i]) for i in srcs)
+
+
+def test_node_rejects_unsupported(hip_lib, sd, tmp_path, monkeypatch):
+    import cfi_amd.rife as R
+
+    with pytest.raises(KeyError):
+        R.RIFE_VFI().vfi("nope.pth", torch.zeros(2, 8, 8, 3))
+    with pytest.raises(NotImplementedError):
+        R.RifeEngine(sd, "4.26")

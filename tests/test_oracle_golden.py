@@ -1,0 +1,72 @@
+"""Pin the oracle: oracle/rife_oracle.py must reproduce outputs of the REAL reference
+(tests/golden/*.npz, written by oracle/make_golden.py from /root/reference) — CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cfi_amd import synth
+from cfi_amd.schedule import InterpolationStateList
+from oracle import ref_import, rife_oracle
+
+# torch-CPU results depend (at the 1-ulp level) on the host's SIMD width / oneDNN kernels, so
+# "same machine" is bit-exact (oracle/VALIDATION.log) while across machines we allow 2e-5.
+TOL = 2e-5
+
+
+def test_warp_matches_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "rife_warp.npz"))
+    y = rife_oracle.warp(torch.from_numpy(g["x"]), torch.from_numpy(g["flow"]))
+    assert np.abs(y.numpy() - g["y"]).max() <= 1e-6
+
+
+def test_ifnet47_matches_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "rife47_net_anime.npz"))
+    sd = synth.rife47_synth_state_dict(1234)
+    fr = torch.from_numpy(g["frames"])
+    ts = torch.from_numpy(g["timesteps"]).view(-1, 1, 1, 1)
+    b = ts.shape[0]
+    i0 = fr[0:1].permute(0, 3, 1, 2).repeat(b, 1, 1, 1)
+    i1 = fr[1:2].permute(0, 3, 1, 2).repeat(b, 1, 1, 1)
+    with torch.inference_mode():
+        out = rife_oracle.ifnet47_forward(sd, i0, i1, ts).permute(0, 2, 3, 1)
+    assert out.shape == g["out"].shape
+    assert np.abs(out.numpy() - g["out"]).max() <= TOL
+
+
+CASES = {
+    "m2": dict(multiplier=2),
+    "m3_bs2": dict(multiplier=3, batch_size=2),
+    "mlist": dict(multiplier=[3, 0, 1]),
+    "m2_skip12": dict(multiplier=2, states=InterpolationStateList([1, 2], True)),
+    "m2_keep12": dict(multiplier=2, states=InterpolationStateList([1, 2], False)),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_node_matches_reference_golden(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, "rife47_node.npz"))
+    sd = synth.rife47_synth_state_dict(1234)
+    out = rife_oracle.rife_vfi(sd, torch.from_numpy(g["frames"]), **CASES[name])
+    assert out.shape == g[name].shape
+    assert np.abs(out.numpy() - g[name]).max() <= TOL
+
+
+@pytest.mark.skipif(not ref_import.available(), reason="reference checkout not mounted")
+def test_oracle_bit_exact_vs_live_reference():
+    """Where /root/reference exists, run the real IFNet next to the oracle: must be identical."""
+    ref = ref_import.rife_arch()
+    sd = synth.rife47_synth_state_dict(7)
+    net = ref.IFNet("4.7")
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    fr = synth.smooth_frames(2, 70, 90, seed=9, shift=3.0)
+    i0 = fr[0:1].permute(0, 3, 1, 2).contiguous()
+    i1 = fr[1:2].permute(0, 3, 1, 2).contiguous()
+    ts = torch.tensor([0.3]).view(1, 1, 1, 1)
+    with torch.inference_mode():
+        a = net(i0, i1, ts, [8, 4, 2, 1], False, False)
+        b = rife_oracle.ifnet47_forward(sd, i0, i1, ts)
+    assert torch.equal(a, b)
