@@ -1,5 +1,6 @@
 // Single-op C entry points (include/vfi_hip.h): thin argument checking + host-side weight packing
 // around the kernels, used by the parity tests and available to other node implementations.
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/vfi_hip.h"
@@ -55,8 +56,8 @@ int vfi_conv3x3(const float* in_dev, const float* weight_host, const float* bias
     int v = variant;
     a.Cin_p = round_up(Cin, 8);
     if (v < 0) v = conv_pick_variant(a, stride, false);
-    VFI_REQUIRE(v >= 0 && v < conv_num_variants(), "vfi_conv3x3: bad variant %d", v);
-    const int ck = conv_variant(v).ck;
+    VFI_REQUIRE(conv_variant_lookup(v), "vfi_conv3x3: bad variant %d", v);
+    const int ck = conv_variant_lookup(v)->ck;
     a.Cin_p = round_up(Cin, ck);
     // the activation tensor must physically hold Cin_p channels: copy into a padded temp if not
     Tmp inpad;
@@ -91,6 +92,10 @@ int vfi_conv3x3(const float* in_dev, const float* weight_host, const float* bias
     a.out_cs = Cout;
     a.act = act;
     a.slope = slope;
+    {
+        static const char* env = getenv("VFI_CONV_ABLATE");  // profiling experiments (tools/conv_ablate.py)
+        a.ablate = env ? atoi(env) : 0;
+    }
     if (conv_launch(a, stride, false, v, st, nullptr)) return -1;
     VFI_CHECK_HIP(hipStreamSynchronize(st));  // temporaries are freed on return
     return 0;

@@ -180,7 +180,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
                 if (cok && oy < a.Hout && ox < a.Wout) {
                     const size_t p = (size_t)(n * a.Hout + oy) * a.Wout + ox;
                     float v = acc[mt][nt][r] + bs;
-                    if (a.beta) v = v * bt + a.res[p * a.res_cs + co];
+                    if (a.beta) v *= bt;
+                    if (a.res) v += a.res[p * a.res_cs + co];
                     if (a.act == 1) v = v > 0.f ? v : v * a.slope;
                     a.out[p * a.out_cs + g * a.Cout_p + co] = v;
                 }
@@ -211,6 +212,11 @@ static const ConvVariant kVariants[] = {
 };
 int conv_num_variants() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }
 const ConvVariant& conv_variant(int i) { return kVariants[i]; }
+const ConvVariant* conv_variant_lookup(int id) {
+    if (id >= 0 && id < conv_num_variants()) return &kVariants[id];
+    if (id >= kConv2Base && id < kConv2Base + conv2_num_variants()) return &conv2_variant(id - kConv2Base);
+    return nullptr;
+}
 
 template <int STRIDE, int TAPS, int MT, int NT, int WM, int WN, int CK, bool GROUPED>
 static int launch_t(ConvArgs a, hipStream_t s, const char* name) {
@@ -241,33 +247,38 @@ static int n_cus_cached() {
     return n;
 }
 
-// Tile-shape heuristic: widest N tile that divides Cout_p; the 256-pixel M tile only when it
-// still leaves >= 2 workgroups per CU, otherwise 128 pixels (coarse pyramid levels, batch 1).
+// Tile-shape heuristic, from tools/conv_sweep.py on MI355X (profiles/r01_conv_sweep_*.txt):
+//   * stride 1: second-generation (LDS-DMA, persistent) 16x16x64 tile for 64 channels, 16x8x64 for the
+//     other multiples of 64; 96 channels stay on the first generation's 16x8x32 tile;
+//   * stride 2 and the grouped transposed conv: first-generation small tiles.
 int conv_pick_variant(const ConvArgs& a, int stride, bool grouped) {
     const long px = (long)a.N * a.Hout * a.Wout;
     const long cus = n_cus_cached();
-    if (grouped) return px >= 128L * 2 * cus ? 12 : 13;
+    if (grouped) return 13;
     const bool n3 = a.Cout_p % 96 == 0;
     const bool n2 = a.Cout_p % 64 == 0;
     if (stride == 2) {
+        if (n2) return px * (a.Cout_p / 64) >= 64L * cus ? 8 : (a.Cin_p % 8 == 0 ? kConv2Base + 7 : 8);
         if (n3) return 9;
-        if (n2) return (px * (a.Cout_p / 64) >= 256L * 2 * cus) ? 11 : 8;
         return 10;
     }
-    if (n3) return (px * (a.Cout_p / 96) >= 256L * 2 * cus) ? 1 : 3;
     if (n2) {
-        if (px * (a.Cout_p / 64) >= 256L * 2 * cus) return 0;
-        if (px * (a.Cout_p / 64) >= 128L * cus) return 2;
-        return 4;
+        if (a.Cin_p % 8) return 4;
+        return a.Cout_p == 64 ? kConv2Base + 0 : kConv2Base + 2;
     }
-    return px >= 256L * 2 * cus ? 5 : 4;
+    return 4;
 }
 
 int conv_launch(const ConvArgs& a, int stride, bool grouped, int variant, hipStream_t s,
                 const char* trace_name) {
+    if (variant < 0 && grouped) {  // experiment hook: force a grouped (transposed-conv) tile variant
+        static const char* env = getenv("VFI_GROUPED_VARIANT");
+        if (env) variant = atoi(env);
+    }
     if (variant < 0) variant = conv_pick_variant(a, stride, grouped);
-    VFI_REQUIRE(variant >= 0 && variant < conv_num_variants(), "conv: bad variant %d", variant);
-    const ConvVariant& v = kVariants[variant];
+    const ConvVariant* vp = conv_variant_lookup(variant);
+    VFI_REQUIRE(vp, "conv: bad variant %d", variant);
+    const ConvVariant& v = *vp;
     VFI_REQUIRE(v.stride == stride && (v.grouped != 0) == grouped && v.taps == a.ntaps,
                 "conv: variant %s does not match stride %d grouped %d taps %d", v.name, stride, (int)grouped,
                 a.ntaps);
@@ -275,6 +286,7 @@ int conv_launch(const ConvArgs& a, int stride, bool grouped, int variant, hipStr
                 "conv: bad channel padding Cin_p=%d Cout_p=%d in_cs=%d", a.Cin_p, a.Cout_p, a.in_cs);
     VFI_REQUIRE(((uintptr_t)a.in & 15) == 0 && ((uintptr_t)a.w & 15) == 0, "conv: unaligned pointers");
     const char* nm = trace_name ? trace_name : v.name;
+    if (variant >= kConv2Base) return conv2_launch(a, variant - kConv2Base, s, nm);
     switch (variant) {
         case 0: return launch_t<1, 9, 2, 2, 4, 1, 16, false>(a, s, nm);
         case 1: return launch_t<1, 9, 2, 3, 4, 1, 16, false>(a, s, nm);

@@ -1,0 +1,351 @@
+// Second-generation NHWC fp32 implicit-GEMM convolution for gfx950: BOTH operands are streamed
+// HBM/L2 -> LDS by the LDS-DMA path (buffer_load_dwordx4 ... lds / global_load_lds_dwordx4), with a
+// double-buffered K-chunk pipeline and one workgroup barrier per chunk.
+//
+// Why (profiles/r01_*_v1.txt): the first-generation kernel (conv_mfma.hip) keeps weights in VGPRs,
+// loaded from L2 one K-step ahead; rocprofv3 shows the matrix pipe only 65 % busy on the block-3
+// ResConv (SQ_WAIT_ANY = 27 % of wave cycles: exposed L2 latency in front of every 16-MFMA step).
+// Here a K-step is  MT+NT ds_read_b128 + 4*MT*NT v_mfma_f32_32x32x2_f32  and nothing else; all global
+// traffic for chunk k+1 is in flight (no VGPRs, no waits) while chunk k is multiplied.
+//
+//   * activations: halo'd input tile, CK channels per chunk, [pixel][CK] in LDS (lane-linear DMA
+//     image); out-of-image halo pixels are zero-filled by the buffer descriptor's range check
+//     (voffset >= num_records returns 0) — no branches, no separate memset;
+//   * weights: host-packed [group][tap][Cin/8][Cout][8]; one (tap, 8-channel) slice of the block's
+//     BN output channels is a contiguous run, copied verbatim: the LDS image IS the B fragment order;
+//   * epilogue fused as in the first generation (+bias, *beta + residual, LeakyReLU, NHWC store).
+#include "vfi_common.h"
+
+namespace vfi {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+template <int STRIDE, int TAPS, int MT, int NT, int WM, int WN, int CK, bool GROUPED>
+struct Conv2Geom {
+    static constexpr int KW = TAPS == 9 ? 3 : (TAPS == 4 ? 2 : 1);
+    static constexpr int SUBS = WM * MT;
+    static constexpr int SUBX = SUBS >= 2 ? 2 : 1;
+    static constexpr int SUBY = SUBS / SUBX;
+    static constexpr int TWO = SUBX * 8, THO = SUBY * 4;
+    static constexpr int TWI = STRIDE * (TWO - 1) + 3;
+    static constexpr int THI = STRIDE * (THO - 1) + 3;
+    static constexpr int NPIX = TWI * THI;
+    static constexpr int Q = CK / 4;
+    static constexpr int C8 = CK / 8;
+    static constexpr int NA_INSTR = (NPIX * Q + 63) / 64;            // 1 KiB wave-wide DMA pieces
+    static constexpr int A_FLOATS = NA_INSTR * 256;
+    static constexpr int NGRP = GROUPED ? 4 : 1;
+    static constexpr int BN = GROUPED ? 32 : WN * NT * 32;           // output channels per group per block
+    static constexpr int NB_INSTR = NGRP * TAPS * C8 * (BN / 32);
+    static constexpr int B_FLOATS = NB_INSTR * 256;
+    static constexpr int BUF_FLOATS = A_FLOATS + B_FLOATS;
+    static constexpr int LDS_BYTES = 2 * BUF_FLOATS * 4;
+    static constexpr int NAW = (NA_INSTR + 3) / 4;                   // pieces per wave
+    static constexpr int NBW = (NB_INSTR + 3) / 4;
+};
+
+template <int STRIDE, int TAPS, int MT, int NT, int WM, int WN, int CK, bool GROUPED>
+__global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource / LDS-DMA builtins do not exist in the host pass
+    using G = Conv2Geom<STRIDE, TAPS, MT, NT, WM, WN, CK, GROUPED>;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(!GROUPED || (WN == 4 && NT == 1 && TAPS == 4), "grouped: one 2x2 tap group per wave column");
+    constexpr int KW = G::KW, SUBX = G::SUBX, TWO = G::TWO, THO = G::THO, TWI = G::TWI;
+    constexpr int Q = G::Q, C8 = G::C8, BN = G::BN;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    const int g = GROUPED ? wn : 0;
+    const int cob = blockIdx.y * BN;                       // first output channel of this block (per group)
+    const int co0 = GROUPED ? cob : cob + wn * NT * 32;    // first output channel of this wave
+    const int cin8 = a.Cin_p >> 3;
+    const int tby = GROUPED ? (g >> 1) - 1 : a.tap_y0;
+    const int tbx = GROUPED ? (g & 1) - 1 : a.tap_x0;
+
+    // ---- persistent tile loop: this workgroup owns M tiles blockIdx.x, +gridDim.x, ...
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    const int T = a.N * tiles_per_img;
+    const int img_floats = a.Hin * a.Win * a.in_cs;
+    auto decode = [&](int tile, int& n, int& Y0, int& X0) {
+        n = tile / tiles_per_img;
+        const int trem = tile - n * tiles_per_img;
+        const int ty = trem / a.tiles_x;
+        Y0 = ty * THO;
+        X0 = (trem - ty * a.tiles_x) * TWO;
+    };
+    // activation DMA: voffset per 16-byte piece inside the image; out-of-image halo -> out of range -> zero fill
+    auto make_avoff = [&](int Y0, int X0, int(&avoff)[G::NAW]) {
+        const int iy0 = STRIDE * Y0 - 1, ix0 = STRIDE * X0 - 1;
+#pragma unroll
+        for (int i = 0; i < G::NAW; ++i) {
+            const int j = wave + 4 * i;
+            const int idx = j * 64 + lane;
+            const int pix = idx / Q, q = idx - pix * Q;
+            const int py = pix / TWI, px = pix - py * TWI;
+            const int iy = iy0 + py, ix = ix0 + px;
+            const bool ok = pix < G::NPIX && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+            avoff[i] = ok ? ((iy * a.Win + ix) * a.in_cs + q * 4) * 4 : (int)0x80000000;
+        }
+    };
+    auto make_rsrc = [&](int n) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)n * img_floats), 0, img_floats * 4, 0x00020000);
+    };
+    // weight DMA: per-lane source pointers of this wave's pieces (tile- and chunk-invariant part)
+    const int tapstride = cin8 * a.Cout_p * 8;
+    const int c8stride = a.Cout_p * 8;
+    const float* wsrc[G::NBW];
+#pragma unroll
+    for (int i = 0; i < G::NBW; ++i) {
+        const int j = wave + 4 * i;  // piece index in LDS order [group][tap][c8][BN/32]
+        const int sub = j % (BN / 32);
+        const int c8 = (j / (BN / 32)) % C8;
+        const int t = (j / (BN / 32) / C8) % TAPS;
+        const int gg = j / (BN / 32) / C8 / TAPS;
+        wsrc[i] = a.w + (size_t)(gg * TAPS + t) * tapstride + c8 * c8stride + (cob + sub * 32) * 8 + lane * 4;
+    }
+    auto issue = [&](const __amdgpu_buffer_rsrc_t& rsrc, const int(&avoff)[G::NAW], int chunk, int buf) {
+        float* abuf = smem + buf * G::BUF_FLOATS;
+        float* bbuf = abuf + G::A_FLOATS;
+        const int cbyte = chunk * CK * 4;
+#pragma unroll
+        for (int i = 0; i < G::NAW; ++i) {
+            const int j = wave + 4 * i;
+            if (G::NA_INSTR % 4 == 0 || j < G::NA_INSTR)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(abuf + j * 256), 16, avoff[i] + cbyte, 0, 0, 0);
+        }
+        const int wadv = chunk * C8 * c8stride;
+#pragma unroll
+        for (int i = 0; i < G::NBW; ++i) {
+            const int j = wave + 4 * i;
+            if (G::NB_INSTR % 4 == 0 || j < G::NB_INSTR)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc[i] + wadv), (lds_ptr_t)(bbuf + j * 256), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment offsets (floats) inside a buffer
+    int abase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int s = wm * MT + mt;
+        const int sx = s % SUBX, sy = s / SUBX;
+        const int oy = sy * 4 + (l31 >> 3), ox = sx * 8 + (l31 & 7);
+        abase[mt] = ((STRIDE * oy + 1 + tby) * TWI + STRIDE * ox + 1 + tbx) * CK + half * 4;
+    }
+    // B image: [group][tap][c8][BN][8]; this wave's channels start at (co0 - cob)
+    const int bbase = G::A_FLOATS + (g * TAPS * C8 * BN + (co0 - cob) + l31) * 8 + half * 4;
+
+    // per-lane epilogue constants (the lane's output channel is fixed per N sub-tile)
+    float bs[NT], bt[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = co0 + nt * 32 + l31;
+        bs[nt] = a.bias[g * a.Cout_p + co];
+        bt[nt] = a.beta ? a.beta[co] : 1.f;
+    }
+
+    const int nchunks = a.Cin_p / CK;
+    const int abl = a.ablate;  // profiling experiments only (tools/conv_ablate.py); 0 in production
+
+    int tile = blockIdx.x;
+    if (tile >= T) return;
+    int n, Y0, X0, avoff[G::NAW];
+    decode(tile, n, Y0, X0);
+    make_avoff(Y0, X0, avoff);
+    __amdgpu_buffer_rsrc_t rsrc = make_rsrc(n);
+    if (!(abl & 1)) issue(rsrc, avoff, 0, 0);
+    __syncthreads();  // LDS-DMA counts on vmcnt: the barrier's release drains it
+    int buf = 0;
+    for (;;) {
+        const int ntile = tile + gridDim.x;
+        const bool has_next = ntile < T;
+        int nn = 0, nY0 = 0, nX0 = 0, navoff[G::NAW];
+        __amdgpu_buffer_rsrc_t nrsrc = rsrc;
+
+        f32x16 acc[MT][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+        for (int k = 0; k < nchunks; ++k) {
+            // keep the DMA queue one K-chunk ahead — across the tile boundary too, so the matrix pipe
+            // never waits for a tile's first chunk and the previous tile's stores drain underneath
+            if (k + 1 < nchunks) {
+                if (!(abl & 1)) issue(rsrc, avoff, k + 1, buf ^ 1);
+            } else if (has_next) {
+                decode(ntile, nn, nY0, nX0);
+                make_avoff(nY0, nX0, navoff);
+                nrsrc = make_rsrc(nn);
+                if (!(abl & 1)) issue(nrsrc, navoff, 0, buf ^ 1);
+            }
+            const float* sb = smem + ((abl & 4) ? 0 : buf * G::BUF_FLOATS);
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                const int toff = ((t / KW) * TWI + (t % KW)) * CK;
+#pragma unroll
+                for (int c8 = 0; c8 < C8; ++c8) {
+                    f32x4 av[MT], bv[NT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) av[mt] = *(const f32x4*)&sb[abase[mt] + ((abl & 4) ? 0 : toff + c8 * 8)];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        bv[nt] = *(const f32x4*)&sb[bbase + ((abl & 4) ? 0 : ((t * C8 + c8) * BN + nt * 32) * 8)];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt][j], bv[nt][j], acc[mt][nt], 0, 0, 0);
+                }
+            }
+            if (!(abl & 8)) __syncthreads();  // chunk consumed by every wave; the next chunk has landed
+            buf ^= 1;
+        }
+
+        // ---- epilogue (stores are fire-and-forget; the next tile's MFMAs start right behind them)
+        if (abl & 2) {  // keep the accumulators alive without the store traffic
+            float sacc = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc += acc[mt][nt][r];
+            if (sacc == 123.456f) a.out[tid] = sacc;
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int co = co0 + nt * 32 + l31;
+                const bool cok = co < a.Cout;
+                const int coc = cok ? co : a.Cout - 1;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int s = wm * MT + mt;
+                    const int sx = s % SUBX, sy = s / SUBX;
+                    // explicit residual (test / non-folded path): 16 loads in flight, clamped addresses, one wait
+                    float rv[16];
+                    if (a.res) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            int oy = Y0 + sy * 4 + (r >> 2), ox = X0 + sx * 8 + (r & 3) + 4 * half;
+                            oy = oy < a.Hout ? oy : a.Hout - 1;
+                            ox = ox < a.Wout ? ox : a.Wout - 1;
+                            rv[r] = a.res[((size_t)(n * a.Hout + oy) * a.Wout + ox) * a.res_cs + coc];
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int oy = Y0 + sy * 4 + (r >> 2);
+                        const int ox = X0 + sx * 8 + (r & 3) + 4 * half;
+                        float v = acc[mt][nt][r] + bs[nt];
+                        if (a.beta) v *= bt[nt];
+                        if (a.res) v += rv[r];
+                        if (a.act == 1) v = v > 0.f ? v : v * a.slope;
+                        if (cok && oy < a.Hout && ox < a.Wout)
+                            a.out[((size_t)(n * a.Hout + oy) * a.Wout + ox) * a.out_cs + g * a.Cout_p + co] = v;
+                    }
+                }
+            }
+        }
+        if (!has_next) break;
+        tile = ntile;
+        n = nn;
+        Y0 = nY0;
+        X0 = nX0;
+        rsrc = nrsrc;
+#pragma unroll
+        for (int i = 0; i < G::NAW; ++i) avoff[i] = navoff[i];
+    }
+#endif
+}
+
+template <int STRIDE, int TAPS, int MT, int NT, int WM, int WN, int CK, bool GROUPED>
+static int launch2_t(ConvArgs a, hipStream_t s, const char* name) {
+    using G = Conv2Geom<STRIDE, TAPS, MT, NT, WM, WN, CK, GROUPED>;
+    a.tiles_x = cdiv(a.Wout, G::TWO);
+    a.tiles_y = cdiv(a.Hout, G::THO);
+    VFI_REQUIRE(a.Cin_p % CK == 0, "conv2 %s: Cin_p=%d not a multiple of the K chunk %d", name, a.Cin_p, CK);
+    VFI_REQUIRE(a.Cout_p % G::BN == 0, "conv2 %s: Cout_p=%d not a multiple of the N tile %d", name, a.Cout_p, G::BN);
+    VFI_REQUIRE((long)a.Hin * a.Win * a.in_cs * 4 < 0x7fffffffL, "conv2 %s: image larger than 2 GiB", name);
+    static int occ = 0;  // resident workgroups per CU for this instantiation
+    static int cus = 0;
+    if (!occ) {
+        VFI_CHECK_HIP(hipFuncSetAttribute(
+            reinterpret_cast<const void*>(&conv_mfma2_kernel<STRIDE, TAPS, MT, NT, WM, WN, CK, GROUPED>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+        int o = 0;
+        VFI_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &o, reinterpret_cast<const void*>(&conv_mfma2_kernel<STRIDE, TAPS, MT, NT, WM, WN, CK, GROUPED>), 256,
+            G::LDS_BYTES));
+        int dev = 0;
+        hipDeviceProp_t p;
+        VFI_CHECK_HIP(hipGetDevice(&dev));
+        VFI_CHECK_HIP(hipGetDeviceProperties(&p, dev));
+        cus = p.multiProcessorCount;
+        occ = o < 1 ? 1 : o;
+    }
+    const int T = a.N * a.tiles_x * a.tiles_y;
+    const int ny = a.Cout_p / G::BN;
+    int gx = (cus * occ) / ny;  // persistent: one resident wave of workgroups, each walks its share of tiles
+    if (gx < 1) gx = 1;
+    if (gx > T) gx = T;
+    dim3 grid(gx, ny);
+    TraceScope ts(name, s);
+    hipLaunchKernelGGL((conv_mfma2_kernel<STRIDE, TAPS, MT, NT, WM, WN, CK, GROUPED>), grid, dim3(256), G::LDS_BYTES, s, a);
+    VFI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// second-generation variants, numbered from kConv2Base in the common variant space
+static const ConvVariant kVariants2[] = {
+    // name            stride taps mt nt wm wn ck grouped
+    {"d1_m2n2", 1, 9, 2, 2, 4, 1, 8, 0},      // 32: 16x16 px x 64 ch
+    {"d1_m2n3", 1, 9, 2, 3, 4, 1, 8, 0},      // 33: 16x16 px x 96 ch
+    {"d1_m1n2", 1, 9, 1, 2, 4, 1, 8, 0},      // 34: 16x8 px x 64 ch
+    {"d1_m1n3", 1, 9, 1, 3, 4, 1, 8, 0},      // 35
+    {"d1_m2n2w22", 1, 9, 2, 2, 2, 2, 8, 0},   // 36: 16x8 px x 128 ch
+    {"d1_m4n2w22", 1, 9, 4, 2, 2, 2, 8, 0},   // 37: 16x16 px x 128 ch
+    {"d1_m2n2k16", 1, 9, 2, 2, 4, 1, 16, 0},  // 38: as 32 with 16-channel chunks
+    {"d2_m1n2", 2, 9, 1, 2, 4, 1, 8, 0},      // 39: stride 2, 16x8 px x 64 ch
+    {"d2_m2n2", 2, 9, 2, 2, 4, 1, 8, 0},      // 40
+    {"d2_m1n3", 2, 9, 1, 3, 4, 1, 8, 0},      // 41
+    {"d2_m2n1", 2, 9, 2, 1, 4, 1, 8, 0},      // 42: stride 2, 16x16 px x 32 ch
+    {"dg_m4", 1, 4, 4, 1, 1, 4, 8, 1},        // 43: grouped 16x8 px
+    {"dg_m8", 1, 4, 8, 1, 1, 4, 8, 1},        // 44: grouped 16x16 px
+};
+int conv2_num_variants() { return (int)(sizeof(kVariants2) / sizeof(kVariants2[0])); }
+const ConvVariant& conv2_variant(int i) { return kVariants2[i]; }
+
+int conv2_launch(const ConvArgs& a, int idx, hipStream_t s, const char* nm) {
+    switch (idx) {
+        case 0: return launch2_t<1, 9, 2, 2, 4, 1, 8, false>(a, s, nm);
+        case 1: return launch2_t<1, 9, 2, 3, 4, 1, 8, false>(a, s, nm);
+        case 2: return launch2_t<1, 9, 1, 2, 4, 1, 8, false>(a, s, nm);
+        case 3: return launch2_t<1, 9, 1, 3, 4, 1, 8, false>(a, s, nm);
+        case 4: return launch2_t<1, 9, 2, 2, 2, 2, 8, false>(a, s, nm);
+        case 5: return launch2_t<1, 9, 4, 2, 2, 2, 8, false>(a, s, nm);
+        case 6: return launch2_t<1, 9, 2, 2, 4, 1, 16, false>(a, s, nm);
+        case 7: return launch2_t<2, 9, 1, 2, 4, 1, 8, false>(a, s, nm);
+        case 8: return launch2_t<2, 9, 2, 2, 4, 1, 8, false>(a, s, nm);
+        case 9: return launch2_t<2, 9, 1, 3, 4, 1, 8, false>(a, s, nm);
+        case 10: return launch2_t<2, 9, 2, 1, 4, 1, 8, false>(a, s, nm);
+        case 11: return launch2_t<1, 4, 4, 1, 1, 4, 8, true>(a, s, nm);
+        case 12: return launch2_t<1, 4, 8, 1, 1, 4, 8, true>(a, s, nm);
+    }
+    set_error("conv2: bad variant %d", idx);
+    return -3;
+}
+
+}  // namespace vfi

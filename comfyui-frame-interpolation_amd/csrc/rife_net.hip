@@ -7,6 +7,7 @@
 //   8 x ResConv (3x3, *beta + x, LeakyReLU)              -> A1 <-> A2   [MFMA]
 //   lastconv (ConvTranspose 4x4 s2, 4 parity groups)     -> T           [MFMA]
 //   flow_up (PixelShuffle + up-resize + flow/mask update) or, for the last block, final_blend.
+#include <cmath>
 #include <cstring>
 
 #include "../../include/vfi_hip.h"
@@ -44,6 +45,7 @@ int upload(DevBuf& b, const std::vector<float>& h) {
 struct ConvLayer {
     DevBuf w, bias, beta;
     int Cin = 0, Cin_p = 0, Cout = 0, Cout_p = 0;
+    bool folded = false;  // residual folded into the centre tap (ResConv)
 };
 
 const int kBlockC[4] = {192, 128, 96, 64};
@@ -72,6 +74,21 @@ static int make_conv3x3(ConvLayer& L, const float* w, const float* b, const floa
     L.Cout = Cout;
     L.Cout_p = round_up(Cout, 32);
     std::vector<float> wp, bp;
+    // ResConv: lrelu((conv(x)+b)*beta + x) == lrelu((conv'(x)+b)*beta) with the identity folded into the
+    // centre tap, w'[co][co][1][1] = w + 1/beta[co].  The residual then costs no memory traffic at all.
+    // (x/beta*beta differs from x by <= 1 ulp.)  Only when every |beta| is comfortably away from 0.
+    std::vector<float> wfold;
+    L.folded = false;
+    if (beta && Cin == Cout) {
+        bool ok = true;
+        for (int i = 0; i < Cout; ++i) ok = ok && std::fabs(beta[i]) >= 1e-2f;
+        if (ok) {
+            wfold.assign(w, w + (size_t)Cout * Cin * 9);
+            for (int i = 0; i < Cout; ++i) wfold[((size_t)i * Cin + i) * 9 + 4] += 1.0f / beta[i];
+            w = wfold.data();
+            L.folded = true;
+        }
+    }
     pack_conv3x3(w, b, Cout, Cin, Cin_p, L.Cout_p, wp, bp);
     if (upload(L.w, wp) || upload(L.bias, bp)) return -1;
     if (beta) {
@@ -307,7 +324,7 @@ int vfi_rife_interpolate(vfi_rife_t* net, int B, const int* slot0, const int* sl
             fill_args(a, net->res[i][r], cur, c, nxt, c, B, Hs / 4, Ws / 4, 1);
             conv3x3_taps(a);
             a.beta = net->res[i][r].beta.p;
-            a.res = cur;
+            a.res = net->res[i][r].folded ? nullptr : cur;
             a.res_cs = c;
             a.act = 1;
             a.slope = 0.2f;

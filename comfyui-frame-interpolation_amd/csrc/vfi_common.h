@@ -65,14 +65,22 @@ struct ConvArgs {
     float slope;
     int tiles_x, tiles_y;  // output tiles per image (filled by the launcher)
     int tap_y0, tap_x0;    // origin of the tap rectangle (3x3: -1,-1), ignored for grouped
+    int ablate;            // profiling experiments only (second-generation kernel); 0 in production
 };
 
 struct ConvVariant {
     const char* name;
     int stride, taps, mt, nt, wm, wn, ck, grouped;
 };
+// Variant ids: 0.. = first generation (conv_mfma.hip, weights in registers),
+// kConv2Base.. = second generation (conv_mfma2.hip, both operands through LDS-DMA).
+constexpr int kConv2Base = 32;
 int conv_num_variants();
 const ConvVariant& conv_variant(int i);
+int conv2_num_variants();
+const ConvVariant& conv2_variant(int i);
+int conv2_launch(const ConvArgs& a, int idx, hipStream_t s, const char* trace_name);
+const ConvVariant* conv_variant_lookup(int id);
 // Launch; variant < 0 selects by heuristic.  grouped convs must use a grouped variant.
 int conv_pick_variant(const ConvArgs& a, int stride, bool grouped);
 int conv_launch(const ConvArgs& a, int stride, bool grouped, int variant, hipStream_t s,

@@ -82,8 +82,11 @@ def _conv_case(lib, n, h, w, cin, cout, stride, res, variant, seed=0, naive=Fals
 
 
 # (variant, cin, cout): every tile configuration of csrc/conv_mfma.hip at least once
-S1 = [(0, 64, 64), (1, 96, 96), (2, 64, 128), (3, 96, 192), (4, 32, 32), (5, 16, 32), (6, 64, 64), (7, 128, 128)]
-S2 = [(8, 24, 64), (9, 16, 96), (10, 24, 32), (11, 32, 64), (8, 24, 48)]
+S1 = [(0, 64, 64), (1, 96, 96), (2, 64, 128), (3, 96, 192), (4, 32, 32), (5, 16, 32), (6, 64, 64), (7, 128, 128),
+      # second generation (LDS-DMA, csrc/conv_mfma2.hip)
+      (32, 64, 64), (33, 96, 96), (34, 64, 128), (35, 96, 192), (36, 128, 128), (37, 128, 128), (38, 64, 64), (32, 8, 64)]
+S2 = [(8, 24, 64), (9, 16, 96), (10, 24, 32), (11, 32, 64), (8, 24, 48),
+      (39, 24, 64), (40, 32, 64), (41, 16, 96), (42, 24, 32), (39, 24, 48)]
 
 
 @pytest.mark.parametrize("variant,cin,cout", S1)
@@ -109,8 +112,26 @@ def test_conv3x3_tiny_and_exact_tile(lib):
     _conv_case(lib, 3, 16, 16, 64, 64, 1, True, 0)     # exactly one 16x16 tile per image
 
 
+@pytest.mark.parametrize("gvariant", [None, 12, 13, 43, 44])
 @pytest.mark.parametrize("cin,h,w", [(64, 17, 30), (192, 9, 15), (96, 34, 60)])
-def test_deconv4x4_pixelshuffle(lib, cin, h, w):
+def test_deconv4x4_pixelshuffle(lib, cin, h, w, gvariant, monkeypatch):
+    import os
+    import subprocess
+    import sys
+
+    if gvariant is not None:
+        # the variant hook is read once per process: run this case in a child process
+        env = dict(os.environ, VFI_GROUPED_VARIANT=str(gvariant), VFI_CHILD="1")
+        code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import conftest, test_gpu_ops as t; "
+                "import cfi_amd._lib as L; lib=L.load(); L.check(lib.vfi_init(0),'init'); "
+                "t._deconv_case(lib, %d, %d, %d)" % (os.path.dirname(__file__), os.path.dirname(os.path.dirname(__file__)), cin, h, w))
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        return
+    _deconv_case(lib, cin, h, w)
+
+
+def _deconv_case(lib, cin, h, w):
     g = torch.Generator().manual_seed(cin)
     x = torch.rand(2, cin, h, w, generator=g) * 2 - 1
     wt = (torch.rand(cin, 24, 4, 4, generator=g) * 2 - 1) / (cin * 4) ** 0.5

@@ -59,6 +59,8 @@ def test_stage_by_stage_against_oracle(engine, sd, h, w):
         for st in range(4):
             fl = engine.debug_read(0, st, 2 * hp * wp * 4).view(2, hp, wp, 4)
             wf = aux[st][0].permute(0, 2, 3, 1)
+            if st == 3:  # the last block is fused with the output kernel, which only visits the un-padded HxW
+                fl, wf = fl[:, :h, :w], wf[:, :h, :w]
             d = (fl - wf).abs().max().item()
             msgs.append(describe_diff(fl, wf, f"flow after block{st}"))
             ok &= d <= 2e-3

@@ -21,9 +21,13 @@ _lib.check(lib.vfi_init(0), "init")
 VARIANTS = {  # index: (stride, BN, CK)
     0: (1, 64, 16), 1: (1, 96, 16), 2: (1, 64, 16), 3: (1, 96, 16), 4: (1, 32, 16), 5: (1, 32, 16), 6: (1, 64, 16),
     7: (1, 128, 16), 8: (2, 64, 8), 9: (2, 96, 8), 10: (2, 32, 8), 11: (2, 64, 8),
+    32: (1, 64, 8), 33: (1, 96, 8), 34: (1, 64, 8), 35: (1, 96, 8), 36: (1, 128, 8), 37: (1, 128, 8), 38: (1, 64, 16),
+    39: (2, 64, 8), 40: (2, 64, 8), 41: (2, 96, 8), 42: (2, 32, 8),
 }
-NAMES = ["s1_m2n2", "s1_m2n3", "s1_m1n2", "s1_m1n3", "s1_m1n1", "s1_m2n1", "s1_m1n1w22", "s1_m2n2w22", "s2_m1n2",
-         "s2_m1n3", "s2_m1n1", "s2_m2n2"]
+NAMES = {0: "s1_m2n2", 1: "s1_m2n3", 2: "s1_m1n2", 3: "s1_m1n3", 4: "s1_m1n1", 5: "s1_m2n1", 6: "s1_m1n1w22",
+         7: "s1_m2n2w22", 8: "s2_m1n2", 9: "s2_m1n3", 10: "s2_m1n1", 11: "s2_m2n2", 32: "d1_m2n2", 33: "d1_m2n3",
+         34: "d1_m1n2", 35: "d1_m1n3", 36: "d1_m2n2w22", 37: "d1_m4n2w22", 38: "d1_m2n2k16", 39: "d2_m1n2",
+         40: "d2_m2n2", 41: "d2_m1n3", 42: "d2_m2n1"}
 
 
 def run(n, h, w, cin, cout, stride, res, variant, reps=5):
@@ -34,6 +38,8 @@ def run(n, h, w, cin, cout, stride, res, variant, reps=5):
     ho, wo = (h + 2 - 3) // stride + 1, (w + 2 - 3) // stride + 1
     out = torch.empty(n, ho, wo, cout, device="cuda")
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    if lib.vfi_conv3x3(p(x), p(wt), p(b), p(beta), p(out), n, h, w, cin, cout, stride, 1, 0.2, variant, None):
+        return None  # (also the untimed warm-up call)
     lib.vfi_trace_reset()
     lib.vfi_trace_enable(1)
     for _ in range(reps):
@@ -50,10 +56,11 @@ def run(n, h, w, cin, cout, stride, res, variant, reps=5):
 
 
 LAYERS = [  # name, H, W, cin, cout, stride, res   (trunk resolution at 1080p = padded 1088x1920)
-    ("res_c64", 272, 480, 64, 64, 1, True),
-    ("res_c96", 136, 240, 96, 96, 1, True),
-    ("res_c128", 68, 120, 128, 128, 1, True),
-    ("res_c192", 34, 60, 192, 192, 1, True),
+    # res=False: in the network the ResConv residual is folded into the centre tap (rife_net.hip)
+    ("res_c64", 272, 480, 64, 64, 1, False),
+    ("res_c96", 136, 240, 96, 96, 1, False),
+    ("res_c128", 68, 120, 128, 128, 1, False),
+    ("res_c192", 34, 60, 192, 192, 1, False),
     ("c0a_b3", 1088, 1920, 24, 32, 2, False),
     ("c0b_b3", 544, 960, 32, 64, 2, False),
     ("c0a_b2", 544, 960, 24, 48, 2, False),
@@ -64,8 +71,42 @@ LAYERS = [  # name, H, W, cin, cout, stride, res   (trunk resolution at 1080p = 
     ("c0b_b0", 68, 120, 96, 192, 2, False),
 ]
 
+def run_deconv(n, h, w, cin, reps=5):
+    x = torch.rand(n, h, w, cin, device="cuda") - 0.5
+    wt = (torch.rand(cin, 24, 4, 4) - 0.5) * 0.1
+    b = torch.rand(24) - 0.5
+    out = torch.empty(n, 4 * h, 4 * w, 6, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    lib.vfi_deconv4x4_ps2(p(x), p(wt), p(b), p(out), n, h, w, cin, 24, None)  # untimed warm-up
+    lib.vfi_trace_reset()
+    lib.vfi_trace_enable(1)
+    for _ in range(reps):
+        if lib.vfi_deconv4x4_ps2(p(x), p(wt), p(b), p(out), n, h, w, cin, 24, None):
+            lib.vfi_trace_enable(0)
+            return None
+    lib.vfi_trace_enable(0)
+    rep = _lib.trace_report()
+    calls, tot = list(rep.values())[0]
+    return tot / calls
+
+
+if __name__ == "__main__" and os.environ.get("VFI_GROUPED_VARIANT"):
+    # child mode: grouped (transposed-conv) variant forced through the environment hook
+    B = int(sys.argv[1])
+    for name, h, w, cin in (("last_b3", 272, 480, 64), ("last_b2", 136, 240, 96), ("last_b1", 68, 120, 128), ("last_b0", 34, 60, 192)):
+        ms = run_deconv(B, h, w, cin)
+        flop = 2.0 * B * h * w * cin * 24 * 16
+        print(f"{name:10s} {B:2d} grouped_v{os.environ['VFI_GROUPED_VARIANT']:3s} {ms:8.4f} {flop / (ms * 1e-3) / 1e12:8.2f} (algorithmic TFLOP/s)", flush=True)
+    sys.exit(0)
+
 if __name__ == "__main__":
     batches = [int(a) for a in sys.argv[1:]] or [1, 8]
+    import subprocess
+    for B in batches:
+        for gv in (12, 13, 43, 44):
+            r = subprocess.run([sys.executable, __file__, str(B)], env=dict(os.environ, VFI_GROUPED_VARIANT=str(gv)),
+                               capture_output=True, text=True)
+            print(r.stdout.strip() or r.stderr[-300:], flush=True)
     print(f"{'layer':10s} {'B':>2s} {'variant':12s} {'ms':>8s} {'TFLOP/s':>8s} {'frac':>6s}")
     for name, h, w, cin, cout, stride, res in LAYERS:
         for B in batches:
