@@ -28,7 +28,7 @@ def _digest():
     files.append(os.path.join(PKG, "..", "include", "vfi_hip.h"))
     for f in files:
         with open(f, "rb") as fh:
-            h.update(f.encode())
+            h.update(os.path.basename(f).encode())  # names only: the checkout path differs on the GPU box
             h.update(fh.read())
     return h.hexdigest()
 

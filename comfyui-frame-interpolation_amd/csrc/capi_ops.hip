@@ -132,7 +132,7 @@ int vfi_deconv4x4_ps2(const float* in_dev, const float* weight_host, const float
     std::vector<float> wp, bp;
     pack_deconv4x4(weight_host, bias_host, Cin, Cout, Cin, 32, wp, bp);
     Tmp dw, db, T;
-    if (dw.put(wp) || db.put(bp) || T.alloc((size_t)N * H * W * 128)) return -1;
+    if (dw.put(wp) || db.put(bp) || T.alloc((size_t)N * H * W * 128)) return -1;  // planar4 [N][2][4H][4W][4]
     VFI_CHECK_HIP(hipMemsetAsync(T.p, 0, (size_t)N * H * W * 128 * sizeof(float), st));
     ConvArgs a;
     memset(&a, 0, sizeof(a));
@@ -148,6 +148,7 @@ int vfi_deconv4x4_ps2(const float* in_dev, const float* weight_host, const float
     a.Cin_p = Cin;
     a.Cout_p = 32;
     a.Cout = Cout;
+    a.out_mode = 1;
     deconv4x4_taps(a);
     if (conv_launch(a, 1, true, -1, st, nullptr)) return -1;
     if (t_to_nhwc_launch(T.p, out_dev, N, H, W, Cout / 4, st)) return -1;

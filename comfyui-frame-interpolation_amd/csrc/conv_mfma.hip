@@ -70,7 +70,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 
     // ---- global -> register staging of the activation tile (geometry is chunk-invariant).
     // Loads are unconditional from a clamped address and zeroed by select: straight-line code.
-    const float* in_n = a.in + (size_t)n * a.Hin * a.Win * a.in_cs;
+    const int pstr = a.in_plane ? 4 : a.in_cs;                      // floats between pixels
+    const int qstr = a.in_plane ? a.in_plane : 4;                   // floats between 4-channel groups
+    const int cadv = a.in_plane ? (CK / 4) * a.in_plane : CK;       // floats between K chunks
+    const float* in_n = a.in + (size_t)n * (a.in_plane ? (size_t)(a.in_cs / 4) * a.in_plane : (size_t)a.Hin * a.Win * a.in_cs);
     int goff[NLOAD];
     bool gok[NLOAD];
 #pragma unroll
@@ -80,12 +83,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         const int py = pix / TWI, px = pix - py * TWI;
         const int iy = iy0 + py, ix = ix0 + px;
         gok[i] = idx < NITEM && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-        goff[i] = gok[i] ? (iy * a.Win + ix) * a.in_cs + q * 4 : 0;
+        goff[i] = gok[i] ? (iy * a.Win + ix) * pstr + q * qstr : 0;
     }
     f32x4 stage[NLOAD];
     auto gload = [&](int c0) {
 #pragma unroll
-        for (int i = 0; i < NLOAD; ++i) stage[i] = *(const f32x4*)(in_n + goff[i] + c0);
+        for (int i = 0; i < NLOAD; ++i) stage[i] = *(const f32x4*)(in_n + goff[i] + (c0 / CK) * cadv);
     };
     auto lstore = [&]() {
 #pragma unroll
@@ -183,7 +186,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
                     if (a.beta) v *= bt;
                     if (a.res) v += a.res[p * a.res_cs + co];
                     if (a.act == 1) v = v > 0.f ? v : v * a.slope;
-                    a.out[p * a.out_cs + g * a.Cout_p + co] = v;
+                    if (GROUPED && a.out_mode == 1) {
+                        const int Ws = 4 * a.Wout, Hs = 4 * a.Hout, c = co >> 2;
+                        const int Yt = 4 * oy + 2 * (g >> 1) + ((co >> 1) & 1), Xt = 4 * ox + 2 * (g & 1) + (co & 1);
+                        a.out[((size_t)(n * 2 + (c >> 2)) * Hs * Ws + (size_t)Yt * Ws + Xt) * 4 + (c & 3)] = v;
+                    } else {
+                        a.out[p * a.out_cs + g * a.Cout_p + co] = v;
+                    }
                 }
             }
         }
@@ -282,6 +291,7 @@ int conv_launch(const ConvArgs& a, int stride, bool grouped, int variant, hipStr
     VFI_REQUIRE(v.stride == stride && (v.grouped != 0) == grouped && v.taps == a.ntaps,
                 "conv: variant %s does not match stride %d grouped %d taps %d", v.name, stride, (int)grouped,
                 a.ntaps);
+    VFI_REQUIRE(!a.out_mode || (grouped && a.Cout % 4 == 0 && a.Cout <= 32), "conv: out_mode 1 is for grouped convs");
     VFI_REQUIRE(a.Cin_p % 8 == 0 && a.Cout_p % 32 == 0 && a.in_cs >= a.Cin_p && a.in_cs % 4 == 0,
                 "conv: bad channel padding Cin_p=%d Cout_p=%d in_cs=%d", a.Cin_p, a.Cout_p, a.in_cs);
     VFI_REQUIRE(((uintptr_t)a.in & 15) == 0 && ((uintptr_t)a.w & 15) == 0, "conv: unaligned pointers");

@@ -74,7 +74,10 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
     // ---- persistent tile loop: this workgroup owns M tiles blockIdx.x, +gridDim.x, ...
     const int tiles_per_img = a.tiles_x * a.tiles_y;
     const int T = a.N * tiles_per_img;
-    const int img_floats = a.Hin * a.Win * a.in_cs;
+    const int pstr = a.in_plane ? 4 : a.in_cs;                 // floats between pixels
+    const int qstr = a.in_plane ? a.in_plane : 4;              // floats between 4-channel groups
+    const int cadv = a.in_plane ? (CK / 4) * a.in_plane : CK;  // floats between K chunks
+    const int img_floats = a.in_plane ? (a.in_cs / 4) * a.in_plane : a.Hin * a.Win * a.in_cs;
     auto decode = [&](int tile, int& n, int& Y0, int& X0) {
         n = tile / tiles_per_img;
         const int trem = tile - n * tiles_per_img;
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
             const int py = pix / TWI, px = pix - py * TWI;
             const int iy = iy0 + py, ix = ix0 + px;
             const bool ok = pix < G::NPIX && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-            avoff[i] = ok ? ((iy * a.Win + ix) * a.in_cs + q * 4) * 4 : (int)0x80000000;
+            avoff[i] = ok ? ((iy * a.Win + ix) * pstr + q * qstr) * 4 : (int)0x80000000;
         }
     };
     auto make_rsrc = [&](int n) {
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
     auto issue = [&](const __amdgpu_buffer_rsrc_t& rsrc, const int(&avoff)[G::NAW], int chunk, int buf) {
         float* abuf = smem + buf * G::BUF_FLOATS;
         float* bbuf = abuf + G::A_FLOATS;
-        const int cbyte = chunk * CK * 4;
+        const int cbyte = chunk * cadv * 4;
 #pragma unroll
         for (int i = 0; i < G::NAW; ++i) {
             const int j = wave + 4 * i;
@@ -253,8 +256,15 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
                         if (a.beta) v *= bt[nt];
                         if (a.res) v += rv[r];
                         if (a.act == 1) v = v > 0.f ? v : v * a.slope;
-                        if (cok && oy < a.Hout && ox < a.Wout)
-                            a.out[((size_t)(n * a.Hout + oy) * a.Wout + ox) * a.out_cs + g * a.Cout_p + co] = v;
+                        if (cok && oy < a.Hout && ox < a.Wout) {
+                            if (GROUPED && a.out_mode == 1) {
+                                const int Ws = 4 * a.Wout, Hs = 4 * a.Hout, c = co >> 2;
+                                const int Yt = 4 * oy + 2 * (g >> 1) + ((co >> 1) & 1), Xt = 4 * ox + 2 * (g & 1) + (co & 1);
+                                a.out[((size_t)(n * 2 + (c >> 2)) * Hs * Ws + (size_t)Yt * Ws + Xt) * 4 + (c & 3)] = v;
+                            } else {
+                                a.out[((size_t)(n * a.Hout + oy) * a.Wout + ox) * a.out_cs + g * a.Cout_p + co] = v;
+                            }
+                        }
                     }
                 }
             }
@@ -279,6 +289,7 @@ static int launch2_t(ConvArgs a, hipStream_t s, const char* name) {
     VFI_REQUIRE(a.Cin_p % CK == 0, "conv2 %s: Cin_p=%d not a multiple of the K chunk %d", name, a.Cin_p, CK);
     VFI_REQUIRE(a.Cout_p % G::BN == 0, "conv2 %s: Cout_p=%d not a multiple of the N tile %d", name, a.Cout_p, G::BN);
     VFI_REQUIRE((long)a.Hin * a.Win * a.in_cs * 4 < 0x7fffffffL, "conv2 %s: image larger than 2 GiB", name);
+    VFI_REQUIRE(!a.in_plane || a.in_plane >= a.Hin * a.Win * 4, "conv2 %s: bad plane stride", name);
     static int occ = 0;  // resident workgroups per CU for this instantiation
     static int cus = 0;
     if (!occ) {

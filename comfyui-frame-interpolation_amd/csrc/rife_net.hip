@@ -235,8 +235,9 @@ int vfi_rife_configure(vfi_rife_t* net, int H, int W, int max_batch, int n_slots
         x = std::max(x, px * cx);
         a0 = std::max(a0, px / 4 * (kBlockC[i] / 2));
         a1 = std::max(a1, px / 16 * kBlockC[i]);
-        t = std::max(t, px / 16 * 128);
+        t = std::max(t, px * 8);
     }
+    // T plane 1 holds only the mask (+1 unused channel): components 2,3 are never written; keep them defined
     if (net->Ppool.ensure(full * 8 * n_slots) || net->E.ensure(full / 4 * 16) || net->F.ensure(B * full * 4) ||
         net->M.ensure(B * full) || net->X.ensure(B * x) || net->A0.ensure(B * a0) || net->A1.ensure(B * a1) ||
         net->A2.ensure(B * a1) || net->T.ensure(B * t))
@@ -291,12 +292,17 @@ int vfi_rife_interpolate(vfi_rife_t* net, int B, const int* slot0, const int* sl
     static const char* kC00Name[4] = {"conv0a_b0", "conv0a_b1", "conv0a_b2", "conv0a_b3"};
     static const char* kC01Name[4] = {"conv0b_b0", "conv0b_b1", "conv0b_b2", "conv0b_b3"};
     static const char* kLastName[4] = {"lastconv_b0", "lastconv_b1", "lastconv_b2", "lastconv_b3"};
+    bool fused_prev = false;
     for (int i = 0; i < 4; ++i) {
         const int s = net->scales[i];
         const int Hs = Hp / s, Ws = Wp / s;
         const int c = kBlockC[i];
         const int CX = i == 0 ? 16 : 24;
-        if (stage_in_launch(net->Ppool.p, net->pack_stride(), tasks, B, net->F.p, net->M.p, net->X.p, Hp, Wp, s, CX,
+        // X of this block: block 0 has no flow yet; later blocks get X from the fused transition kernel of the
+        // previous iteration when the scale list allows it (standard [8,4,2,1]), else from stage_in.
+        const bool x_ready = i > 0 && fused_prev;
+        if (!x_ready &&
+            stage_in_launch(net->Ppool.p, net->pack_stride(), tasks, B, net->F.p, net->M.p, net->X.p, Hp, Wp, s, CX,
                             i > 0, st))
             return -1;
         if (net->keep) {
@@ -307,6 +313,7 @@ int vfi_rife_interpolate(vfi_rife_t* net, int B, const int* slot0, const int* sl
         ConvArgs a;
         // conv0.0: 3x3 stride 2 + LeakyReLU(0.2)
         fill_args(a, net->conv00[i], net->X.p, CX, net->A0.p, c / 2, B, Hs, Ws, 2);
+        a.in_plane = Hs * Ws * 4;  // X is planar4
         conv3x3_taps(a);
         a.act = 1;
         a.slope = 0.2f;
@@ -333,10 +340,19 @@ int vfi_rife_interpolate(vfi_rife_t* net, int B, const int* slot0, const int* sl
         }
         // lastconv: ConvTranspose2d(c,24,4,2,1) as 4 parity groups -> T[.,4,32]
         fill_args(a, net->last[i], cur, c, net->T.p, 128, B, Hs / 4, Ws / 4, 1);
+        a.out_mode = 1;  // PixelShuffle(2) resolved by the epilogue: T is planar4 [B][2][Hs][Ws][4]
         deconv4x4_taps(a);
         if (conv_launch(a, 1, true, -1, st, kLastName[i])) return -1;
         if (i < 3) {
-            if (flow_up_launch(net->T.p, net->F.p, net->M.p, B, Hp, Wp, s, i > 0, st)) return -1;
+            const int sn = net->scales[i + 1];
+            fused_prev = s == 2 * sn && (sn == 4 || sn == 2 || sn == 1);
+            if (fused_prev) {
+                if (stage_trans_launch(net->Ppool.p, net->pack_stride(), tasks, B, net->T.p, net->F.p, net->X.p, Hp, Wp,
+                                       s, sn, i > 0, st))
+                    return -1;
+            } else if (flow_up_launch(net->T.p, net->F.p, net->M.p, B, Hp, Wp, s, i > 0, st)) {
+                return -1;
+            }
             if (net->keep) {
                 const size_t n = (size_t)B * Hp * Wp * 4;
                 if (net->Fdbg[i].ensure(n)) return -1;

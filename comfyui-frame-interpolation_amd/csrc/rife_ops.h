@@ -17,6 +17,8 @@ int prep_frame_launch(const float* src, float* P, float* E, const float* w0, con
 int stage_in_launch(const float* Ppool, size_t pack_stride, const RifeTasks& tasks, int B, const float* F,
                     const float* M, float* X, int Hp, int Wp, int s, int CX, bool has_flow, hipStream_t st);
 int flow_up_launch(const float* T, float* F, float* M, int B, int Hp, int Wp, int s, bool has_prev, hipStream_t st);
+int stage_trans_launch(const float* Ppool, size_t pack_stride, const RifeTasks& tasks, int B, const float* T, float* F,
+                       float* X, int Hp, int Wp, int s_prev, int s_next, bool has_prev, hipStream_t st);
 int final_blend_launch(const float* Ppool, size_t pack_stride, const RifeTasks& tasks, int B, const float* T,
                        const float* F, float* out, float* Fdbg, int H, int W, int Hp, int Wp, int s, hipStream_t st);
 int t_to_nhwc_launch(const float* T, float* out, int N, int Hq, int Wq, int C4, hipStream_t st);

@@ -1,13 +1,15 @@
 // HBM-bound kernels of the RIFE 4.7 hot loop (everything that is not a trunk convolution).
 //
 // Layouts (all fp32, NHWC):
-//   frame pack  P[slot] : [Hp][Wp][8]   ch0-2 = clamp(rgb,0,1) zero-padded to x64, ch3 = 0,
-//                                        ch4-7 = encode(img)  -> one 32-byte read per warp tap
-//                                        serves both the image warp and the feature warp.
+// "planar4" = a C-channel image stored as C/4 planes of [H][W] float4: every load/store of a wave is a run of
+// consecutive 16-byte items (the rocprofv3 TCP/SQ counters of the first, interleaved version showed these
+// kernels bound by L1 line touches per instruction, not by HBM: profiles/r01_pmc2_*).
+//   frame pack  P[slot] : planar4 [2][Hp][Wp][4]   plane 0 = clamp(rgb,0,1),0 zero-padded to x64,
+//                                                   plane 1 = encode(img)
 //   flow        F       : [B][Hp][Wp][4] (F01 -> frame0, F23 -> frame1), mask M : [B][Hp][Wp]
-//   stage input X       : [B][Hs][Ws][CX] channel order of the reference's torch.cat
-//   block output T      : [B][Hs/4][Ws/4][4 parity classes][32]  (ConvTranspose2d parity class
-//                         (py,px), channel co of 24; PixelShuffle is resolved when T is read)
+//   stage input X       : planar4 [B][CX/4][Hs][Ws][4], channel order of the reference's torch.cat
+//   block output T      : planar4 [B][2][Hs][Ws][4]: the PixelShuffle'd lastconv output, plane 0 = flow
+//                         delta (4 ch), plane 1 = (mask, unused, 0, 0); written by the conv epilogue
 //
 // Reference semantics restated (vfi_models/rife/rife_arch.py): warp :31-70; IFBlock's
 // F.interpolate calls :238-248,263-266; input torch.cat :543-548,629-644; flow/mask update
@@ -82,15 +84,16 @@ __device__ static inline float4 lerp4(const float4 a, const float4 b, const floa
     return r;
 }
 
-// Sample the 8-channel frame pack: lo = channels 0-3 (rgb,0), hi = channels 4-7 (features).
+// Sample the frame pack: lo = plane 0 (rgb,0), hi = plane 1 (features) at offset hi_off floats.
 template <bool WANT_HI>
-__device__ static inline void sample_pack(const float* __restrict__ P, const Tap4& t, float4& lo, float4& hi) {
-    const float4* p00 = (const float4*)(P + (size_t)t.o00 * 8);
-    const float4* p01 = (const float4*)(P + (size_t)t.o01 * 8);
-    const float4* p10 = (const float4*)(P + (size_t)t.o10 * 8);
-    const float4* p11 = (const float4*)(P + (size_t)t.o11 * 8);
-    lo = lerp4(p00[0], p01[0], p10[0], p11[0], t);
-    if (WANT_HI) hi = lerp4(p00[1], p01[1], p10[1], p11[1], t);
+__device__ static inline void sample_pack(const float* __restrict__ P, size_t hi_off, const Tap4& t, float4& lo,
+                                          float4& hi) {
+    const float4* q = (const float4*)P;
+    lo = lerp4(q[t.o00], q[t.o01], q[t.o10], q[t.o11], t);
+    if (WANT_HI) {
+        const float4* h = (const float4*)(P + hi_off);
+        hi = lerp4(h[t.o00], h[t.o01], h[t.o10], h[t.o11], t);
+    }
 }
 
 // generic NHWC warp (C arbitrary) — parity-test entry point and building block for other nodes
@@ -136,7 +139,7 @@ __global__ void prep_frame_kernel(const float* __restrict__ src, float* __restri
         v.y = fminf(fmaxf(s[1], 0.f), 1.f);
         v.z = fminf(fmaxf(s[2], 0.f), 1.f);
     }
-    *(float4*)(P + (size_t)idx * 8) = v;
+    *(float4*)(P + (size_t)idx * 4) = v;
 }
 
 // encode.0: Conv2d(3,16,3,stride 2,pad 1), no activation.   weights [tap][ci][co] (uniform -> SGPRs)
@@ -156,7 +159,7 @@ __global__ void encode_conv_kernel(const float* __restrict__ P, const float* __r
         for (int kx = 0; kx < 3; ++kx) {
             const int ix = 2 * x - 1 + kx;
             float4 v = {0.f, 0.f, 0.f, 0.f};
-            if (iy >= 0 && iy < Hp && ix >= 0 && ix < Wp) v = *(const float4*)(P + ((size_t)iy * Wp + ix) * 8);
+            if (iy >= 0 && iy < Hp && ix >= 0 && ix < Wp) v = *(const float4*)(P + ((size_t)iy * Wp + ix) * 4);
             const float* wt = w + (ky * 3 + kx) * 48;
 #pragma unroll
             for (int co = 0; co < 16; ++co)
@@ -171,7 +174,7 @@ __global__ void encode_conv_kernel(const float* __restrict__ P, const float* __r
 }
 
 // encode.1: ConvTranspose2d(16,4,4,stride 2,pad 1), no activation; one thread = one E pixel = a 2x2
-// output quad (all 4 parities).  weights [ky][kx][ci][co(4)]; result goes to pack channels 4-7.
+// output quad (all 4 parities).  weights [ky][kx][ci][co(4)]; result goes to pack plane 1.
 __global__ void encode_deconv_kernel(const float* __restrict__ E, const float* __restrict__ w,
                                      const float* __restrict__ bias, float* __restrict__ P, int Hp, int Wp) {
     const int He = Hp / 2, We = Wp / 2;
@@ -223,7 +226,7 @@ __global__ void encode_deconv_kernel(const float* __restrict__ E, const float* _
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int Y = 2 * y + (g >> 1), X = 2 * x + (g & 1);
-        *(float4*)(P + ((size_t)Y * Wp + X) * 8 + 4) = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
+        *(float4*)(P + (size_t)Hp * Wp * 4 + ((size_t)Y * Wp + X) * 4) = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
     }
 }
 
@@ -264,6 +267,7 @@ __global__ __launch_bounds__(128) void stage_in_kernel(const float* __restrict__
     const int xl = idx % Ws, yl = idx / Ws;
     const float* P0 = Ppool + (size_t)tasks.slot0[b] * pack_stride;
     const float* P1 = Ppool + (size_t)tasks.slot1[b] * pack_stride;
+    const size_t hi_off = (size_t)Hp * Wp * 4;
     const float tstep = tasks.t[b];
     const WarpGeo g = make_warp_geo(Wp, Hp);
     const int off = NP == 1 ? 0 : s / 2 - 1;
@@ -286,20 +290,18 @@ __global__ __launch_bounds__(128) void stage_in_kernel(const float* __restrict__
                 const float4 f = ((const float4*)F)[pb];
                 const Tap4 t0 = warp_taps(g, X, Y, f.x, f.y);
                 const Tap4 t1 = warp_taps(g, X, Y, f.z, f.w);
-                sample_pack<true>(P0, t0, a_lo, a_hi);
-                sample_pack<true>(P1, t1, b_lo, b_hi);
+                sample_pack<true>(P0, hi_off, t0, a_lo, a_hi);
+                sample_pack<true>(P1, hi_off, t1, b_lo, b_hi);
                 o[NC - 5] = M[pb];
                 o[NC - 4] = f.x;
                 o[NC - 3] = f.y;
                 o[NC - 2] = f.z;
                 o[NC - 1] = f.w;
             } else {
-                const float4* q0 = (const float4*)(P0 + p * 8);
-                const float4* q1 = (const float4*)(P1 + p * 8);
-                a_lo = q0[0];
-                a_hi = q0[1];
-                b_lo = q1[0];
-                b_hi = q1[1];
+                a_lo = ((const float4*)P0)[p];
+                a_hi = ((const float4*)(P0 + hi_off))[p];
+                b_lo = ((const float4*)P1)[p];
+                b_hi = ((const float4*)(P1 + hi_off))[p];
             }
             o[0] = a_lo.x; o[1] = a_lo.y; o[2] = a_lo.z;
             o[3] = b_lo.x; o[4] = b_lo.y; o[5] = b_lo.z;
@@ -318,10 +320,10 @@ __global__ __launch_bounds__(128) void stage_in_kernel(const float* __restrict__
 #pragma unroll
         for (int c = 16; c < 20; ++c) r[c] = r[c] * inv_s;  // interpolate(flow) * 1.0 / scale
     }
-    float4* op = (float4*)(Xo + ((size_t)b * Hs * Ws + idx) * CX);
+    float4* op = (float4*)Xo + (size_t)b * (CX / 4) * Hs * Ws + idx;
 #pragma unroll
     for (int q = 0; q < 6; ++q)
-        if (q < CX / 4) op[q] = make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
+        if (q < CX / 4) op[(size_t)q * Hs * Ws] = make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
 }
 
 int stage_in_launch(const float* Ppool, size_t pack_stride, const RifeTasks& tasks, int B, const float* F,
@@ -347,12 +349,31 @@ int stage_in_launch(const float* Ppool, size_t pack_stride, const RifeTasks& tas
 // block output -> full resolution:  tmp = interpolate(PixelShuffle(deconv), x s);
 // flow (+)= tmp[:, :4]*s; mask = tmp[:, 4:5]                       rife_arch.py:262-276,645,698
 // ---------------------------------------------------------------------------------------
-// channel c of the pixel-shuffled tensor at (Yt,Xt), read from the parity-class layout
-__device__ static inline float t_read(const float* __restrict__ Tb, int Wq, int Yt, int Xt, int c) {
-    const int y = Yt >> 2, x = Xt >> 2;
-    const int cls = (Yt >> 1 & 1) * 2 + (Xt >> 1 & 1);
-    const int co = c * 4 + (Yt & 1) * 2 + (Xt & 1);
-    return Tb[((size_t)(y * Wq + x) * 4 + cls) * 32 + co];
+// T is planar4 [2][Hs][Ws][4]: flow delta = plane 0, mask = plane 1 component 0
+struct TVal {
+    float4 f;
+    float m;
+};
+__device__ static inline TVal t_read(const float* __restrict__ Tb, int Hs, int Ws, int Yt, int Xt) {
+    const size_t p = (size_t)Yt * Ws + Xt;
+    TVal v;
+    v.f = ((const float4*)Tb)[p];
+    v.m = Tb[((size_t)Hs * Ws + p) * 4];
+    return v;
+}
+__device__ static inline TVal t_bilerp(const TVal& a, const TVal& b, const TVal& c, const TVal& d, float wy0, float wy1,
+                                       float wx0, float wx1) {
+    // torch upsample_bilinear2d: wy0*(wx0*a + wx1*b) + wy1*(wx0*c + wx1*d), explicit rounding order
+#define VFI_BL(A, B, C, D) \
+    __fadd_rn(__fmul_rn(wy0, __fadd_rn(__fmul_rn(wx0, A), __fmul_rn(wx1, B))), __fmul_rn(wy1, __fadd_rn(__fmul_rn(wx0, C), __fmul_rn(wx1, D))))
+    TVal r;
+    r.f.x = VFI_BL(a.f.x, b.f.x, c.f.x, d.f.x);
+    r.f.y = VFI_BL(a.f.y, b.f.y, c.f.y, d.f.y);
+    r.f.z = VFI_BL(a.f.z, b.f.z, c.f.z, d.f.z);
+    r.f.w = VFI_BL(a.f.w, b.f.w, c.f.w, d.f.w);
+    r.m = VFI_BL(a.m, b.m, c.m, d.m);
+#undef VFI_BL
+    return r;
 }
 
 struct Bil {
@@ -375,24 +396,12 @@ __device__ static inline Bil bil_index(int d, float rscale, int in_size) {
     return b;
 }
 
-template <int NCH>
-__device__ static inline void t_upsample(const float* __restrict__ Tb, int Hs, int Ws, int s, int Y, int X,
-                                         float (&val)[NCH]) {
-    const int Wq = Ws / 4;
-    if (s == 1) {
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) val[c] = t_read(Tb, Wq, Y, X, c);
-        return;
-    }
+__device__ static inline TVal t_upsample(const float* __restrict__ Tb, int Hs, int Ws, int s, int Y, int X) {
+    if (s == 1) return t_read(Tb, Hs, Ws, Y, X);
     const float rs = 1.0f / (float)s;
     const Bil by = bil_index(Y, rs, Hs), bx = bil_index(X, rs, Ws);
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const float a = t_read(Tb, Wq, by.i0, bx.i0, c), b = t_read(Tb, Wq, by.i0, bx.i1, c);
-        const float cc = t_read(Tb, Wq, by.i1, bx.i0, c), d = t_read(Tb, Wq, by.i1, bx.i1, c);
-        val[c] = __fadd_rn(__fmul_rn(by.w0, __fadd_rn(__fmul_rn(bx.w0, a), __fmul_rn(bx.w1, b))),
-                           __fmul_rn(by.w1, __fadd_rn(__fmul_rn(bx.w0, cc), __fmul_rn(bx.w1, d))));
-    }
+    return t_bilerp(t_read(Tb, Hs, Ws, by.i0, bx.i0), t_read(Tb, Hs, Ws, by.i0, bx.i1), t_read(Tb, Hs, Ws, by.i1, bx.i0),
+                    t_read(Tb, Hs, Ws, by.i1, bx.i1), by.w0, by.w1, bx.w0, bx.w1);
 }
 
 template <bool HAS_PREV>
@@ -403,18 +412,17 @@ __global__ void flow_up_kernel(const float* __restrict__ T, float* __restrict__ 
     const int b = blockIdx.y;
     const int X = idx % Wp, Y = idx / Wp;
     const int Hs = Hp / s, Ws = Wp / s;
-    const float* Tb = T + (size_t)b * (Hs / 4) * (Ws / 4) * 128;
-    float val[5];
-    t_upsample<5>(Tb, Hs, Ws, s, Y, X, val);
+    const float* Tb = T + (size_t)b * Hs * Ws * 8;
+    const TVal v = t_upsample(Tb, Hs, Ws, s, Y, X);
     const size_t pb = (size_t)b * Hp * Wp + idx;
     const float fs = (float)s;
-    float4 f = make_float4(val[0] * fs, val[1] * fs, val[2] * fs, val[3] * fs);
+    float4 f = make_float4(v.f.x * fs, v.f.y * fs, v.f.z * fs, v.f.w * fs);
     if (HAS_PREV) {
         const float4 o = ((const float4*)F)[pb];
         f = make_float4(o.x + f.x, o.y + f.y, o.z + f.z, o.w + f.w);
     }
     ((float4*)F)[pb] = f;
-    M[pb] = val[4];
+    M[pb] = v.m;
 }
 
 int flow_up_launch(const float* T, float* F, float* M, int B, int Hp, int Wp, int s, bool has_prev,
@@ -425,6 +433,129 @@ int flow_up_launch(const float* T, float* F, float* M, int B, int Hp, int Wp, in
         hipLaunchKernelGGL(flow_up_kernel<true>, grid, dim3(256), 0, st, T, F, M, Hp, Wp, s);
     else
         hipLaunchKernelGGL(flow_up_kernel<false>, grid, dim3(256), 0, st, T, F, M, Hp, Wp, s);
+    VFI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// fused block transition i -> i+1 for the standard scale list (block scales 2*SP -> SP):
+//   flow_up(i)  +  stage_in(i+1)  in one pass over the full-resolution flow field.
+// One thread owns one SP x SP cell (= one pixel of X_{i+1}).  Because SP divides the previous scale
+// 2*SP, every pixel of the cell up-samples from the same 2x2 T pixels, so the 20 T values are loaded
+// once per thread; the mask never goes to memory and the flow is read+written exactly once.
+// Thread blocks are 16x16 cells (2-D) so that warp taps of vertically adjacent pixels share L2 lines.
+// ---------------------------------------------------------------------------------------
+template <int SP, bool HAS_PREV>
+__global__ __launch_bounds__(256) void stage_trans_kernel(const float* __restrict__ Ppool, size_t pack_stride,
+                                                          RifeTasks tasks, const float* __restrict__ T,
+                                                          float* __restrict__ F, float* __restrict__ Xo, int Hp,
+                                                          int Wp, int tiles_x) {
+    constexpr int SI = 2 * SP;            // scale of the block that produced T
+    constexpr int NP = SP == 1 ? 1 : 2;   // centre pixels per axis that the down-resize samples
+    constexpr int OFF = SP == 1 ? 0 : SP / 2 - 1;
+    const int Hs = Hp / SP, Ws = Wp / SP;
+    const int b = blockIdx.y;
+    const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x - tile_y * tiles_x;
+    const int xl = tile_x * 16 + (threadIdx.x & 15), yl = tile_y * 16 + (threadIdx.x >> 4);
+    if (xl >= Ws || yl >= Hs) return;
+    const int Hi = Hp / SI, Wi = Wp / SI;  // resolution of the pixel-shuffled T
+    const float* Tb = T + (size_t)b * Hi * Wi * 8;
+    const float rs = 1.0f / (float)SI;
+    const Bil by0 = bil_index(yl * SP, rs, Hi), bx0 = bil_index(xl * SP, rs, Wi);
+    const TVal t00 = t_read(Tb, Hi, Wi, by0.i0, bx0.i0), t01 = t_read(Tb, Hi, Wi, by0.i0, bx0.i1);
+    const TVal t10 = t_read(Tb, Hi, Wi, by0.i1, bx0.i0), t11 = t_read(Tb, Hi, Wi, by0.i1, bx0.i1);
+    // ---- phase 1: flow (+)= up(T)*SI for every pixel of the cell; keep flow+mask of the centre pixels
+    float4 fc[NP * NP];
+    float mc[NP * NP];
+#pragma unroll
+    for (int dy = 0; dy < SP; ++dy) {
+        const Bil wy = bil_index(yl * SP + dy, rs, Hi);
+#pragma unroll
+        for (int dx = 0; dx < SP; ++dx) {
+            const Bil wx = bil_index(xl * SP + dx, rs, Wi);
+            const TVal v = t_bilerp(t00, t01, t10, t11, wy.w0, wy.w1, wx.w0, wx.w1);
+            const size_t pb = (size_t)b * Hp * Wp + (size_t)(yl * SP + dy) * Wp + xl * SP + dx;
+            const float fs = (float)SI;
+            float4 f = make_float4(v.f.x * fs, v.f.y * fs, v.f.z * fs, v.f.w * fs);
+            if (HAS_PREV) {
+                const float4 o = ((const float4*)F)[pb];
+                f = make_float4(o.x + f.x, o.y + f.y, o.z + f.z, o.w + f.w);
+            }
+            ((float4*)F)[pb] = f;
+            const int cy = dy - OFF, cx = dx - OFF;
+            if (cy >= 0 && cy < NP && cx >= 0 && cx < NP) {
+                fc[cy * NP + cx] = f;
+                mc[cy * NP + cx] = v.m;
+            }
+        }
+    }
+    // ---- phase 2: warp both frame packs at the centre pixels, down-resize (weights 1/2), write X
+    const float* P0 = Ppool + (size_t)tasks.slot0[b] * pack_stride;
+    const float* P1 = Ppool + (size_t)tasks.slot1[b] * pack_stride;
+    const size_t hi_off = (size_t)Hp * Wp * 4;
+    const float tstep = tasks.t[b];
+    const WarpGeo g = make_warp_geo(Wp, Hp);
+    float r[24], row[20], o[20];
+#pragma unroll
+    for (int c = 0; c < 24; ++c) r[c] = 0.f;
+#pragma unroll 1
+    for (int k = 0; k < NP * NP; ++k) {  // rolled on purpose (register footprint of the gathers)
+        const int dy = k / NP, dx = k % NP;
+        float4 f = fc[0];
+        float m = mc[0];
+#pragma unroll
+        for (int q = 1; q < NP * NP; ++q) {  // select without dynamic register indexing
+            if (k == q) {
+                f = fc[q];
+                m = mc[q];
+            }
+        }
+        const int Y = yl * SP + OFF + dy, X = xl * SP + OFF + dx;
+        const Tap4 t0 = warp_taps(g, X, Y, f.x, f.y);
+        const Tap4 t1 = warp_taps(g, X, Y, f.z, f.w);
+        float4 a_lo, a_hi, b_lo, b_hi;
+        sample_pack<true>(P0, hi_off, t0, a_lo, a_hi);
+        sample_pack<true>(P1, hi_off, t1, b_lo, b_hi);
+        o[0] = a_lo.x; o[1] = a_lo.y; o[2] = a_lo.z;
+        o[3] = b_lo.x; o[4] = b_lo.y; o[5] = b_lo.z;
+        o[6] = a_hi.x; o[7] = a_hi.y; o[8] = a_hi.z; o[9] = a_hi.w;
+        o[10] = b_hi.x; o[11] = b_hi.y; o[12] = b_hi.z; o[13] = b_hi.w;
+        o[14] = tstep;
+        o[15] = m;
+        o[16] = f.x; o[17] = f.y; o[18] = f.z; o[19] = f.w;
+#pragma unroll
+        for (int c = 0; c < 20; ++c) row[c] = dx == 0 ? o[c] : __fadd_rn(0.5f * row[c], 0.5f * o[c]);
+        if (dx == NP - 1) {
+#pragma unroll
+            for (int c = 0; c < 20; ++c) r[c] = dy == 0 ? row[c] : __fadd_rn(0.5f * r[c], 0.5f * row[c]);
+        }
+    }
+    const float inv_s = 1.0f / (float)SP;
+#pragma unroll
+    for (int c = 16; c < 20; ++c) r[c] = r[c] * inv_s;  // interpolate(flow) * 1.0 / scale
+    float4* op = (float4*)Xo + (size_t)b * 6 * Hs * Ws + (size_t)yl * Ws + xl;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) op[(size_t)q * Hs * Ws] = make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
+}
+
+int stage_trans_launch(const float* Ppool, size_t pack_stride, const RifeTasks& tasks, int B, const float* T, float* F,
+                       float* X, int Hp, int Wp, int s_prev, int s_next, bool has_prev, hipStream_t st) {
+    VFI_REQUIRE(s_prev == 2 * s_next && (s_next == 4 || s_next == 2 || s_next == 1),
+                "stage_trans: scales %d -> %d not on the fused path", s_prev, s_next);
+    const int Hs = Hp / s_next, Ws = Wp / s_next;
+    const int tiles_x = cdiv(Ws, 16), tiles_y = cdiv(Hs, 16);
+    dim3 grid(tiles_x * tiles_y, B);
+    TraceScope ts("stage_trans", st);
+#define VFI_ST(SPV, HP) \
+    hipLaunchKernelGGL((stage_trans_kernel<SPV, HP>), grid, dim3(256), 0, st, Ppool, pack_stride, tasks, T, F, X, Hp, Wp, tiles_x)
+    if (s_next == 4) {
+        if (has_prev) VFI_ST(4, true); else VFI_ST(4, false);
+    } else if (s_next == 2) {
+        if (has_prev) VFI_ST(2, true); else VFI_ST(2, false);
+    } else {
+        if (has_prev) VFI_ST(1, true); else VFI_ST(1, false);
+    }
+#undef VFI_ST
     VFI_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -442,21 +573,20 @@ __global__ void final_blend_kernel(const float* __restrict__ Ppool, size_t pack_
     const int b = blockIdx.y;
     const int X = idx % W, Y = idx / W;
     const int Hs = Hp / s, Ws = Wp / s;
-    const float* Tb = T + (size_t)b * (Hs / 4) * (Ws / 4) * 128;
-    float val[5];
-    t_upsample<5>(Tb, Hs, Ws, s, Y, X, val);
+    const float* Tb = T + (size_t)b * Hs * Ws * 8;
+    const TVal tv = t_upsample(Tb, Hs, Ws, s, Y, X);
     const size_t pb = (size_t)b * Hp * Wp + (size_t)Y * Wp + X;
     const float fs = (float)s;
     const float4 o = ((const float4*)F)[pb];
-    const float4 f = make_float4(o.x + val[0] * fs, o.y + val[1] * fs, o.z + val[2] * fs, o.w + val[3] * fs);
+    const float4 f = make_float4(o.x + tv.f.x * fs, o.y + tv.f.y * fs, o.z + tv.f.z * fs, o.w + tv.f.w * fs);
     if (Fdbg) ((float4*)Fdbg)[pb] = f;
     const WarpGeo g = make_warp_geo(Wp, Hp);
     const Tap4 t0 = warp_taps(g, X, Y, f.x, f.y);
     const Tap4 t1 = warp_taps(g, X, Y, f.z, f.w);
     float4 a, bb, unused;
-    sample_pack<false>(Ppool + (size_t)tasks.slot0[b] * pack_stride, t0, a, unused);
-    sample_pack<false>(Ppool + (size_t)tasks.slot1[b] * pack_stride, t1, bb, unused);
-    const float m = 1.0f / (1.0f + expf(-val[4]));
+    sample_pack<false>(Ppool + (size_t)tasks.slot0[b] * pack_stride, 0, t0, a, unused);
+    sample_pack<false>(Ppool + (size_t)tasks.slot1[b] * pack_stride, 0, t1, bb, unused);
+    const float m = 1.0f / (1.0f + expf(-tv.m));
     const float om = 1.0f - m;
     float* op = out + ((size_t)b * H * W + idx) * 3;
     op[0] = fminf(fmaxf(a.x * m + bb.x * om, 0.f), 1.f);
@@ -475,15 +605,15 @@ int final_blend_launch(const float* Ppool, size_t pack_stride, const RifeTasks& 
     return 0;
 }
 
-// deconv+PixelShuffle result in plain NHWC [N,4H,4W,C4] from the parity-class layout (test entry)
+// deconv+PixelShuffle result in plain NHWC [N,4H,4W,C4] from the planar4 T layout (test entry, C4 <= 6)
 __global__ void t_to_nhwc_kernel(const float* __restrict__ T, float* __restrict__ out, int N, int Hq, int Wq, int C4) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int Hs = Hq * 4, Ws = Wq * 4;
     if (idx >= (long)N * Hs * Ws) return;
-    const int X = idx % Ws, Y = (idx / Ws) % Hs;
+    const long p = idx % ((long)Hs * Ws);
     const int n = idx / ((long)Hs * Ws);
-    const float* Tb = T + (size_t)n * Hq * Wq * 128;
-    for (int c = 0; c < C4; ++c) out[idx * C4 + c] = t_read(Tb, Wq, Y, X, c);
+    const float* Tb = T + (size_t)n * Hs * Ws * 8;
+    for (int c = 0; c < C4; ++c) out[idx * C4 + c] = Tb[((size_t)(c >> 2) * Hs * Ws + p) * 4 + (c & 3)];
 }
 int t_to_nhwc_launch(const float* T, float* out, int N, int Hq, int Wq, int C4, hipStream_t st) {
     const long total = (long)N * Hq * 4 * Wq * 4;

@@ -66,6 +66,10 @@ struct ConvArgs {
     int tiles_x, tiles_y;  // output tiles per image (filled by the launcher)
     int tap_y0, tap_x0;    // origin of the tap rectangle (3x3: -1,-1), ignored for grouped
     int ablate;            // profiling experiments only (second-generation kernel); 0 in production
+    int in_plane;          // 0: input is NHWC [.,.,in_cs]; >0: planar4 input, floats between 4-channel planes
+                           //    (image = in_cs/4 planes of [Hin][Win][4])
+    int out_mode;          // 0: NHWC store; 1 (grouped only): PixelShuffle(2) of the transposed conv, planar4
+                           //    [N][2][4*Hout][4*Wout][4] (channel c of Cout/4 -> plane c/4, component c%4)
 };
 
 struct ConvVariant {

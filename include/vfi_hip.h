@@ -106,8 +106,9 @@ int vfi_rife_interpolate(vfi_rife_t* net, int B, const int* slot0, const int* sl
                          const float* timestep, float* out_dev, void* stream);
 
 /* Debug taps for parity tests: copy internal tensors of the LAST interpolate call to host.
- * what: 0 = flow after stage `stage` [B,Hp,Wp,4];  1 = stage input X [B,Hs,Ws,Cx] of `stage`;
- *       2 = frame slot pack [Hp,Wp,8] (stage = slot).  Returns number of floats written or <0. */
+ * what: 0 = flow after stage `stage` [B,Hp,Wp,4];  1 = stage input X of `stage`, planar4 [B,Cx/4,Hs,Ws,4];
+ *       2 = frame slot pack, planar4 [2,Hp,Wp,4] = (rgb0 | encode features) (stage = slot).
+ * Returns number of floats written or <0. */
 int64_t vfi_rife_debug_read(vfi_rife_t* net, int what, int stage, float* host_buf, int64_t cap);
 int vfi_rife_debug_keep(vfi_rife_t* net, int on);
 

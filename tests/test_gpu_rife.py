@@ -84,13 +84,13 @@ def test_frame_pack_against_oracle(engine, sd):
         feat = rife_oracle.encode(sd, img)
     found = 0
     for slot in range(4):
-        pk = engine.debug_read(2, slot, hp * wp * 8).view(hp, wp, 8)
+        pk = engine.debug_read(2, slot, hp * wp * 8).view(2, hp, wp, 4)   # planar4: [rgb0 | features]
         for k in range(2):
-            if (pk[..., :3] - img[k].permute(1, 2, 0)).abs().max().item() == 0.0:
+            if (pk[0][..., :3] - img[k].permute(1, 2, 0)).abs().max().item() == 0.0:
                 found += 1
-                d = (pk[..., 4:8] - feat[k].permute(1, 2, 0)).abs().max().item()
-                assert d <= 2e-5, describe_diff(pk[..., 4:8], feat[k].permute(1, 2, 0), "encode features")
-                assert pk[..., 3].abs().max().item() == 0.0
+                d = (pk[1] - feat[k].permute(1, 2, 0)).abs().max().item()
+                assert d <= 2e-5, describe_diff(pk[1], feat[k].permute(1, 2, 0), "encode features")
+                assert pk[0][..., 3].abs().max().item() == 0.0
     assert found == 2, "frame packs not found / image channels not bit-exact"
 
 
@@ -116,6 +116,24 @@ def test_batch_invariance_and_determinism(engine, sd):
     c = run_tasks(engine, frames, tasks, batch_size=4)
     assert torch.equal(b, c), "run-to-run non-determinism"
     assert (a - b).abs().max().item() <= 1e-5, describe_diff(a, b, "batch 1 vs batch 4")
+
+
+def test_scale_factor_half(engine, sd):
+    """scale_factor=0.5 -> block scales [16,8,4,2]: exercises the un-fused stage kernels (16->8) and the
+    bilinear up-resize inside the output kernel (last scale 2)."""
+    from cfi_amd.rife import run_tasks
+
+    frames = synth.smooth_frames(2, 120, 200, seed=8, shift=3.0)
+    tasks = [(0, 0.5), (0, 0.7)]
+    got = run_tasks(engine, frames, tasks, batch_size=2, scale_factor=0.5)
+    x = frames.permute(0, 3, 1, 2)
+    ts = torch.tensor([0.5, 0.7]).view(-1, 1, 1, 1)
+    with torch.inference_mode():
+        want = rife_oracle.ifnet47_forward(sd, x[0:1].repeat(2, 1, 1, 1), x[1:2].repeat(2, 1, 1, 1), ts,
+                                           (16.0, 8.0, 4.0, 2.0)).clamp(0, 1).permute(0, 2, 3, 1)
+    assert (got - want).abs().max().item() <= TOL, describe_diff(got, want, "scale_factor 0.5")
+    with pytest.raises(RuntimeError):
+        run_tasks(engine, frames, tasks, batch_size=1, scale_factor=2.0)   # fractional block scale: not implemented
 
 
 def test_full_size_1080p(engine, sd):

@@ -9,4 +9,3 @@ d=json.load(open("gpurun_out/bench_b$b.json")); print("B=$b", d["value"], "fps",
 for k,v in d["kernels"].items(): print("   %-16s %3d calls %8.3f ms/step %5.1f%%" % (k, v["calls"], v["ms"]/d["steps"], 100*v["share"]))
 PY
 done
-echo "=== conv sweep"; timeout 900 python tools/conv_sweep.py 1 8 2>&1 | tee gpurun_out/conv_sweep.log | grep -E "best|rror|grouped" 
