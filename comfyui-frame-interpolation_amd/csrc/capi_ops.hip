@@ -92,10 +92,6 @@ int vfi_conv3x3(const float* in_dev, const float* weight_host, const float* bias
     a.out_cs = Cout;
     a.act = act;
     a.slope = slope;
-    {
-        static const char* env = getenv("VFI_CONV_ABLATE");  // profiling experiments (tools/conv_ablate.py)
-        a.ablate = env ? atoi(env) : 0;
-    }
     if (conv_launch(a, stride, false, v, st, nullptr)) return -1;
     VFI_CHECK_HIP(hipStreamSynchronize(st));  // temporaries are freed on return
     return 0;

@@ -258,23 +258,23 @@ static int n_cus_cached() {
 
 // Tile-shape heuristic, from tools/conv_sweep.py on MI355X (profiles/r01_conv_sweep_*.txt):
 //   * stride 1: second-generation (LDS-DMA, persistent) 16x16x64 tile for 64 channels, 16x8x64 for the
-//     other multiples of 64; 96 channels stay on the first generation's 16x8x32 tile;
-//   * stride 2 and the grouped transposed conv: first-generation small tiles.
+//     other multiples of 64, 16x8x96 for 96 channels;
+//   * stride 2 with Cout a multiple of 64: second generation 16x8x64; the other stride-2 shapes and the
+//     grouped transposed conv: first-generation small tiles.
 int conv_pick_variant(const ConvArgs& a, int stride, bool grouped) {
     const long px = (long)a.N * a.Hout * a.Wout;
     const long cus = n_cus_cached();
     if (grouped) return 13;
     const bool n3 = a.Cout_p % 96 == 0;
     const bool n2 = a.Cout_p % 64 == 0;
+    (void)cus;
     if (stride == 2) {
-        if (n2) return px * (a.Cout_p / 64) >= 64L * cus ? 8 : (a.Cin_p % 8 == 0 ? kConv2Base + 7 : 8);
-        if (n3) return 9;
-        return 10;
+        if (n2) return kConv2Base + 7;   // d2_m1n2
+        if (n3) return 9;                // s2_m1n3
+        return 10;                       // s2_m1n1
     }
-    if (n2) {
-        if (a.Cin_p % 8) return 4;
-        return a.Cout_p == 64 ? kConv2Base + 0 : kConv2Base + 2;
-    }
+    if (n2) return a.Cout_p == 64 ? kConv2Base + 0 : kConv2Base + 2;  // d1_m2n2 / d1_m1n2
+    if (n3) return px >= 100000 ? kConv2Base + 3 : 4;                  // d1_m1n3 / s1_m1n1
     return 4;
 }
 

@@ -156,7 +156,6 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
     }
 
     const int nchunks = a.Cin_p / CK;
-    const int abl = a.ablate;  // profiling experiments only (tools/conv_ablate.py); 0 in production
 
     int tile = blockIdx.x;
     if (tile >= T) return;
@@ -164,7 +163,7 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
     decode(tile, n, Y0, X0);
     make_avoff(Y0, X0, avoff);
     __amdgpu_buffer_rsrc_t rsrc = make_rsrc(n);
-    if (!(abl & 1)) issue(rsrc, avoff, 0, 0);
+    issue(rsrc, avoff, 0, 0);
     __syncthreads();  // LDS-DMA counts on vmcnt: the barrier's release drains it
     int buf = 0;
     for (;;) {
@@ -185,49 +184,50 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
             // keep the DMA queue one K-chunk ahead — across the tile boundary too, so the matrix pipe
             // never waits for a tile's first chunk and the previous tile's stores drain underneath
             if (k + 1 < nchunks) {
-                if (!(abl & 1)) issue(rsrc, avoff, k + 1, buf ^ 1);
+                issue(rsrc, avoff, k + 1, buf ^ 1);
             } else if (has_next) {
                 decode(ntile, nn, nY0, nX0);
                 make_avoff(nY0, nX0, navoff);
                 nrsrc = make_rsrc(nn);
-                if (!(abl & 1)) issue(nrsrc, navoff, 0, buf ^ 1);
+                issue(nrsrc, navoff, 0, buf ^ 1);
             }
-            const float* sb = smem + ((abl & 4) ? 0 : buf * G::BUF_FLOATS);
+            const float* sb = smem + buf * G::BUF_FLOATS;
+            // K-steps of this chunk, software-pipelined: the fragments of step s+1 are requested from LDS
+            // before the MFMAs of step s issue (two register sets), so one wave alone keeps the matrix pipe fed.
+            constexpr int NS = TAPS * C8;
+            f32x4 av[2][MT], bv[2][NT];
+            auto frag = [&](int st, f32x4(&fa)[MT], f32x4(&fb)[NT]) {
+                const int t = st / C8, c8 = st % C8;
+                const int toff = ((t / KW) * TWI + (t % KW)) * CK + c8 * 8;
 #pragma unroll
-            for (int t = 0; t < TAPS; ++t) {
-                const int toff = ((t / KW) * TWI + (t % KW)) * CK;
+                for (int mt = 0; mt < MT; ++mt) fa[mt] = *(const f32x4*)&sb[abase[mt] + toff];
 #pragma unroll
-                for (int c8 = 0; c8 < C8; ++c8) {
-                    f32x4 av[MT], bv[NT];
+                for (int nt = 0; nt < NT; ++nt)
+                    fb[nt] = *(const f32x4*)&sb[bbase + ((t * C8 + c8) * BN + nt * 32) * 8];
+            };
+            frag(0, av[0], bv[0]);
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) av[mt] = *(const f32x4*)&sb[abase[mt] + ((abl & 4) ? 0 : toff + c8 * 8)];
+            for (int st = 0; st < NS; ++st) {
+                if (st + 1 < NS) frag(st + 1, av[(st + 1) & 1], bv[(st + 1) & 1]);
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        bv[nt] = *(const f32x4*)&sb[bbase + ((abl & 4) ? 0 : ((t * C8 + c8) * BN + nt * 32) * 8)];
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt)
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt][j], bv[nt][j], acc[mt][nt], 0, 0, 0);
-                }
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st & 1][mt][j], bv[st & 1][nt][j],
+                                                                               acc[mt][nt], 0, 0, 0);
+                // pin the order "LDS reads of step s+1, then the MFMAs of step s" (hipcc otherwise sinks the reads
+                // next to their first use and exposes the LDS latency once per step)
+                if (st + 1 < NS) __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT * NT, 0);
             }
-            if (!(abl & 8)) __syncthreads();  // chunk consumed by every wave; the next chunk has landed
+            __syncthreads();  // chunk consumed by every wave; the next chunk has landed
             buf ^= 1;
         }
 
         // ---- epilogue (stores are fire-and-forget; the next tile's MFMAs start right behind them)
-        if (abl & 2) {  // keep the accumulators alive without the store traffic
-            float sacc = 0.f;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sacc += acc[mt][nt][r];
-            if (sacc == 123.456f) a.out[tid] = sacc;
-        } else {
+        {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int co = co0 + nt * 32 + l31;
@@ -309,9 +309,12 @@ static int launch2_t(ConvArgs a, hipStream_t s, const char* name) {
     }
     const int T = a.N * a.tiles_x * a.tiles_y;
     const int ny = a.Cout_p / G::BN;
-    int gx = (cus * occ) / ny;  // persistent: one resident wave of workgroups, each walks its share of tiles
+    // Persistent (one resident wave of workgroups, each walks its share of tiles, DMA pipelined across tiles)
+    // when every workgroup gets several tiles; with only a few tiles per slot a static split leaves some
+    // CUs a whole tile behind, so then launch one workgroup per tile and let the dispatcher balance.
+    int gx = (cus * occ) / ny;
     if (gx < 1) gx = 1;
-    if (gx > T) gx = T;
+    if (gx > T || (long)T * ny < 4L * cus * occ) gx = T;
     dim3 grid(gx, ny);
     TraceScope ts(name, s);
     hipLaunchKernelGGL((conv_mfma2_kernel<STRIDE, TAPS, MT, NT, WM, WN, CK, GROUPED>), grid, dim3(256), G::LDS_BYTES, s, a);

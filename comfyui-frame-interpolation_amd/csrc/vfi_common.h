@@ -65,7 +65,6 @@ struct ConvArgs {
     float slope;
     int tiles_x, tiles_y;  // output tiles per image (filled by the launcher)
     int tap_y0, tap_x0;    // origin of the tap rectangle (3x3: -1,-1), ignored for grouped
-    int ablate;            // profiling experiments only (second-generation kernel); 0 in production
     int in_plane;          // 0: input is NHWC [.,.,in_cs]; >0: planar4 input, floats between 4-channel planes
                            //    (image = in_cs/4 planes of [Hin][Win][4])
     int out_mode;          // 0: NHWC store; 1 (grouped only): PixelShuffle(2) of the transposed conv, planar4
