@@ -33,33 +33,43 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip ta
 
 
 def cpu_baseline(sd, H, W, budget_s=25.0):
-    """Oracle on the host cores: 1 warm-up + up to 3 timed 1080p forwards (bounded by budget_s)."""
+    """Oracle on the host cores, bounded sample: for a few thread counts (all cores is often NOT the fastest
+    on a many-core host), 1 warm-up + 2 timed 1080p forwards each; report the best median."""
     from cfi_amd import synth
     from oracle import rife_oracle
 
     frames = synth.smooth_frames(2, H, W, seed=2, shift=4.0)
     x = frames.permute(0, 3, 1, 2)
     ts = torch.tensor([0.5]).view(1, 1, 1, 1)
-    times = []
+    default = torch.get_num_threads()
+    cands = sorted({default, max(1, default // 2), max(1, default // 4)}, reverse=True)
+    best = None
+    tried = []
     t_begin = time.time()
     with torch.inference_mode():
-        for i in range(4):
-            t0 = time.time()
-            rife_oracle.ifnet47_forward(sd, x[0:1], x[1:2], ts)
-            dt = time.time() - t0
-            if i > 0:
-                times.append(dt)
-            if time.time() - t_begin > budget_s and times:
+        for nt in cands:
+            if best is not None and time.time() - t_begin > budget_s:
                 break
-    times.sort()
-    med = times[len(times) // 2]
+            torch.set_num_threads(nt)
+            times = []
+            for i in range(3):
+                t0 = time.time()
+                rife_oracle.ifnet47_forward(sd, x[0:1], x[1:2], ts)
+                if i > 0:
+                    times.append(time.time() - t0)
+            med = sorted(times)[len(times) // 2]
+            tried.append((nt, round(med, 3)))
+            if best is None or med < best[1]:
+                best = (nt, med)
+    torch.set_num_threads(default)
     return {
-        "value": round(1.0 / med, 4),
+        "value": round(1.0 / best[1], 4),
         "unit": "interpolated frames/s",
-        "cores": torch.get_num_threads(),
+        "cores": best[0],
         "kind": "port",
-        "sample": f"{len(times)} timed + 1 warm-up forwards of oracle.rife_oracle.ifnet47_forward (torch-CPU fp32, "
-                  f"bit-exact vs reference IFNet('4.7') in the build container), 1 pair {H}x{W}, median {med:.3f} s/frame",
+        "sample": f"oracle.rife_oracle.ifnet47_forward (torch-CPU fp32 restatement, bit-exact vs the reference's IFNet('4.7') "
+                  f"in the build container), 1 pair {H}x{W}; per thread count 1 warm-up + 2 timed forwards, "
+                  f"(threads, median s/frame) tried: {tried}; best reported",
     }
 
 

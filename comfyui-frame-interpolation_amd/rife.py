@@ -136,29 +136,61 @@ class _FrameSlots:
 _model_cache: typing.Dict[typing.Tuple, RifeEngine] = {}
 
 
-def run_tasks(engine, frames_cpu, tasks, batch_size, scale_factor=1.0, out_device=False):
-    """Interpolate ``tasks`` = [(pair, t), ...] over CPU frames [N,H,W,C]; returns [len(tasks),H,W,3]
-    (CPU tensor, or device tensor when ``out_device``)."""
+def run_tasks(engine, frames_cpu, tasks, batch_size, scale_factor=1.0, out_device=False, out=None, out_rows=None):
+    """Interpolate ``tasks`` = [(pair, t), ...] over CPU frames [N,H,W,C].
+
+    Returns [len(tasks),H,W,3] (CPU tensor, or device tensor when ``out_device``).  With ``out``/``out_rows`` the
+    new frame of task i is written straight into ``out[out_rows[i]]`` (the node's final output tensor) instead.
+
+    Host pipeline: device outputs are double-buffered and batch k is copied back on a side stream while
+    batch k+1 computes; each input frame is uploaded once and its pad/encode result cached on the device."""
     n, H, W, _ = frames_cpu.shape
     bs = max(1, min(int(batch_size), MAX_LIB_BATCH))
     n_slots = 2 * bs + 2
     engine.configure(H, W, bs, n_slots, scale_factor)
     slots = _FrameSlots(engine, frames_cpu, n_slots)
     dev = engine.device
-    out = torch.empty((len(tasks), H, W, 3), dtype=torch.float32, device=dev if out_device else "cpu")
+    if out_device:
+        res = torch.empty((len(tasks), H, W, 3), dtype=torch.float32, device=dev)
+    elif out is None:
+        res = torch.empty((len(tasks), H, W, 3), dtype=torch.float32)
+        out, out_rows = res, list(range(len(tasks)))
+    else:
+        res = out
+    main = torch.cuda.current_stream(dev)
+    copy_stream = torch.cuda.Stream(dev)
+    bufs = [torch.empty((bs, H, W, 3), dtype=torch.float32, device=dev) for _ in range(2)] if not out_device else None
+    done = [torch.cuda.Event(), torch.cuda.Event()]
+    pending = None  # (buffer index, first task, count) of the batch whose copy-back is outstanding
+
+    def drain(p):
+        k, first, cnt = p
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(done[k])
+            for i in range(cnt):
+                out[out_rows[first + i]].copy_(bufs[k][i])  # device -> host, directly into its final row
+        copy_stream.synchronize()
+
     pos = 0
+    k = 0
     while pos < len(tasks):
         bt = tasks[pos:pos + bs]
         need = []
         for p, _ in bt:
             need += [p, p + 1]
         m = slots.ensure(need)
-        buf = out[pos:pos + len(bt)] if out_device else torch.empty((len(bt), H, W, 3), dtype=torch.float32, device=dev)
+        buf = res[pos:pos + len(bt)] if out_device else bufs[k][:len(bt)]
         engine.interpolate([m[p] for p, _ in bt], [m[p + 1] for p, _ in bt], [t for _, t in bt], buf)
         if not out_device:
-            out[pos:pos + len(bt)] = buf.cpu()
+            done[k].record(main)
+            if pending is not None:
+                drain(pending)  # overlaps with the batch just enqueued
+            pending = (k, pos, len(bt))
+            k ^= 1
         pos += len(bt)
-    return out
+    if pending is not None:
+        drain(pending)
+    return res
 
 
 class RIFE_VFI:
@@ -221,18 +253,25 @@ class RIFE_VFI:
         frames = frames[..., :3]  # preprocess_frames: drop alpha; layout stays NHWC on this path
         n = len(frames)
         _, tasks = rife_task_list(n, multiplier, optional_interpolation_states)
+        plan = rife_output_plan(n, tasks)
+        out = torch.empty((len(plan),) + tuple(frames.shape[1:]), dtype=torch.float32)
+        src_rows = [i for i, (kind, _) in enumerate(plan) if kind == "src"]
+        src_idx = [idx for kind, idx in plan if kind == "src"]
+        new_rows = [0] * len(tasks)
+        for i, (kind, idx) in enumerate(plan):
+            if kind == "new":
+                new_rows[idx] = i
+        # pass-through frames: one vectorised copy (bit-exact), alpha already dropped
+        out.index_copy_(0, torch.tensor(src_rows, dtype=torch.long), frames.index_select(0, torch.tensor(src_idx, dtype=torch.long)).to(torch.float32))
         rank, ws = world()
         if ws > 1:
             lo, hi = shard_tasks(tasks, rank, ws)
             counts = [shard_tasks(tasks, r, ws)[1] - shard_tasks(tasks, r, ws)[0] for r in range(ws)]
             local = run_tasks(engine, frames, tasks[lo:hi], batch_size, scale_factor, out_device=True)
-            new_frames = all_gather_frames(local, counts).cpu()
+            new_frames = all_gather_frames(local, counts)
+            for i in range(len(tasks)):
+                out[new_rows[i]].copy_(new_frames[i])
         else:
-            new_frames = run_tasks(engine, frames, tasks, batch_size, scale_factor)
-
-        plan = rife_output_plan(n, tasks)
-        out = torch.empty((len(plan),) + tuple(frames.shape[1:]), dtype=torch.float32)
-        for i, (kind, idx) in enumerate(plan):
-            out[i] = frames[idx] if kind == "src" else new_frames[idx]
+            run_tasks(engine, frames, tasks, batch_size, scale_factor, out=out, out_rows=new_rows)
         print(f"Comfy-VFI done! {len(plan)} frames generated")
         return (out,)
