@@ -73,6 +73,23 @@ int vfi_conv3x3_naive(const float* in_dev, const float* weight_host, const float
 int vfi_deconv4x4_ps2(const float* in_dev, const float* weight_host, const float* bias_host,
                       float* out_dev, int N, int H, int W, int Cin, int Cout, void* stream);
 
+/* ---- M2M custom ops ---------------------------------------------------------------------- */
+
+/* Summation splat (forward warp): out[n, y', x', c] += in[n,y,x,c] * bilinear weight at the 4 integer
+ * neighbours of (x + flow_x, y + flow_y); out-of-image targets dropped, non-finite targets skipped.
+ * `out` is zeroed by the call.  Replaces softsplat_func.forward / the softsplat_out CUDA kernel,
+ * vfi_models/ops/cupy_ops/softsplat.py:140-233.   in/out [N,H,W,C], flow [N,H,W,2] (NHWC). */
+int vfi_softsplat_sum(const float* in_dev, const float* flow_dev, float* out_dev, int N, int H, int W, int C,
+                      void* stream);
+
+/* 9x9 mean-L1 cost volume: out[n,y,x, out_coff + 9*(dy+4)+(dx+4)] = mean_c |one[n,y,x,c] - two[n,y+dy,x+dx,c]|,
+ * out-of-image (y+dy,x+dx) -> mean_c |one|.  Replaces costvol_func.forward / costvol_out,
+ * vfi_models/ops/cupy_ops/costvol.py:4-43,135-183.   one/two [N,H,W,C] (C % 4 == 0); out [N,H,W,out_cs]:
+ * the 81 channels are written at channel offset out_coff of a wider NHWC tensor (the reference's
+ * torch.cat of the volume with features, vfi_models/m2m/M2M_arch.py:484-490, then costs nothing). */
+int vfi_costvol9x9(const float* one_dev, const float* two_dev, float* out_dev, int N, int H, int W, int C,
+                   int out_cs, int out_coff, void* stream);
+
 /* ---- RIFE 4.7 / 4.9 model --------------------------------------------------------------- */
 
 typedef struct vfi_rife vfi_rife_t;

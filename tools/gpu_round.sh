@@ -2,6 +2,5 @@
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-echo "=== pytest node tests"; timeout 600 python -m pytest tests/test_gpu_rife.py -q -m gpu --no-header -rf 2>&1 | tail -8
-echo "=== node e2e"; timeout 300 python tools/node_e2e.py 33 8 2>&1 | grep "node e2e"
-timeout 300 python tools/node_e2e.py 33 1 2>&1 | grep "node e2e"
+for m in 0 1 2; do echo "=== splat mode $m"; VFI_SPLAT_MODE=$m timeout 300 python tools/splat_bench.py 2>&1 | grep -E "softsplat" | cut -c1-250; done
+echo "=== tests mode 1"; VFI_SPLAT_MODE=1 timeout 300 python -m pytest tests/test_gpu_m2m_ops.py -q -m gpu --no-header -k splat 2>&1 | tail -3
