@@ -8,6 +8,7 @@ scheduler does not require the HIP library to be built.
 
 _LAZY = {
     "RIFE_VFI": ("rife", "RIFE_VFI"),
+    "FILM_VFI": ("film", "FILM_VFI"),
     "MakeInterpolationStateList": ("schedule", "MakeInterpolationStateList"),
     "InterpolationStateList": ("schedule", "InterpolationStateList"),
 }
@@ -25,15 +26,18 @@ def __getattr__(name):
 
 
 def _node_class_mappings():
+    from .film import FILM_VFI
     from .rife import RIFE_VFI
     from .schedule import MakeInterpolationStateList
 
     return {
         "RIFE VFI": RIFE_VFI,
+        "FILM VFI": FILM_VFI,
         "Make Interpolation State List": MakeInterpolationStateList,
     }
 
 
 NODE_DISPLAY_NAME_MAPPINGS = {
     "RIFE VFI": "RIFE VFI (MI355X HIP; rife47 / rife49)",
+    "FILM VFI": "FILM VFI (MI355X HIP)",
 }

@@ -186,6 +186,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
                     if (a.beta) v *= bt;
                     if (a.res) v += a.res[p * a.res_cs + co];
                     if (a.act == 1) v = v > 0.f ? v : v * a.slope;
+                        else if (a.act == 2) v = fminf(fmaxf(v, 0.f), 1.f);
                     if (GROUPED && a.out_mode == 1) {
                         const int Ws = 4 * a.Wout, Hs = 4 * a.Hout, c = co >> 2;
                         const int Yt = 4 * oy + 2 * (g >> 1) + ((co >> 1) & 1), Xt = 4 * ox + 2 * (g & 1) + (co & 1);
@@ -263,6 +264,11 @@ static int n_cus_cached() {
 //     grouped transposed conv: first-generation small tiles.
 int conv_pick_variant(const ConvArgs& a, int stride, bool grouped) {
     const long px = (long)a.N * a.Hout * a.Wout;
+    if (!grouped && stride == 1 && a.ntaps != 9) {  // 2x2 'same' / 1x1 convs (FILM): second generation only
+        const bool big = px * (a.Cout_p / 32) >= 256L * 4 * n_cus_cached();
+        if (a.Cout_p % 64 == 0) return kConv2Base + (a.ntaps == 4 ? (big ? 14 : 15) : (big ? 16 : 17));
+        return kConv2Base + (a.ntaps == 4 ? 19 : 18);
+    }
     const long cus = n_cus_cached();
     if (grouped) return 13;
     const bool n3 = a.Cout_p % 96 == 0;
@@ -275,7 +281,7 @@ int conv_pick_variant(const ConvArgs& a, int stride, bool grouped) {
     }
     if (n2) return a.Cout_p == 64 ? kConv2Base + 0 : kConv2Base + 2;  // d1_m2n2 / d1_m1n2
     if (n3) return px >= 100000 ? kConv2Base + 3 : 4;                  // d1_m1n3 / s1_m1n1
-    return 4;
+    return a.Cin_p % 16 == 0 && px < 20000 ? 4 : kConv2Base + 13;      // 32-channel N tile: s1_m1n1 / d1_m2n1
 }
 
 int conv_launch(const ConvArgs& a, int stride, bool grouped, int variant, hipStream_t s,

@@ -256,6 +256,7 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
                         if (a.beta) v *= bt[nt];
                         if (a.res) v += rv[r];
                         if (a.act == 1) v = v > 0.f ? v : v * a.slope;
+                        else if (a.act == 2) v = fminf(fmaxf(v, 0.f), 1.f);
                         if (cok && oy < a.Hout && ox < a.Wout) {
                             if (GROUPED && a.out_mode == 1) {
                                 const int Ws = 4 * a.Wout, Hs = 4 * a.Hout, c = co >> 2;
@@ -338,6 +339,13 @@ static const ConvVariant kVariants2[] = {
     {"d2_m2n1", 2, 9, 2, 1, 4, 1, 8, 0},      // 42: stride 2, 16x16 px x 32 ch
     {"dg_m4", 1, 4, 4, 1, 1, 4, 8, 1},        // 43: grouped 16x8 px
     {"dg_m8", 1, 4, 8, 1, 1, 4, 8, 1},        // 44: grouped 16x16 px
+    {"d1_m2n1", 1, 9, 2, 1, 4, 1, 8, 0},      // 45: 3x3, 16x16 px x 32 ch
+    {"d1t4_m2n2", 1, 4, 2, 2, 4, 1, 8, 0},    // 46: 2x2 taps (FILM 'same' conv, pad bottom/right)
+    {"d1t4_m1n2", 1, 4, 1, 2, 4, 1, 8, 0},    // 47
+    {"d1t1_m2n2", 1, 1, 2, 2, 4, 1, 8, 0},    // 48: 1x1
+    {"d1t1_m1n2", 1, 1, 1, 2, 4, 1, 8, 0},    // 49
+    {"d1t1_m2n1", 1, 1, 2, 1, 4, 1, 8, 0},    // 50: 1x1, 32-channel N tile
+    {"d1t4_m2n1", 1, 4, 2, 1, 4, 1, 8, 0},    // 51
 };
 int conv2_num_variants() { return (int)(sizeof(kVariants2) / sizeof(kVariants2[0])); }
 const ConvVariant& conv2_variant(int i) { return kVariants2[i]; }
@@ -357,6 +365,13 @@ int conv2_launch(const ConvArgs& a, int idx, hipStream_t s, const char* nm) {
         case 10: return launch2_t<2, 9, 2, 1, 4, 1, 8, false>(a, s, nm);
         case 11: return launch2_t<1, 4, 4, 1, 1, 4, 8, true>(a, s, nm);
         case 12: return launch2_t<1, 4, 8, 1, 1, 4, 8, true>(a, s, nm);
+        case 13: return launch2_t<1, 9, 2, 1, 4, 1, 8, false>(a, s, nm);
+        case 14: return launch2_t<1, 4, 2, 2, 4, 1, 8, false>(a, s, nm);
+        case 15: return launch2_t<1, 4, 1, 2, 4, 1, 8, false>(a, s, nm);
+        case 16: return launch2_t<1, 1, 2, 2, 4, 1, 8, false>(a, s, nm);
+        case 17: return launch2_t<1, 1, 1, 2, 4, 1, 8, false>(a, s, nm);
+        case 18: return launch2_t<1, 1, 2, 1, 4, 1, 8, false>(a, s, nm);
+        case 19: return launch2_t<1, 4, 2, 1, 4, 1, 8, false>(a, s, nm);
     }
     set_error("conv2: bad variant %d", idx);
     return -3;

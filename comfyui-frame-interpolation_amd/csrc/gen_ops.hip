@@ -1,0 +1,299 @@
+// Generic NHWC fp32 building blocks behind the C ABI, used by the FILM path (film.py): every tensor argument is
+// a pointer to the first channel of a channel WINDOW inside a possibly wider NHWC tensor (`*_cs` = floats per
+// pixel of the underlying tensor), so torch.cat along channels never materialises — producers write their slice.
+//
+// Reference semantics restated (vfi_models/film/film_arch.py): conv helper 'same' padding :784-798 (2x2 kernels
+// pad bottom/right), avg_pool2d pyramids :655-674, warp (align_corners=False, border) :677-724, bilinear flow
+// up-sampling F.interpolate(2*v, size=...) :597,610,752, nearest up-sampling :286.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+
+#include "../../include/vfi_hip.h"
+#include "vfi_common.h"
+
+namespace vfi {
+
+struct Bil2 {
+    int i0, i1;
+    float w0, w1;
+};
+// torch area_pixel_compute_source_index(scale, dst, align_corners=False) + guard_index_and_lambda
+__device__ static inline Bil2 bil2(int d, float rscale, int in_size) {
+    float src = __fsub_rn(__fmul_rn(rscale, __fadd_rn((float)d, 0.5f)), 0.5f);
+    if (src < 0.f) src = 0.f;
+    int i0 = (int)floorf(src);
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    float l = fminf(fmaxf(__fsub_rn(src, (float)i0), 0.f), 1.f);
+    Bil2 b;
+    b.i0 = i0;
+    b.i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    b.w1 = l;
+    b.w0 = __fsub_rn(1.0f, l);
+    return b;
+}
+
+// ---- avg_pool2d(2, 2): out[y][x] = (((a + b) + c) + d) / 4, odd sizes floor -------------------------------
+__global__ void avgpool2_kernel(const float* __restrict__ in, int in_cs, float* __restrict__ out, int out_cs, int N,
+                                int H, int W, int C4) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)N * Ho * Wo * C4) return;
+    const int q = idx % C4;
+    long p = idx / C4;
+    const int x = p % Wo;
+    p /= Wo;
+    const int y = p % Ho;
+    const int n = p / Ho;
+    const float* b = in + ((size_t)(n * H + 2 * y) * W + 2 * x) * in_cs + q * 4;
+    const float4 a0 = *(const float4*)b, a1 = *(const float4*)(b + in_cs);
+    const float4 b0 = *(const float4*)(b + (size_t)W * in_cs), b1 = *(const float4*)(b + (size_t)W * in_cs + in_cs);
+    float4 r;
+    r.x = __fmul_rn(__fadd_rn(__fadd_rn(__fadd_rn(a0.x, a1.x), b0.x), b1.x), 0.25f);
+    r.y = __fmul_rn(__fadd_rn(__fadd_rn(__fadd_rn(a0.y, a1.y), b0.y), b1.y), 0.25f);
+    r.z = __fmul_rn(__fadd_rn(__fadd_rn(__fadd_rn(a0.z, a1.z), b0.z), b1.z), 0.25f);
+    r.w = __fmul_rn(__fadd_rn(__fadd_rn(__fadd_rn(a0.w, a1.w), b0.w), b1.w), 0.25f);
+    *(float4*)(out + ((size_t)(n * Ho + y) * Wo + x) * out_cs + q * 4) = r;
+}
+
+// ---- nearest up-sampling to a given size: src = min(floor(dst * in/out), in-1) -----------------------------
+__global__ void upsample_nearest_kernel(const float* __restrict__ in, int in_cs, float* __restrict__ out, int out_cs,
+                                        int N, int Hi, int Wi, int Ho, int Wo, int C4, float sy, float sx) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)N * Ho * Wo * C4) return;
+    const int q = idx % C4;
+    long p = idx / C4;
+    const int x = p % Wo;
+    p /= Wo;
+    const int y = p % Ho;
+    const int n = p / Ho;
+    const int iy = min((int)floorf(__fmul_rn((float)y, sy)), Hi - 1);
+    const int ix = min((int)floorf(__fmul_rn((float)x, sx)), Wi - 1);
+    *(float4*)(out + ((size_t)(n * Ho + y) * Wo + x) * out_cs + q * 4) =
+        *(const float4*)(in + ((size_t)(n * Hi + iy) * Wi + ix) * in_cs + q * 4);
+}
+
+// ---- bilinear resize to a given size, align_corners=False, input pre-multiplied by `mul` -------------------
+__global__ void resize_bilinear_kernel(const float* __restrict__ in, int in_cs, float* __restrict__ out, int out_cs,
+                                       int N, int Hi, int Wi, int Ho, int Wo, int C, float sy, float sx, float mul) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)N * Ho * Wo) return;
+    const int x = idx % Wo, y = (idx / Wo) % Ho;
+    const int n = idx / ((long)Wo * Ho);
+    const Bil2 by = bil2(y, sy, Hi), bx = bil2(x, sx, Wi);
+    const float* b = in + (size_t)n * Hi * Wi * in_cs;
+    float* o = out + (size_t)idx * out_cs;
+    for (int c = 0; c < C; ++c) {
+        const float a = __fmul_rn(b[((size_t)by.i0 * Wi + bx.i0) * in_cs + c], mul);
+        const float bb = __fmul_rn(b[((size_t)by.i0 * Wi + bx.i1) * in_cs + c], mul);
+        const float cc = __fmul_rn(b[((size_t)by.i1 * Wi + bx.i0) * in_cs + c], mul);
+        const float d = __fmul_rn(b[((size_t)by.i1 * Wi + bx.i1) * in_cs + c], mul);
+        o[c] = __fadd_rn(__fmul_rn(by.w0, __fadd_rn(__fmul_rn(bx.w0, a), __fmul_rn(bx.w1, bb))),
+                         __fmul_rn(by.w1, __fadd_rn(__fmul_rn(bx.w0, cc), __fmul_rn(bx.w1, d))));
+    }
+}
+
+// ---- FILM warp: out(x,y) = bilinear(image, x + fx*mul, y + fy*mul), border clamp, align_corners=False ------
+// fp32 expression order of film_arch.warp + grid_sample: grid = linspace(-(1-1/W), 1-1/W, W)[x] + f/(W*0.5);
+// ix = ((grid + 1) * W - 1) / 2, clipped to [0, W-1].
+__device__ static inline float lin_ls(int i, int n, float startf, float endf, float step) {
+    return i < n / 2 ? __fadd_rn(startf, __fmul_rn(step, (float)i)) : __fsub_rn(endf, __fmul_rn(step, (float)(n - 1 - i)));
+}
+__global__ void warp_film_kernel(const float* __restrict__ in, int in_cs, const float* __restrict__ flow, int flow_cs,
+                                 float fmul, float* __restrict__ out, int out_cs, int N, int H, int W, int C4,
+                                 float sx0, float sx1, float stepx, float sy0, float sy1, float stepy) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)N * H * W * C4) return;
+    const int q = idx % C4;
+    const long p = idx / C4;
+    const int x = p % W, y = (p / W) % H;
+    const int n = p / ((long)W * H);
+    const float fx = __fmul_rn(flow[p * flow_cs], fmul), fy = __fmul_rn(flow[p * flow_cs + 1], fmul);
+    // grid = lin - ((-f) / (size*0.5))
+    const float gx = __fsub_rn(lin_ls(x, W, sx0, sx1, stepx), __fdiv_rn(-fx, __fmul_rn((float)W, 0.5f)));
+    const float gy = __fsub_rn(lin_ls(y, H, sy0, sy1, stepy), __fdiv_rn(-fy, __fmul_rn((float)H, 0.5f)));
+    float px = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(gx, 1.0f), (float)W), 1.0f), 2.0f);
+    float py = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(gy, 1.0f), (float)H), 1.0f), 2.0f);
+    px = fminf((float)(W - 1), fmaxf(px, 0.f));
+    py = fminf((float)(H - 1), fmaxf(py, 0.f));
+    const float x0f = floorf(px), y0f = floorf(py);
+    const float w = __fsub_rn(px, x0f), e = __fsub_rn(1.0f, w), nn = __fsub_rn(py, y0f), s = __fsub_rn(1.0f, nn);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const int x1 = x0 + (x0 < W - 1 ? 1 : 0), y1 = y0 + (y0 < H - 1 ? 1 : 0);
+    const float nw = __fmul_rn(s, e), ne = __fmul_rn(s, w), sw = __fmul_rn(nn, e), se = __fmul_rn(nn, w);
+    const float* b = in + (size_t)n * H * W * in_cs + q * 4;
+    const float4 a = *(const float4*)(b + ((size_t)y0 * W + x0) * in_cs), bb = *(const float4*)(b + ((size_t)y0 * W + x1) * in_cs);
+    const float4 c = *(const float4*)(b + ((size_t)y1 * W + x0) * in_cs), d = *(const float4*)(b + ((size_t)y1 * W + x1) * in_cs);
+    float4 r;
+    r.x = a.x * nw + bb.x * ne + c.x * sw + d.x * se;
+    r.y = a.y * nw + bb.y * ne + c.y * sw + d.y * se;
+    r.z = a.z * nw + bb.z * ne + c.z * sw + d.z * se;
+    r.w = a.w * nw + bb.w * ne + c.w * sw + d.w * se;
+    *(float4*)(out + p * out_cs + q * 4) = r;
+}
+
+// ---- out = alpha * a + beta * b (b may be null), arbitrary channel windows -------------------------------
+__global__ void axpby_kernel(const float* __restrict__ a, int a_cs, const float* __restrict__ b, int b_cs,
+                             float* __restrict__ out, int out_cs, long px, int C, float alpha, float beta) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= px * C) return;
+    const int c = idx % C;
+    const long p = idx / C;
+    float v = __fmul_rn(a[p * a_cs + c], alpha);
+    if (b) v = __fadd_rn(v, __fmul_rn(b[p * b_cs + c], beta));
+    out[p * out_cs + c] = v;
+}
+
+}  // namespace vfi
+
+using namespace vfi;
+
+struct vfi_conv {
+    float* w = nullptr;
+    float* bias = nullptr;
+    int Cout = 0, Cout_p = 0, Cin = 0, Cin_p = 0, kh = 0, kw = 0, taps = 0;
+};
+
+static unsigned nblk(long n) { return (unsigned)((n + 255) / 256); }
+
+extern "C" {
+
+vfi_conv_t* vfi_conv_create(const float* w_oihw_host, const float* bias_host, int Cout, int Cin, int kh, int kw,
+                            const int* chan_map, int Cin_phys) {
+    if (!w_oihw_host || Cout <= 0 || Cin <= 0 || kh != kw || (kh != 1 && kh != 2 && kh != 3) || Cin_phys % 8 || Cin_phys < Cin) {
+        set_error("vfi_conv_create: bad arguments (Cout=%d Cin=%d k=%dx%d Cin_phys=%d; k in {1,2,3}, Cin_phys a multiple of 8)",
+                  Cout, Cin, kh, kw, Cin_phys);
+        return nullptr;
+    }
+    vfi_conv* c = new vfi_conv();
+    c->Cout = Cout;
+    c->Cout_p = round_up(Cout, 32);
+    c->Cin = Cin;
+    c->Cin_p = Cin_phys;
+    c->kh = kh;
+    c->kw = kw;
+    c->taps = kh * kw;
+    const int cin8 = Cin_phys / 8;
+    std::vector<float> wp((size_t)c->taps * cin8 * c->Cout_p * 8, 0.f), bp(c->Cout_p, 0.f);
+    for (int co = 0; co < Cout; ++co) {
+        if (bias_host) bp[co] = bias_host[co];
+        for (int ci = 0; ci < Cin; ++ci) {
+            const int pc = chan_map ? chan_map[ci] : ci;
+            if (pc < 0 || pc >= Cin_phys) {
+                set_error("vfi_conv_create: chan_map[%d]=%d outside 0..%d", ci, pc, Cin_phys - 1);
+                delete c;
+                return nullptr;
+            }
+            for (int t = 0; t < c->taps; ++t)
+                wp[(((size_t)t * cin8 + pc / 8) * c->Cout_p + co) * 8 + (pc & 7)] = w_oihw_host[((size_t)co * Cin + ci) * c->taps + t];
+        }
+    }
+    if (hipMalloc((void**)&c->w, wp.size() * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&c->bias, bp.size() * sizeof(float)) != hipSuccess ||
+        hipMemcpy(c->w, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->bias, bp.data(), bp.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        set_error("vfi_conv_create: device allocation/upload failed");
+        vfi_conv_destroy(c);
+        return nullptr;
+    }
+    return c;
+}
+
+void vfi_conv_destroy(vfi_conv_t* c) {
+    if (!c) return;
+    if (c->w) (void)hipFree(c->w);
+    if (c->bias) (void)hipFree(c->bias);
+    delete c;
+}
+
+int vfi_conv_forward(const vfi_conv_t* c, const float* in_dev, int in_cs, float* out_dev, int out_cs, int N, int H, int W,
+                     int act, float slope, void* stream) {
+    VFI_REQUIRE(c && in_dev && out_dev && N > 0 && H > 0 && W > 0, "vfi_conv_forward: bad arguments");
+    VFI_REQUIRE(in_cs >= c->Cin_p && in_cs % 4 == 0 && ((uintptr_t)in_dev & 15) == 0,
+                "vfi_conv_forward: input window must hold %d channels, 16-byte aligned (in_cs=%d)", c->Cin_p, in_cs);
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in_dev;
+    a.w = c->w;
+    a.bias = c->bias;
+    a.out = out_dev;
+    a.N = N;
+    a.Hin = a.Hout = H;
+    a.Win = a.Wout = W;
+    a.in_cs = in_cs;
+    a.out_cs = out_cs;
+    a.Cin_p = c->Cin_p;
+    a.Cout_p = c->Cout_p;
+    a.Cout = c->Cout;
+    a.ntaps = c->taps;
+    a.tap_y0 = a.tap_x0 = c->kh == 3 ? -1 : 0;  // 'same': 3x3 centred, 2x2 pads bottom/right, 1x1
+    a.act = act;
+    a.slope = slope;
+    char name[48];
+    snprintf(name, sizeof(name), "conv%dx%d", c->kh, c->kw);
+    static std::map<std::string, const char*> names;  // stable storage for trace names
+    auto it = names.find(name);
+    if (it == names.end()) it = names.emplace(name, strdup(name)).first;
+    return conv_launch(a, 1, false, -1, (hipStream_t)stream, it->second);
+}
+
+int vfi_avgpool2(const float* in_dev, int in_cs, float* out_dev, int out_cs, int N, int H, int W, int C, void* stream) {
+    VFI_REQUIRE(in_dev && out_dev && C % 4 == 0 && in_cs % 4 == 0 && out_cs % 4 == 0 && H >= 2 && W >= 2,
+                "vfi_avgpool2: bad arguments (C, strides multiples of 4)");
+    const long n = (long)N * (H / 2) * (W / 2) * (C / 4);
+    TraceScope ts("avgpool2", (hipStream_t)stream);
+    hipLaunchKernelGGL(avgpool2_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, in_dev, in_cs, out_dev, out_cs, N, H, W, C / 4);
+    VFI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int vfi_upsample_nearest(const float* in_dev, int in_cs, float* out_dev, int out_cs, int N, int Hin, int Win, int Hout,
+                         int Wout, int C, void* stream) {
+    VFI_REQUIRE(in_dev && out_dev && C % 4 == 0 && in_cs % 4 == 0 && out_cs % 4 == 0, "vfi_upsample_nearest: bad arguments");
+    const long n = (long)N * Hout * Wout * (C / 4);
+    TraceScope ts("upsample_nearest", (hipStream_t)stream);
+    hipLaunchKernelGGL(upsample_nearest_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, in_dev, in_cs, out_dev, out_cs, N,
+                       Hin, Win, Hout, Wout, C / 4, (float)Hin / (float)Hout, (float)Win / (float)Wout);
+    VFI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int vfi_resize_bilinear(const float* in_dev, int in_cs, float* out_dev, int out_cs, int N, int Hin, int Win, int Hout,
+                        int Wout, int C, float mul, void* stream) {
+    VFI_REQUIRE(in_dev && out_dev && C > 0, "vfi_resize_bilinear: bad arguments");
+    const long n = (long)N * Hout * Wout;
+    TraceScope ts("resize_bilinear", (hipStream_t)stream);
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, in_dev, in_cs, out_dev, out_cs, N,
+                       Hin, Win, Hout, Wout, C, (float)Hin / (float)Hout, (float)Win / (float)Wout, mul);
+    VFI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int vfi_warp_film(const float* in_dev, int in_cs, const float* flow_dev, int flow_cs, float flow_mul, float* out_dev,
+                  int out_cs, int N, int H, int W, int C, void* stream) {
+    VFI_REQUIRE(in_dev && flow_dev && out_dev && C % 4 == 0 && in_cs % 4 == 0 && out_cs % 4 == 0 && H > 1 && W > 1,
+                "vfi_warp_film: bad arguments (C and strides multiples of 4)");
+    // torch.linspace(-ls, ls, n) in fp32: start/end rounded from double, step = (end-start)/(n-1)
+    const float sx1 = (float)(1.0 - 1.0 / (double)W), sx0 = -sx1, stepx = (sx1 - sx0) / (float)(W - 1);
+    const float sy1 = (float)(1.0 - 1.0 / (double)H), sy0 = -sy1, stepy = (sy1 - sy0) / (float)(H - 1);
+    const long n = (long)N * H * W * (C / 4);
+    TraceScope ts("warp_film", (hipStream_t)stream);
+    hipLaunchKernelGGL(warp_film_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, in_dev, in_cs, flow_dev, flow_cs,
+                       flow_mul, out_dev, out_cs, N, H, W, C / 4, sx0, sx1, stepx, sy0, sy1, stepy);
+    VFI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int vfi_axpby(const float* a_dev, int a_cs, const float* b_dev, int b_cs, float* out_dev, int out_cs, int64_t pixels, int C,
+              float alpha, float beta, void* stream) {
+    VFI_REQUIRE(a_dev && out_dev && pixels > 0 && C > 0, "vfi_axpby: bad arguments");
+    TraceScope ts("axpby", (hipStream_t)stream);
+    hipLaunchKernelGGL(axpby_kernel, dim3(nblk(pixels * C)), dim3(256), 0, (hipStream_t)stream, a_dev, a_cs, b_dev, b_cs, out_dev,
+                       out_cs, (long)pixels, C, alpha, beta);
+    VFI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

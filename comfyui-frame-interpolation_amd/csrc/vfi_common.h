@@ -61,7 +61,7 @@ struct ConvArgs {
     int Hout, Wout, out_cs, res_cs;
     int Cin_p, Cout_p, Cout;
     int ntaps;
-    int act;      // 0 none, 1 leaky relu
+    int act;      // 0 none, 1 leaky relu, 2 clamp to [0,1]
     float slope;
     int tiles_x, tiles_y;  // output tiles per image (filled by the launcher)
     int tap_y0, tap_x0;    // origin of the tap rectangle (3x3: -1,-1), ignored for grouped

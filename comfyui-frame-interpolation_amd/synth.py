@@ -49,6 +49,26 @@ def rife47_synth_state_dict(seed=1234):
     return synth_state_dict(rife47_shapes(), seed)
 
 
+def film_synth_state_dict(seed=1234, gain=1.2):
+    """FILM: torch-default init shrinks the signal to a bias-dominated constant through ~20 LeakyReLU convs, which
+    would make parity tests insensitive; weights are U(+-gain*sqrt(3/fan_in)) (roughly variance preserving), biases
+    U(+-0.1): features O(1), finest-level flows of ~15 px, outputs O(1)."""
+    from .film_spec import film_shapes
+
+    sd = {}
+    for k, shp in film_shapes().items():
+        g = _gen(seed, k)
+        if k.endswith("weight"):
+            fan_in = 1
+            for d in shp[1:]:
+                fan_in *= d
+            t = (torch.rand(shp, generator=g) * 2 - 1) * (gain * math.sqrt(3.0 / fan_in))
+        else:
+            t = (torch.rand(shp, generator=g) * 2 - 1) * 0.1
+        sd[k] = t.to(torch.float32).contiguous()
+    return sd
+
+
 def smooth_frames(n, h, w, seed=0, shift=3.0, c=3):
     """[n,h,w,c] f32 in [0,1]: low-pass noise drifting ``shift`` px/frame (ComfyUI IMAGE layout)."""
     g = torch.Generator(device="cpu")

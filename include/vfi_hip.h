@@ -73,6 +73,41 @@ int vfi_conv3x3_naive(const float* in_dev, const float* weight_host, const float
 int vfi_deconv4x4_ps2(const float* in_dev, const float* weight_host, const float* bias_host,
                       float* out_dev, int N, int H, int W, int Cin, int Cout, void* stream);
 
+/* ---- generic NHWC building blocks (FILM path; vfi_models/film/film_arch.py) -------------------------
+ * Every tensor pointer addresses the first channel of a channel WINDOW inside a (possibly wider) NHWC tensor
+ * whose pixel stride is `*_cs` floats, so the reference's torch.cat along channels is a matter of offsets. */
+
+typedef struct vfi_conv vfi_conv_t;
+
+/* nn.Conv2d(Cin, Cout, k, padding='same') with k in {1,2,3} (k=2 pads bottom/right like torch), weights
+ * [Cout,Cin,k,k] in the reference layout (host).  `chan_map[ci]` (nullable) = position of reference input
+ * channel ci inside the physical input window of `Cin_phys` channels (multiple of 8; unmapped positions get
+ * zero weights — they must hold finite values).  Replaces film_arch.conv(), film_arch.py:784-798. */
+vfi_conv_t* vfi_conv_create(const float* w_oihw_host, const float* bias_host, int Cout, int Cin, int kh, int kw,
+                            const int* chan_map, int Cin_phys);
+void vfi_conv_destroy(vfi_conv_t* conv);
+/* out[..., :Cout] = act(conv(in[..., :Cin_phys]) + bias);  act: 0 none, 1 LeakyReLU(slope), 2 clamp to [0,1]
+ * (the FILM node's prediction.clamp(0, 1), vfi_models/film/__init__.py:39). */
+int vfi_conv_forward(const vfi_conv_t* conv, const float* in_dev, int in_cs, float* out_dev, int out_cs,
+                     int N, int H, int W, int act, float slope, void* stream);
+
+/* F.avg_pool2d(x, 2, 2) (odd sizes floor), film_arch.py:655-674, :112-113.  C % 4 == 0. */
+int vfi_avgpool2(const float* in_dev, int in_cs, float* out_dev, int out_cs, int N, int H, int W, int C, void* stream);
+/* F.interpolate(x, size=(Hout,Wout), mode='nearest'), film_arch.py:286.  C % 4 == 0. */
+int vfi_upsample_nearest(const float* in_dev, int in_cs, float* out_dev, int out_cs, int N, int Hin, int Win,
+                         int Hout, int Wout, int C, void* stream);
+/* F.interpolate(mul * x, size=(Hout,Wout), mode='bilinear') (align_corners=False), film_arch.py:597,610,752. */
+int vfi_resize_bilinear(const float* in_dev, int in_cs, float* out_dev, int out_cs, int N, int Hin, int Win,
+                        int Hout, int Wout, int C, float mul, void* stream);
+/* film_arch.warp(image, flow_mul * flow): backward bilinear warp sampling at (x + fx, y + fy), border padding,
+ * align_corners=False, reference fp32 expression order; flow = [dx, dy] per pixel.  film_arch.py:677-724. */
+int vfi_warp_film(const float* in_dev, int in_cs, const float* flow_dev, int flow_cs, float flow_mul,
+                  float* out_dev, int out_cs, int N, int H, int W, int C, void* stream);
+/* out = alpha * a + beta * b over a C-channel window (b may be NULL): flow accumulation v = v_res + v,
+ * multiply_pyramid, and channel-window copies.  film_arch.py:600-602,727-742. */
+int vfi_axpby(const float* a_dev, int a_cs, const float* b_dev, int b_cs, float* out_dev, int out_cs,
+              int64_t pixels, int C, float alpha, float beta, void* stream);
+
 /* ---- M2M custom ops ---------------------------------------------------------------------- */
 
 /* Summation splat (forward warp): out[n, y', x', c] += in[n,y,x,c] * bilinear weight at the 4 integer
