@@ -24,8 +24,9 @@ import torch
 
 from . import _lib
 from .ckpt import load_file_from_github_release
+from .dist import all_gather_frames, world
 from .film_spec import FLOW_FILTERS, check_state_dict, feat_channels
-from .schedule import InterpolationStateList
+from .schedule import InterpolationStateList, shard_tasks
 
 MODEL_TYPE = "film"
 PYR, FUS = 7, 5
@@ -297,19 +298,27 @@ class FILM_VFI:
             else:
                 multipliers = list(map(int, multiplier))
                 multipliers += [2] * (n - len(multipliers) - 1)
-            out = []
             dev = engine.device
-            for i in range(n - 1):
-                if optional_interpolation_states is not None and optional_interpolation_states.is_frame_skipped(i):
-                    continue   # FILM drops skipped pairs entirely (film/__init__.py:89-90)
+            H, W = frames.shape[1:3]
+            # pairs are independent (the bisection inside a pair is sequential): block-partition the kept pairs over
+            # ranks, all-gather the per-rank frame blocks
+            pairs = [i for i in range(n - 1)
+                     if not (optional_interpolation_states is not None and optional_interpolation_states.is_frame_skipped(i))]
+            rank, ws = world()
+            lo, hi = shard_tasks(pairs, rank, ws)
+            per_pair = [multipliers[i] for i in pairs]           # output frames contributed by each kept pair
+            counts = [sum(per_pair[slice(*shard_tasks(pairs, r, ws))]) for r in range(ws)]
+            local = torch.empty((counts[rank], H, W, 3), dtype=torch.float32, device=dev)
+            pos = 0
+            for i in pairs[lo:hi]:
                 res = {0: frames[i].to(dev, torch.float32).contiguous(),
                        multipliers[i]: frames[i + 1].to(dev, torch.float32).contiguous()}
                 for (l, r, new) in film_schedule(multipliers[i] - 1):
                     res[new] = engine.forward(res[l], res[r], clamp=True)
-                keys = sorted(res)[:-1]
-                out.append(frames[i:i + 1].to(torch.float32))
-                out.extend(res[k].cpu()[None] for k in keys[1:])
-            out.append(frames[-1:].to(torch.float32))
-            return (torch.cat(out, 0),)
+                for k in sorted(res)[:-1]:
+                    local[pos] = res[k]      # res[0] is the uploaded original: bit-exact round trip
+                    pos += 1
+            allf = all_gather_frames(local, counts).cpu()
+            return (torch.cat([allf, frames[-1:].to(torch.float32)], 0),)
         finally:
             engine.close()

@@ -69,6 +69,29 @@ def film_synth_state_dict(seed=1234, gain=1.2):
     return sd
 
 
+def m2m_synth_state_dict(seed=1234, gain=1.0):
+    """M2M: conv weights U(+-gain*sqrt(3/fan_in)) (fan_in over dims 1.. of the weight, so ConvTranspose2d follows
+    torch's convention), biases U(+-0.05), PReLU slopes U(0.1,0.4), paramAlpha 10 (its trained-from value)."""
+    from .m2m_spec import m2m_shapes
+
+    sd = {}
+    for k, shp in m2m_shapes().items():
+        g = _gen(seed, k)
+        if k == "paramAlpha":
+            t = torch.full(shp, 10.0)
+        elif len(shp) == 4:
+            fan_in = 1
+            for d in shp[1:]:
+                fan_in *= d
+            t = (torch.rand(shp, generator=g) * 2 - 1) * (gain * math.sqrt(3.0 / fan_in))
+        elif k.endswith("bias"):
+            t = (torch.rand(shp, generator=g) * 2 - 1) * 0.05
+        else:  # PReLU slope(s)
+            t = 0.1 + 0.3 * torch.rand(shp, generator=g)
+        sd[k] = t.to(torch.float32).contiguous()
+    return sd
+
+
 def smooth_frames(n, h, w, seed=0, shift=3.0, c=3):
     """[n,h,w,c] f32 in [0,1]: low-pass noise drifting ``shift`` px/frame (ComfyUI IMAGE layout)."""
     g = torch.Generator(device="cpu")

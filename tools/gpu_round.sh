@@ -2,4 +2,5 @@
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-echo "=== pytest film"; timeout 900 python -m pytest tests/test_gpu_film.py -q -m gpu --no-header -rf 2>&1 | tail -40 | cut -c1-400
+timeout 600 python tools/film_bench.py 270 480 --check 2>&1 | grep -E "FILM|calls" | tee gpurun_out/film_bench_270.log
+timeout 900 python tools/film_bench.py 1080 1920 --check 2>&1 | grep -E "FILM|calls" | tee gpurun_out/film_bench_1080.log
