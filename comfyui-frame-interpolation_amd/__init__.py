@@ -9,6 +9,7 @@ scheduler does not require the HIP library to be built.
 _LAZY = {
     "RIFE_VFI": ("rife", "RIFE_VFI"),
     "FILM_VFI": ("film", "FILM_VFI"),
+    "M2M_VFI": ("m2m", "M2M_VFI"),
     "MakeInterpolationStateList": ("schedule", "MakeInterpolationStateList"),
     "InterpolationStateList": ("schedule", "InterpolationStateList"),
 }
@@ -27,12 +28,14 @@ def __getattr__(name):
 
 def _node_class_mappings():
     from .film import FILM_VFI
+    from .m2m import M2M_VFI
     from .rife import RIFE_VFI
     from .schedule import MakeInterpolationStateList
 
     return {
         "RIFE VFI": RIFE_VFI,
         "FILM VFI": FILM_VFI,
+        "M2M VFI": M2M_VFI,
         "Make Interpolation State List": MakeInterpolationStateList,
     }
 
@@ -40,4 +43,5 @@ def _node_class_mappings():
 NODE_DISPLAY_NAME_MAPPINGS = {
     "RIFE VFI": "RIFE VFI (MI355X HIP; rife47 / rife49)",
     "FILM VFI": "FILM VFI (MI355X HIP)",
+    "M2M VFI": "M2M VFI (MI355X HIP)",
 }

@@ -43,8 +43,25 @@ PROTOTYPES = {
     "vfi_axpby": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_float,
                             C.c_float, C.c_void_p]),
     "vfi_softsplat_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    "vfi_costvol9x9": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                 C.c_void_p]),
+    "vfi_costvol9x9": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vfi_conv_create_ex": (C.c_void_p, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_int_p,
+                                        C.c_int, C.c_void_p]),
+    "vfi_conv_forward_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                      C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
+    "vfi_m2m_normalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                    C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "vfi_warp_m2m": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                               C.c_int, C.c_void_p]),
+    "vfi_pool_mean": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vfi_m2m_cube_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vfi_m2m_photo": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                C.c_void_p]),
+    "vfi_m2m_splat_inputs": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int,
+                                       C.c_int, C.c_void_p]),
+    "vfi_m2m_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                  C.c_int, C.c_void_p]),
     "vfi_rife_create": (C.c_void_p, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int]),
     "vfi_rife_destroy": (None, [C.c_void_p]),
     "vfi_rife_configure": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]),

@@ -82,8 +82,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         const int pix = idx / Q, q = idx - pix * Q;
         const int py = pix / TWI, px = pix - py * TWI;
         const int iy = iy0 + py, ix = ix0 + px;
-        gok[i] = idx < NITEM && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-        goff[i] = gok[i] ? (iy * a.Win + ix) * pstr + q * qstr : 0;
+        if (a.pad_replicate) {
+            gok[i] = idx < NITEM;
+            const int cy = min(max(iy, 0), a.Hin - 1), cx = min(max(ix, 0), a.Win - 1);
+            goff[i] = gok[i] ? (cy * a.Win + cx) * pstr + q * qstr : 0;
+        } else {
+            gok[i] = idx < NITEM && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+            goff[i] = gok[i] ? (iy * a.Win + ix) * pstr + q * qstr : 0;
+        }
     }
     f32x4 stage[NLOAD];
     auto gload = [&](int c0) {
@@ -187,10 +193,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
                     if (a.res) v += a.res[p * a.res_cs + co];
                     if (a.act == 1) v = v > 0.f ? v : v * a.slope;
                         else if (a.act == 2) v = fminf(fmaxf(v, 0.f), 1.f);
+                        else if (a.act == 3) v = v > 0.f ? v : v * a.prelu[co];
+                        else if (a.act == 4) v = 1.0f / (1.0f + expf(-v));
+                        if (a.post_scale != 0.f) v = v * a.post_scale + a.post_shift;
                     if (GROUPED && a.out_mode == 1) {
                         const int Ws = 4 * a.Wout, Hs = 4 * a.Hout, c = co >> 2;
                         const int Yt = 4 * oy + 2 * (g >> 1) + ((co >> 1) & 1), Xt = 4 * ox + 2 * (g & 1) + (co & 1);
                         a.out[((size_t)(n * 2 + (c >> 2)) * Hs * Ws + (size_t)Yt * Ws + Xt) * 4 + (c & 3)] = v;
+                    } else if (GROUPED && a.out_mode == 2) {
+                        const size_t q2 = (size_t)(n * 2 * a.Hout + 2 * oy + (g >> 1)) * (2 * a.Wout) + 2 * ox + (g & 1);
+                        a.out[q2 * a.out_cs + co] = v;
                     } else {
                         a.out[p * a.out_cs + g * a.Cout_p + co] = v;
                     }
@@ -264,13 +276,14 @@ static int n_cus_cached() {
 //     grouped transposed conv: first-generation small tiles.
 int conv_pick_variant(const ConvArgs& a, int stride, bool grouped) {
     const long px = (long)a.N * a.Hout * a.Wout;
+    if (!grouped && stride == 2 && a.ntaps == 4) return kConv2Base + (a.Cout_p % 64 == 0 ? 21 : 20);
     if (!grouped && stride == 1 && a.ntaps != 9) {  // 2x2 'same' / 1x1 convs (FILM): second generation only
         const bool big = px * (a.Cout_p / 32) >= 256L * 4 * n_cus_cached();
         if (a.Cout_p % 64 == 0) return kConv2Base + (a.ntaps == 4 ? (big ? 14 : 15) : (big ? 16 : 17));
         return kConv2Base + (a.ntaps == 4 ? 19 : 18);
     }
     const long cus = n_cus_cached();
-    if (grouped) return 13;
+    if (grouped) return a.Cin_p % 16 == 0 ? 13 : kConv2Base + 11;
     const bool n3 = a.Cout_p % 96 == 0;
     const bool n2 = a.Cout_p % 64 == 0;
     (void)cus;
@@ -297,7 +310,9 @@ int conv_launch(const ConvArgs& a, int stride, bool grouped, int variant, hipStr
     VFI_REQUIRE(v.stride == stride && (v.grouped != 0) == grouped && v.taps == a.ntaps,
                 "conv: variant %s does not match stride %d grouped %d taps %d", v.name, stride, (int)grouped,
                 a.ntaps);
-    VFI_REQUIRE(!a.out_mode || (grouped && a.Cout % 4 == 0 && a.Cout <= 32), "conv: out_mode 1 is for grouped convs");
+    VFI_REQUIRE(a.out_mode != 1 || (grouped && a.Cout % 4 == 0 && a.Cout <= 32), "conv: out_mode 1 is for grouped convs");
+    VFI_REQUIRE(a.out_mode != 2 || grouped, "conv: out_mode 2 is for grouped convs");
+    VFI_REQUIRE(a.act != 3 || a.prelu, "conv: act 3 needs per-channel slopes");
     VFI_REQUIRE(a.Cin_p % 8 == 0 && a.Cout_p % 32 == 0 && a.in_cs >= a.Cin_p && a.in_cs % 4 == 0,
                 "conv: bad channel padding Cin_p=%d Cout_p=%d in_cs=%d", a.Cin_p, a.Cout_p, a.in_cs);
     VFI_REQUIRE(((uintptr_t)a.in & 15) == 0 && ((uintptr_t)a.w & 15) == 0, "conv: unaligned pointers");

@@ -95,8 +95,13 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
             const int pix = idx / Q, q = idx - pix * Q;
             const int py = pix / TWI, px = pix - py * TWI;
             const int iy = iy0 + py, ix = ix0 + px;
-            const bool ok = pix < G::NPIX && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-            avoff[i] = ok ? ((iy * a.Win + ix) * pstr + q * qstr) * 4 : (int)0x80000000;
+            if (a.pad_replicate) {  // edge clamp instead of the descriptor's zero fill
+                const int cy = min(max(iy, 0), a.Hin - 1), cx = min(max(ix, 0), a.Win - 1);
+                avoff[i] = pix < G::NPIX ? ((cy * a.Win + cx) * pstr + q * qstr) * 4 : (int)0x80000000;
+            } else {
+                const bool ok = pix < G::NPIX && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+                avoff[i] = ok ? ((iy * a.Win + ix) * pstr + q * qstr) * 4 : (int)0x80000000;
+            }
         }
     };
     auto make_rsrc = [&](int n) {
@@ -257,11 +262,17 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
                         if (a.res) v += rv[r];
                         if (a.act == 1) v = v > 0.f ? v : v * a.slope;
                         else if (a.act == 2) v = fminf(fmaxf(v, 0.f), 1.f);
+                        else if (a.act == 3) v = v > 0.f ? v : v * a.prelu[coc];
+                        else if (a.act == 4) v = 1.0f / (1.0f + expf(-v));
+                        if (a.post_scale != 0.f) v = v * a.post_scale + a.post_shift;
                         if (cok && oy < a.Hout && ox < a.Wout) {
                             if (GROUPED && a.out_mode == 1) {
                                 const int Ws = 4 * a.Wout, Hs = 4 * a.Hout, c = co >> 2;
                                 const int Yt = 4 * oy + 2 * (g >> 1) + ((co >> 1) & 1), Xt = 4 * ox + 2 * (g & 1) + (co & 1);
                                 a.out[((size_t)(n * 2 + (c >> 2)) * Hs * Ws + (size_t)Yt * Ws + Xt) * 4 + (c & 3)] = v;
+                            } else if (GROUPED && a.out_mode == 2) {
+                                const size_t q2 = (size_t)(n * 2 * a.Hout + 2 * oy + (g >> 1)) * (2 * a.Wout) + 2 * ox + (g & 1);
+                                a.out[q2 * a.out_cs + co] = v;
                             } else {
                                 a.out[((size_t)(n * a.Hout + oy) * a.Wout + ox) * a.out_cs + g * a.Cout_p + co] = v;
                             }
@@ -346,6 +357,8 @@ static const ConvVariant kVariants2[] = {
     {"d1t1_m1n2", 1, 1, 1, 2, 4, 1, 8, 0},    // 49
     {"d1t1_m2n1", 1, 1, 2, 1, 4, 1, 8, 0},    // 50: 1x1, 32-channel N tile
     {"d1t4_m2n1", 1, 4, 2, 1, 4, 1, 8, 0},    // 51
+    {"d2t4_m2n1", 2, 4, 2, 1, 4, 1, 8, 0},    // 52: 2x2 stride 2 (M2M 'sconv(2)'), 32-channel N tile
+    {"d2t4_m1n2", 2, 4, 1, 2, 4, 1, 8, 0},    // 53
 };
 int conv2_num_variants() { return (int)(sizeof(kVariants2) / sizeof(kVariants2[0])); }
 const ConvVariant& conv2_variant(int i) { return kVariants2[i]; }
@@ -372,6 +385,8 @@ int conv2_launch(const ConvArgs& a, int idx, hipStream_t s, const char* nm) {
         case 17: return launch2_t<1, 1, 1, 2, 4, 1, 8, false>(a, s, nm);
         case 18: return launch2_t<1, 1, 2, 1, 4, 1, 8, false>(a, s, nm);
         case 19: return launch2_t<1, 4, 2, 1, 4, 1, 8, false>(a, s, nm);
+        case 20: return launch2_t<2, 4, 2, 1, 4, 1, 8, false>(a, s, nm);
+        case 21: return launch2_t<2, 4, 1, 2, 4, 1, 8, false>(a, s, nm);
     }
     set_error("conv2: bad variant %d", idx);
     return -3;

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <vector>
 
 #include "../../include/vfi_hip.h"
 #include "vfi_common.h"
@@ -153,7 +154,9 @@ using namespace vfi;
 struct vfi_conv {
     float* w = nullptr;
     float* bias = nullptr;
+    float* prelu = nullptr;  // per-channel PReLU slopes [Cout_p] (optional)
     int Cout = 0, Cout_p = 0, Cin = 0, Cin_p = 0, kh = 0, kw = 0, taps = 0;
+    int stride = 1, pad_mode = 0, kind = 0;  // kind 0: Conv2d, 1: ConvTranspose2d(4, 2, 1)
 };
 
 static unsigned nblk(long n) { return (unsigned)((n + 255) / 256); }
@@ -205,7 +208,123 @@ void vfi_conv_destroy(vfi_conv_t* c) {
     if (!c) return;
     if (c->w) (void)hipFree(c->w);
     if (c->bias) (void)hipFree(c->bias);
+    if (c->prelu) (void)hipFree(c->prelu);
     delete c;
+}
+
+static bool upload(float** dst, const std::vector<float>& v) {
+    return hipMalloc((void**)dst, v.size() * sizeof(float)) == hipSuccess &&
+           hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+}
+
+vfi_conv_t* vfi_conv_create_ex(int kind, const float* w_host, const float* bias_host, int Cout, int Cin, int k, int stride,
+                               int pad_mode, const int* chan_map, int Cin_phys, const float* prelu_host) {
+    const bool conv_ok = kind == 0 && ((k == 3 && (stride == 1 || stride == 2)) || (k == 2 && stride == 2) || (k == 1 && stride == 1));
+    const bool deconv_ok = kind == 1 && k == 4 && stride == 2;
+    if (!w_host || Cout <= 0 || Cin <= 0 || !(conv_ok || deconv_ok) || Cin_phys % 8 || Cin_phys < Cin || pad_mode < 0 || pad_mode > 1) {
+        set_error("vfi_conv_create_ex: unsupported layer (kind=%d Cout=%d Cin=%d k=%d stride=%d pad_mode=%d Cin_phys=%d)", kind, Cout,
+                  Cin, k, stride, pad_mode, Cin_phys);
+        return nullptr;
+    }
+    vfi_conv* c = new vfi_conv();
+    c->kind = kind;
+    c->Cout = Cout;
+    c->Cout_p = round_up(Cout, 32);
+    c->Cin = Cin;
+    c->Cin_p = Cin_phys;
+    c->kh = c->kw = k;
+    c->taps = kind == 1 ? 4 : k * k;
+    c->stride = stride;
+    c->pad_mode = pad_mode;
+    const int cin8 = Cin_phys / 8, ngrp = kind == 1 ? 4 : 1;
+    std::vector<float> wp((size_t)ngrp * c->taps * cin8 * c->Cout_p * 8, 0.f), bp((size_t)ngrp * c->Cout_p, 0.f);
+    for (int ci = 0; ci < Cin; ++ci) {
+        const int pc = chan_map ? chan_map[ci] : ci;
+        if (pc < 0 || pc >= Cin_phys) {
+            set_error("vfi_conv_create_ex: chan_map[%d]=%d outside 0..%d", ci, pc, Cin_phys - 1);
+            delete c;
+            return nullptr;
+        }
+        for (int co = 0; co < Cout; ++co) {
+            if (kind == 0) {
+                for (int t = 0; t < c->taps; ++t)
+                    wp[(((size_t)t * cin8 + pc / 8) * c->Cout_p + co) * 8 + (pc & 7)] = w_host[((size_t)co * Cin + ci) * c->taps + t];
+            } else {
+                // out[co, 2y+py, 2x+px] = b[co] + sum in[ci, y+py-1+a, x+px-1+b] * w[ci, co, 3-py-2a, 3-px-2b]
+                for (int g = 0; g < 4; ++g)
+                    for (int t = 0; t < 4; ++t) {
+                        const int ky = 3 - (g >> 1) - 2 * (t >> 1), kx = 3 - (g & 1) - 2 * (t & 1);
+                        wp[((((size_t)g * 4 + t) * cin8 + pc / 8) * c->Cout_p + co) * 8 + (pc & 7)] =
+                            w_host[(((size_t)ci * Cout + co) * 4 + ky) * 4 + kx];
+                    }
+            }
+        }
+    }
+    if (bias_host)
+        for (int g = 0; g < ngrp; ++g)
+            for (int co = 0; co < Cout; ++co) bp[(size_t)g * c->Cout_p + co] = bias_host[co];
+    bool ok = upload(&c->w, wp) && upload(&c->bias, bp);
+    if (ok && prelu_host) {
+        std::vector<float> pp(c->Cout_p, 0.f);
+        for (int co = 0; co < Cout; ++co) pp[co] = prelu_host[co];
+        ok = upload(&c->prelu, pp);
+    }
+    if (!ok) {
+        set_error("vfi_conv_create_ex: device allocation/upload failed");
+        vfi_conv_destroy(c);
+        return nullptr;
+    }
+    return c;
+}
+
+int vfi_conv_forward_ex(const vfi_conv_t* c, const float* in_dev, int in_cs, int Hin, int Win, float* out_dev, int out_cs, int N,
+                        int act, float slope, float post_scale, float post_shift, const float* res_dev, int res_cs, void* stream) {
+    VFI_REQUIRE(c && in_dev && out_dev && N > 0 && Hin > 0 && Win > 0, "vfi_conv_forward_ex: bad arguments");
+    VFI_REQUIRE(in_cs >= c->Cin_p && in_cs % 4 == 0 && ((uintptr_t)in_dev & 15) == 0,
+                "vfi_conv_forward_ex: input window must hold %d channels, 16-byte aligned (in_cs=%d)", c->Cin_p, in_cs);
+    VFI_REQUIRE(act != 3 || c->prelu, "vfi_conv_forward_ex: act 3 (per-channel PReLU) needs slopes given at create time");
+    VFI_REQUIRE(c->stride == 1 || (Hin % 2 == 0 && Win % 2 == 0) || c->kind == 1,
+                "vfi_conv_forward_ex: stride-2 layers need even input sizes (%dx%d)", Hin, Win);
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in_dev;
+    a.w = c->w;
+    a.bias = c->bias;
+    a.prelu = c->prelu;
+    a.res = res_dev;
+    a.res_cs = res_cs;
+    a.out = out_dev;
+    a.N = N;
+    a.Hin = Hin;
+    a.Win = Win;
+    a.in_cs = in_cs;
+    a.out_cs = out_cs;
+    a.Cin_p = c->Cin_p;
+    a.Cout_p = c->Cout_p;
+    a.Cout = c->Cout;
+    a.ntaps = c->taps;
+    a.act = act;
+    a.slope = slope;
+    a.post_scale = post_scale;
+    a.post_shift = post_shift;
+    a.pad_replicate = c->pad_mode;
+    char name[48];
+    if (c->kind == 1) {
+        VFI_REQUIRE(!res_dev, "vfi_conv_forward_ex: residual not supported for transposed convs");
+        a.Hout = Hin;  // per parity group; the kernel interleaves the 4 groups into [2*Hin, 2*Win]
+        a.Wout = Win;
+        a.out_mode = 2;
+        snprintf(name, sizeof(name), "deconv4x4s2");
+    } else {
+        a.Hout = Hin / c->stride;
+        a.Wout = Win / c->stride;
+        a.tap_y0 = a.tap_x0 = c->kh == 3 ? -1 : 0;
+        snprintf(name, sizeof(name), "conv%dx%ds%d", c->kh, c->kw, c->stride);
+    }
+    static std::map<std::string, const char*> names;
+    auto it = names.find(name);
+    if (it == names.end()) it = names.emplace(name, strdup(name)).first;
+    return conv_launch(a, c->kind == 1 ? 1 : c->stride, c->kind == 1, -1, (hipStream_t)stream, it->second);
 }
 
 int vfi_conv_forward(const vfi_conv_t* c, const float* in_dev, int in_cs, float* out_dev, int out_cs, int N, int H, int W,

@@ -178,7 +178,8 @@ constexpr int CV_TW = CV_T + 8;     // + 4-pixel halo each side
 constexpr int CV_CK = 16;           // channels per LDS pass
 constexpr int CV_S = CV_CK + 4;     // LDS pixel stride (floats)
 
-__global__ __launch_bounds__(256) void costvol_kernel(const float* __restrict__ one, const float* __restrict__ two,
+__global__ __launch_bounds__(256) void costvol_kernel(const float* __restrict__ one, int one_cs,
+                                                      const float* __restrict__ two, int two_cs, int two_swap,
                                                       float* __restrict__ out, int N, int H, int W, int C, int out_cs,
                                                       int out_coff, int tiles_x, int tiles_y) {
     __shared__ __attribute__((aligned(16))) float lds[CV_TW * CV_TW * CV_S];
@@ -190,6 +191,7 @@ __global__ __launch_bounds__(256) void costvol_kernel(const float* __restrict__ 
     const int lx = tid & 15, ly = tid >> 4;
     const int x = X0 + lx, y = Y0 + ly;
     const bool inb = x < W && y < H;
+    const int n2 = two_swap ? (n ^ 1) : n;  // `two` taken from the partner image of a (0,1) batch pair
     float acc[81];
 #pragma unroll
     for (int k = 0; k < 81; ++k) acc[k] = 0.f;
@@ -202,14 +204,14 @@ __global__ __launch_bounds__(256) void costvol_kernel(const float* __restrict__ 
             const int iy = Y0 - 4 + py, ix = X0 - 4 + px;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (iy >= 0 && iy < H && ix >= 0 && ix < W && c0 + q * 4 < C)
-                v = *(const float4*)(two + ((size_t)(n * H + iy) * W + ix) * C + c0 + q * 4);
+                v = *(const float4*)(two + ((size_t)(n2 * H + iy) * W + ix) * two_cs + c0 + q * 4);
             *(float4*)&lds[pix * CV_S + q * 4] = v;
         }
         float o[CV_CK];
 #pragma unroll
         for (int q = 0; q < CV_CK / 4; ++q) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (inb && c0 + q * 4 < C) v = *(const float4*)(one + ((size_t)(n * H + y) * W + x) * C + c0 + q * 4);
+            if (inb && c0 + q * 4 < C) v = *(const float4*)(one + ((size_t)(n * H + y) * W + x) * one_cs + c0 + q * 4);
             o[4 * q] = v.x;
             o[4 * q + 1] = v.y;
             o[4 * q + 2] = v.z;
@@ -242,12 +244,12 @@ __global__ __launch_bounds__(256) void costvol_kernel(const float* __restrict__ 
     }
 }
 
-int costvol_launch(const float* one, const float* two, float* out, int N, int H, int W, int C, int out_cs, int out_coff,
-                   hipStream_t s) {
+int costvol_launch(const float* one, int one_cs, const float* two, int two_cs, int two_swap, float* out, int N, int H, int W,
+                   int C, int out_cs, int out_coff, hipStream_t s) {
     const int tiles_x = cdiv(W, CV_T), tiles_y = cdiv(H, CV_T);
     TraceScope ts("costvol9x9", s);
-    hipLaunchKernelGGL(costvol_kernel, dim3(N * tiles_x * tiles_y), dim3(256), 0, s, one, two, out, N, H, W, C, out_cs,
-                       out_coff, tiles_x, tiles_y);
+    hipLaunchKernelGGL(costvol_kernel, dim3(N * tiles_x * tiles_y), dim3(256), 0, s, one, one_cs, two, two_cs, two_swap, out, N,
+                       H, W, C, out_cs, out_coff, tiles_x, tiles_y);
     VFI_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -265,13 +267,15 @@ int vfi_softsplat_sum(const float* in_dev, const float* flow_dev, float* out_dev
     return softsplat_sum_launch(in_dev, flow_dev, out_dev, N, H, W, C, (hipStream_t)stream);
 }
 
-int vfi_costvol9x9(const float* one_dev, const float* two_dev, float* out_dev, int N, int H, int W, int C, int out_cs,
-                   int out_coff, void* stream) {
+int vfi_costvol9x9(const float* one_dev, int one_cs, const float* two_dev, int two_cs, int two_swap, float* out_dev, int N,
+                   int H, int W, int C, int out_cs, int out_coff, void* stream) {
     VFI_REQUIRE(one_dev && two_dev && out_dev && N > 0 && H > 0 && W > 0, "vfi_costvol9x9: bad arguments");
+    VFI_REQUIRE(one_cs >= C && two_cs >= C && one_cs % 4 == 0 && two_cs % 4 == 0 && (!two_swap || N % 2 == 0),
+                "vfi_costvol9x9: bad strides (one_cs=%d two_cs=%d) or odd batch with two_swap", one_cs, two_cs);
     VFI_REQUIRE(C > 0 && C % 4 == 0, "vfi_costvol9x9: C=%d must be a multiple of 4", C);
     VFI_REQUIRE(out_cs >= out_coff + 81 && out_coff >= 0, "vfi_costvol9x9: out_cs=%d cannot hold 81 channels at offset %d",
                 out_cs, out_coff);
-    return costvol_launch(one_dev, two_dev, out_dev, N, H, W, C, out_cs, out_coff, (hipStream_t)stream);
+    return costvol_launch(one_dev, one_cs, two_dev, two_cs, two_swap, out_dev, N, H, W, C, out_cs, out_coff, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -61,14 +61,18 @@ struct ConvArgs {
     int Hout, Wout, out_cs, res_cs;
     int Cin_p, Cout_p, Cout;
     int ntaps;
-    int act;      // 0 none, 1 leaky relu, 2 clamp to [0,1]
+    int act;      // 0 none, 1 leaky relu(slope), 2 clamp to [0,1], 3 PReLU per channel (prelu[]), 4 sigmoid
     float slope;
     int tiles_x, tiles_y;  // output tiles per image (filled by the launcher)
     int tap_y0, tap_x0;    // origin of the tap rectangle (3x3: -1,-1), ignored for grouped
     int in_plane;          // 0: input is NHWC [.,.,in_cs]; >0: planar4 input, floats between 4-channel planes
                            //    (image = in_cs/4 planes of [Hin][Win][4])
     int out_mode;          // 0: NHWC store; 1 (grouped only): PixelShuffle(2) of the transposed conv, planar4
-                           //    [N][2][4*Hout][4*Wout][4] (channel c of Cout/4 -> plane c/4, component c%4)
+                           //    [N][2][4*Hout][4*Wout][4] (channel c of Cout/4 -> plane c/4, component c%4);
+                           //    2 (grouped only): plain transposed-conv output, NHWC [N][2*Hout][2*Wout][out_cs]
+    int pad_replicate;     // 0: zero padding; 1: replicate (edge clamp) padding of the input
+    const float* prelu;    // [Cout_p] per-channel negative slopes (act == 3)
+    float post_scale, post_shift;  // y = act(...) * post_scale + post_shift  (post_scale == 0 means "not set" = 1, 0)
 };
 
 struct ConvVariant {

@@ -81,6 +81,46 @@ def rife_output_plan(n_frames, tasks):
     return plan
 
 
+def generic_output_plan(n_frames, multiplier, states=None):
+    """Output order of ``generic_frame_loop`` in timestep mode (vfi_utils.py:149-389), used by the M2M node.
+
+    Returns ``(plan, tasks)``: ``plan`` = list of ``("src", frame_idx)`` / ``("new", k)`` entries in output order,
+    ``tasks`` = list of ``(pair_idx, [timesteps])`` whose new frames are numbered k = 0.. in order.
+    int multiplier: frame_i, its m-1 middle frames (none when the pair is skipped), ..., last frame.
+    list multiplier (padded with 2): each pair runs as its own 2-frame loop — m == 0 drops the pair INCLUDING its
+    first frame (and the clip's last frame when it is the last pair), and the skip list is consulted with the
+    pair's LOCAL index 0 (vfi_utils.py:364-386 passes a 2-frame slice to the same loop)."""
+    plan, tasks, n_new = [], [], 0
+
+    def one_pair(pair, m, skipped):
+        nonlocal n_new
+        plan.append(("src", pair))
+        if skipped or m <= 1:
+            return
+        ts = [k / m for k in range(1, m)]
+        tasks.append((pair, ts))
+        for _ in ts:
+            plan.append(("new", n_new))
+            n_new += 1
+
+    if type(multiplier) == int:
+        for pair in range(n_frames - 1):
+            one_pair(pair, multiplier, states is not None and states.is_frame_skipped(pair))
+        plan.append(("src", n_frames - 1))
+    elif type(multiplier) == list:
+        ms = list(map(int, multiplier))
+        ms += [2] * (n_frames - len(ms) - 1)
+        for pair in range(n_frames - 1):
+            if ms[pair] == 0:
+                continue
+            one_pair(pair, ms[pair], states is not None and states.is_frame_skipped(0))
+            if pair == n_frames - 2:
+                plan.append(("src", n_frames - 1))
+    else:
+        raise NotImplementedError(f"multipiler of {type(multiplier)}")
+    return plan, tasks
+
+
 def shard_tasks(tasks, rank, world):
     """Contiguous block partition of the task list over ``world`` ranks.
 

@@ -122,8 +122,54 @@ int vfi_softsplat_sum(const float* in_dev, const float* flow_dev, float* out_dev
  * vfi_models/ops/cupy_ops/costvol.py:4-43,135-183.   one/two [N,H,W,C] (C % 4 == 0); out [N,H,W,out_cs]:
  * the 81 channels are written at channel offset out_coff of a wider NHWC tensor (the reference's
  * torch.cat of the volume with features, vfi_models/m2m/M2M_arch.py:484-490, then costs nothing). */
-int vfi_costvol9x9(const float* one_dev, const float* two_dev, float* out_dev, int N, int H, int W, int C,
-                   int out_cs, int out_coff, void* stream);
+int vfi_costvol9x9(const float* one_dev, int one_cs, const float* two_dev, int two_cs, int two_swap, float* out_dev,
+                   int N, int H, int W, int C, int out_cs, int out_coff, void* stream);
+/* one/two are channel windows (pixel strides one_cs/two_cs); two_swap != 0 reads `two` from the partner image
+ * n^1 of a batch of direction pairs (the reference runs the decoder on (a,b) and on (b,a), M2M_arch.py:521-546). */
+
+/* ---- M2M network building blocks (vfi_models/m2m/M2M_arch.py) -------------------------------- */
+
+/* Generalised layer object: kind 0 = nn.Conv2d(Cin, Cout, k, stride, padding) with (k,stride) in
+ * {(3,1),(3,2),(2,2),(1,1)}: k=3 pads 1 — pad_mode 0 zeros (M2M_arch.py:589-602), 1 replicate (the "conv(3,replpad)"
+ * of Basic, :228-260); k=2/s=2 pads 0 ("sconv(2)" after evenize, :205-226 — sizes must be even).
+ * kind 1 = nn.ConvTranspose2d(Cin, Cout, 4, 2, 1) (deconv(), :605-618), weights [Cin,Cout,4,4].
+ * prelu_host (nullable): Cout per-channel PReLU slopes, applied by act 3. */
+vfi_conv_t* vfi_conv_create_ex(int kind, const float* w_host, const float* bias_host, int Cout, int Cin, int k, int stride,
+                               int pad_mode, const int* chan_map, int Cin_phys, const float* prelu_host);
+/* out = post_scale * act(layer(in) + bias + res) + post_shift.  act: 0 none, 1 LeakyReLU / single-parameter PReLU
+ * (slope), 2 clamp01, 3 per-channel PReLU, 4 sigmoid.  post_scale == 0 disables the affine.  res (nullable):
+ * [N,Hout,Wout,res_cs] added before the activation (the decoder's `flow + netMain(...)`, :503).
+ * Output is [N, Hin/stride, Win/stride, out_cs] (kind 0) or [N, 2*Hin, 2*Win, out_cs] (kind 1). */
+int vfi_conv_forward_ex(const vfi_conv_t* conv, const float* in_dev, int in_cs, int Hin, int Win, float* out_dev, int out_cs,
+                        int N, int act, float slope, float post_scale, float post_shift, const float* res_dev, int res_cs,
+                        void* stream);
+
+/* Replicate-pad both frames to Hp x Wp (M2M_arch.py:903-913), joint mean/std over the padded pair (:915-931),
+ * and write (frame_n - mean) / (std + 1e-7) to out[n, y, x, out_coff + 0..2] (n = 0,1; out [2,Hp,Wp,out_cs]).
+ * stats_dev[0] = mean, stats_dev[1] = std + 1e-7.  frames: [H,W,C] fp32, C >= 3.  workspace: >= 16 KiB device. */
+int vfi_m2m_normalize(const float* frame0_dev, const float* frame1_dev, int C, int H, int W, int Hp, int Wp, float* out_dev,
+                      int out_cs, int out_coff, float* stats_dev, void* workspace_dev, int64_t workspace_bytes, void* stream);
+/* backwarp(): grid_sample(in, grid + flow*2/(size-1), bilinear, zeros, align_corners=True), M2M_arch.py:24-92.
+ * in_swap != 0 samples the partner image n^1.  flow = [dx, dy] per pixel. */
+int vfi_warp_m2m(const float* in_dev, int in_cs, int in_swap, const float* flow_dev, int flow_cs, float* out_dev, int out_cs,
+                 int N, int H, int W, int C, void* stream);
+/* adaptive_avg_pool2d to 1x1 (mode 0 -> out [N,1,C]), Hx1 (mode 1 -> [N,H,C]) or 1xW (mode 2 -> [N,W,C]), :689-703 */
+int vfi_pool_mean(const float* in_dev, int in_cs, float* out_dev, int out_cs, int N, int H, int W, int C, int mode, void* stream);
+/* out = s3 * mean_k(cC[n,k*C+c] * cH[n,y,k] * cW[n,x,k]), k < 16 — the EncDec "cube" attention, :786-795 */
+int vfi_m2m_cube_apply(const float* s3_dev, int s3_cs, const float* cC_dev, const float* cH_dev, int cH_cs, const float* cW_dev,
+                       int cW_cs, float* out_dev, int out_cs, int N, int H, int W, int C, void* stream);
+/* Timestep-independent splat preparation for the 8 splats s = 2*branch + direction of one pair (:945-1010, :559-561):
+ * tf_dev [8,H,W,2] = flow + residual, e_dev [8,H,W] = exp(clip(alpha * photometric, -20, 20)).
+ * d0 [2,H,W,d0_cs] = (flow 0..1 | normalised image 2..4 | ..), r [2,H,W,r_cs] = (8 residuals | mask logit). */
+int vfi_m2m_photo(const float* d0_dev, int d0_cs, const float* r_dev, int r_cs, float alpha, float* tf_dev, float* e_dev, int H,
+                  int W, void* stream);
+/* Per timestep t: in_dev [8,H,W,4] = (image*td*e, td*e), flow_dev [8,H,W,2] = tf * tm (:1012-1024, :563-567) */
+int vfi_m2m_splat_inputs(const float* d0_dev, int d0_cs, const float* tf_dev, const float* e_dev, float t, float* in_dev,
+                         float* flow_dev, int H, int W, void* stream);
+/* splat_dev [8,Hp,Wp,4] (vfi_softsplat_sum of the above) -> out [H,W,3]: normalise by the splatted weights, fill holes
+ * with the t-blend, undo the input normalisation, crop (:569-581, :1026-1037) */
+int vfi_m2m_combine(const float* splat_dev, const float* d0_dev, int d0_cs, const float* stats_dev, float t, float* out_dev,
+                    int Hp, int Wp, int H, int W, void* stream);
 
 /* ---- RIFE 4.7 / 4.9 model --------------------------------------------------------------- */
 

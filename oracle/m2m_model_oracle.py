@@ -240,18 +240,35 @@ def m2m_forward(sd, im0, im1, flt_times, ratio=4, return_aux=False):
     return outs
 
 
-def m2m_vfi(sd, frames, multiplier=2, states=None):
-    """Node-level oracle: generic_frame_loop in timestep mode (vfi_utils.py:339-389; per-pair loop :199-217,:253-300):
-    int multiplier; frame_i, its m-1 middle frames, ..., last frame; skipped pair -> frame kept, no middles."""
-    x = frames[..., :3].permute(0, 3, 1, 2).float()
+def _m2m_loop(sd, x, multiplier, states):
+    """_generic_frame_loop, timestep mode, batch_size 1 (vfi_utils.py:149-338)"""
     out = []
-    with torch.inference_mode():
-        for i in range(len(x) - 1):
-            out.append(x[i:i + 1])
-            if states is not None and states.is_frame_skipped(i):
-                continue
-            for k in range(1, multiplier):
-                t = torch.tensor([k / multiplier]).view(1, 1, 1, 1)
-                out.append(m2m_forward(sd, x[i:i + 1], x[i + 1:i + 2], [t])[0])
+    for i in range(len(x) - 1):
+        out.append(x[i:i + 1])
+        if states is not None and states.is_frame_skipped(i):
+            continue
+        for k in range(1, multiplier):
+            t = torch.tensor([k / multiplier]).view(1, 1, 1, 1)
+            out.append(m2m_forward(sd, x[i:i + 1], x[i + 1:i + 2], [t])[0])
     out.append(x[-1:])
+    return out
+
+
+def m2m_vfi(sd, frames, multiplier=2, states=None):
+    """Node-level oracle: generic_frame_loop (vfi_utils.py:339-389).  int multiplier: one loop over the clip;
+    list multiplier: one 2-frame loop per pair (m == 0 drops the pair, the last frame is kept only by the last pair,
+    and the skip list sees local pair index 0)."""
+    x = frames[..., :3].permute(0, 3, 1, 2).float()
+    with torch.inference_mode():
+        if type(multiplier) == int:
+            out = _m2m_loop(sd, x, multiplier, states)
+        else:
+            ms = list(map(int, multiplier))
+            ms += [2] * (len(x) - len(ms) - 1)
+            out = []
+            for i in range(len(x) - 1):
+                if ms[i] == 0:
+                    continue
+                part = _m2m_loop(sd, x[i:i + 2], ms[i], states)
+                out.extend(part if i == len(x) - 2 else part[:-1])
     return torch.cat(out, 0).permute(0, 2, 3, 1).contiguous()

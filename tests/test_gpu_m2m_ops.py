@@ -55,7 +55,7 @@ def test_costvol_vs_c_oracle(lib, shape):
     n, c, h, w = shape
     # written at channel offset 3 of a wider tensor (the M2M decoder's concat)
     out = torch.full((n, h, w, 90), float("nan"), device="cuda")
-    _lib.check(lib.vfi_costvol9x9(ptr(od), ptr(td), ptr(out), n, h, w, c, 90, 3, None), "costvol")
+    _lib.check(lib.vfi_costvol9x9(ptr(od), c, ptr(td), c, 0, ptr(out), n, h, w, c, 90, 3, None), "costvol")
     torch.cuda.synchronize()
     got = out.cpu()
     assert torch.isnan(got[..., :3]).all() and torch.isnan(got[..., 84:]).all(), "wrote outside its channel window"

@@ -41,11 +41,11 @@ if __name__ == "__main__":
     for (h, w) in ((272, 480), (136, 240), (68, 120)):
         one = torch.randn(1, h, w, 32).cuda(); two = torch.randn(1, h, w, 32).cuda()
         out = torch.empty(1, h, w, 81).cuda()
-        lib.vfi_costvol9x9(p(one), p(two), p(out), 1, h, w, 32, 81, 0, None)
+        lib.vfi_costvol9x9(p(one), 32, p(two), 32, 0, p(out), 1, h, w, 32, 81, 0, None)
         torch.cuda.synchronize()
         lib.vfi_trace_reset(); lib.vfi_trace_enable(1)
         for _ in range(8):
-            lib.vfi_costvol9x9(p(one), p(two), p(out), 1, h, w, 32, 81, 0, None)
+            lib.vfi_costvol9x9(p(one), 32, p(two), 32, 0, p(out), 1, h, w, 32, 81, 0, None)
         lib.vfi_trace_enable(0)
         calls, ms = _lib.trace_report()["costvol9x9"]
         bytes_ = (32 + 32 + 81) * 4 * h * w
