@@ -26,7 +26,9 @@ namespace vfi {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int STRIDE, int TAPS, int MT, int NT, int WM, int WN, int CK, bool GROUPED>
+// EXT: extended feature set (replicate padding, per-channel PReLU / sigmoid, post affine, interleaved
+// transposed-conv store) compiled as a separate instantiation; the RIFE path runs EXT = false.
+template <int STRIDE, int TAPS, int MT, int NT, int WM, int WN, int CK, bool GROUPED, bool EXT>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(!GROUPED || (WN == 4 && NT == 1 && TAPS == 4), "grouped: one 2x2 tap group per wave column");
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         const int pix = idx / Q, q = idx - pix * Q;
         const int py = pix / TWI, px = pix - py * TWI;
         const int iy = iy0 + py, ix = ix0 + px;
-        if (a.pad_replicate) {
+        if (EXT && a.pad_replicate) {
             gok[i] = idx < NITEM;
             const int cy = min(max(iy, 0), a.Hin - 1), cx = min(max(ix, 0), a.Win - 1);
             goff[i] = gok[i] ? (cy * a.Win + cx) * pstr + q * qstr : 0;
@@ -193,14 +195,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
                     if (a.res) v += a.res[p * a.res_cs + co];
                     if (a.act == 1) v = v > 0.f ? v : v * a.slope;
                         else if (a.act == 2) v = fminf(fmaxf(v, 0.f), 1.f);
-                        else if (a.act == 3) v = v > 0.f ? v : v * a.prelu[co];
-                        else if (a.act == 4) v = 1.0f / (1.0f + expf(-v));
-                        if (a.post_scale != 0.f) v = v * a.post_scale + a.post_shift;
+                        else if (EXT && a.act == 3) v = v > 0.f ? v : v * a.prelu[co];
+                        else if (EXT && a.act == 4) v = 1.0f / (1.0f + expf(-v));
+                        if (EXT && a.post_scale != 0.f) v = v * a.post_scale + a.post_shift;
                     if (GROUPED && a.out_mode == 1) {
                         const int Ws = 4 * a.Wout, Hs = 4 * a.Hout, c = co >> 2;
                         const int Yt = 4 * oy + 2 * (g >> 1) + ((co >> 1) & 1), Xt = 4 * ox + 2 * (g & 1) + (co & 1);
                         a.out[((size_t)(n * 2 + (c >> 2)) * Hs * Ws + (size_t)Yt * Ws + Xt) * 4 + (c & 3)] = v;
-                    } else if (GROUPED && a.out_mode == 2) {
+                    } else if (EXT && GROUPED && a.out_mode == 2) {
                         const size_t q2 = (size_t)(n * 2 * a.Hout + 2 * oy + (g >> 1)) * (2 * a.Wout) + 2 * ox + (g & 1);
                         a.out[q2 * a.out_cs + co] = v;
                     } else {
@@ -252,7 +254,10 @@ static int launch_t(ConvArgs a, hipStream_t s, const char* name) {
                 name, a.Cout_p, WN * NT * 32);
     dim3 grid(a.N * a.tiles_x * a.tiles_y, GROUPED ? a.Cout_p / 32 : a.Cout_p / (WN * NT * 32));
     TraceScope ts(name, s);
-    hipLaunchKernelGGL((conv_mfma_kernel<STRIDE, TAPS, MT, NT, WM, WN, CK, GROUPED>), grid, dim3(256), 0, s, a);
+    if (a.pad_replicate || a.act >= 3 || a.post_scale != 0.f || a.out_mode == 2)
+        hipLaunchKernelGGL((conv_mfma_kernel<STRIDE, TAPS, MT, NT, WM, WN, CK, GROUPED, true>), grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((conv_mfma_kernel<STRIDE, TAPS, MT, NT, WM, WN, CK, GROUPED, false>), grid, dim3(256), 0, s, a);
     VFI_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -47,7 +47,9 @@ struct Conv2Geom {
     static constexpr int NBW = (NB_INSTR + 3) / 4;
 };
 
-template <int STRIDE, int TAPS, int MT, int NT, int WM, int WN, int CK, bool GROUPED>
+// EXT = the layer uses the extended feature set (replicate padding, per-channel PReLU / sigmoid, post affine,
+// interleaved transposed-conv store): compiled separately so the RIFE / FILM hot path carries none of its branches.
+template <int STRIDE, int TAPS, int MT, int NT, int WM, int WN, int CK, bool GROUPED, bool EXT>
 __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource / LDS-DMA builtins do not exist in the host pass
     using G = Conv2Geom<STRIDE, TAPS, MT, NT, WM, WN, CK, GROUPED>;
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
             const int pix = idx / Q, q = idx - pix * Q;
             const int py = pix / TWI, px = pix - py * TWI;
             const int iy = iy0 + py, ix = ix0 + px;
-            if (a.pad_replicate) {  // edge clamp instead of the descriptor's zero fill
+            if (EXT && a.pad_replicate) {  // edge clamp instead of the descriptor's zero fill
                 const int cy = min(max(iy, 0), a.Hin - 1), cx = min(max(ix, 0), a.Win - 1);
                 avoff[i] = pix < G::NPIX ? ((cy * a.Win + cx) * pstr + q * qstr) * 4 : (int)0x80000000;
             } else {
@@ -262,15 +264,15 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
                         if (a.res) v += rv[r];
                         if (a.act == 1) v = v > 0.f ? v : v * a.slope;
                         else if (a.act == 2) v = fminf(fmaxf(v, 0.f), 1.f);
-                        else if (a.act == 3) v = v > 0.f ? v : v * a.prelu[coc];
-                        else if (a.act == 4) v = 1.0f / (1.0f + expf(-v));
-                        if (a.post_scale != 0.f) v = v * a.post_scale + a.post_shift;
+                        else if (EXT && a.act == 3) v = v > 0.f ? v : v * a.prelu[coc];
+                        else if (EXT && a.act == 4) v = 1.0f / (1.0f + expf(-v));
+                        if (EXT && a.post_scale != 0.f) v = v * a.post_scale + a.post_shift;
                         if (cok && oy < a.Hout && ox < a.Wout) {
                             if (GROUPED && a.out_mode == 1) {
                                 const int Ws = 4 * a.Wout, Hs = 4 * a.Hout, c = co >> 2;
                                 const int Yt = 4 * oy + 2 * (g >> 1) + ((co >> 1) & 1), Xt = 4 * ox + 2 * (g & 1) + (co & 1);
                                 a.out[((size_t)(n * 2 + (c >> 2)) * Hs * Ws + (size_t)Yt * Ws + Xt) * 4 + (c & 3)] = v;
-                            } else if (GROUPED && a.out_mode == 2) {
+                            } else if (EXT && GROUPED && a.out_mode == 2) {
                                 const size_t q2 = (size_t)(n * 2 * a.Hout + 2 * oy + (g >> 1)) * (2 * a.Wout) + 2 * ox + (g & 1);
                                 a.out[q2 * a.out_cs + co] = v;
                             } else {
@@ -293,8 +295,8 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
 #endif
 }
 
-template <int STRIDE, int TAPS, int MT, int NT, int WM, int WN, int CK, bool GROUPED>
-static int launch2_t(ConvArgs a, hipStream_t s, const char* name) {
+template <int STRIDE, int TAPS, int MT, int NT, int WM, int WN, int CK, bool GROUPED, bool EXT>
+static int launch2_e(ConvArgs a, hipStream_t s, const char* name) {
     using G = Conv2Geom<STRIDE, TAPS, MT, NT, WM, WN, CK, GROUPED>;
     a.tiles_x = cdiv(a.Wout, G::TWO);
     a.tiles_y = cdiv(a.Hout, G::THO);
@@ -306,11 +308,11 @@ static int launch2_t(ConvArgs a, hipStream_t s, const char* name) {
     static int cus = 0;
     if (!occ) {
         VFI_CHECK_HIP(hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&conv_mfma2_kernel<STRIDE, TAPS, MT, NT, WM, WN, CK, GROUPED>),
+            reinterpret_cast<const void*>(&conv_mfma2_kernel<STRIDE, TAPS, MT, NT, WM, WN, CK, GROUPED, EXT>),
             hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
         int o = 0;
         VFI_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &o, reinterpret_cast<const void*>(&conv_mfma2_kernel<STRIDE, TAPS, MT, NT, WM, WN, CK, GROUPED>), 256,
+            &o, reinterpret_cast<const void*>(&conv_mfma2_kernel<STRIDE, TAPS, MT, NT, WM, WN, CK, GROUPED, EXT>), 256,
             G::LDS_BYTES));
         int dev = 0;
         hipDeviceProp_t p;
@@ -329,9 +331,16 @@ static int launch2_t(ConvArgs a, hipStream_t s, const char* name) {
     if (gx > T || (long)T * ny < 4L * cus * occ) gx = T;
     dim3 grid(gx, ny);
     TraceScope ts(name, s);
-    hipLaunchKernelGGL((conv_mfma2_kernel<STRIDE, TAPS, MT, NT, WM, WN, CK, GROUPED>), grid, dim3(256), G::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((conv_mfma2_kernel<STRIDE, TAPS, MT, NT, WM, WN, CK, GROUPED, EXT>), grid, dim3(256), G::LDS_BYTES, s, a);
     VFI_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+template <int STRIDE, int TAPS, int MT, int NT, int WM, int WN, int CK, bool GROUPED>
+static int launch2_t(const ConvArgs& a, hipStream_t s, const char* name) {
+    const bool ext = a.pad_replicate || a.act >= 3 || a.post_scale != 0.f || a.out_mode == 2;
+    return ext ? launch2_e<STRIDE, TAPS, MT, NT, WM, WN, CK, GROUPED, true>(a, s, name)
+               : launch2_e<STRIDE, TAPS, MT, NT, WM, WN, CK, GROUPED, false>(a, s, name);
 }
 
 // second-generation variants, numbered from kConv2Base in the common variant space

@@ -314,12 +314,12 @@ int vfi_conv_forward_ex(const vfi_conv_t* c, const float* in_dev, int in_cs, int
         a.Hout = Hin;  // per parity group; the kernel interleaves the 4 groups into [2*Hin, 2*Win]
         a.Wout = Win;
         a.out_mode = 2;
-        snprintf(name, sizeof(name), "deconv4x4s2");
+        snprintf(name, sizeof(name), "deconv4x4s2_%dto%d", c->Cin_p, c->Cout);
     } else {
         a.Hout = Hin / c->stride;
         a.Wout = Win / c->stride;
         a.tap_y0 = a.tap_x0 = c->kh == 3 ? -1 : 0;
-        snprintf(name, sizeof(name), "conv%dx%ds%d", c->kh, c->kw, c->stride);
+        snprintf(name, sizeof(name), "conv%dx%ds%d_%dto%d", c->kh, c->kw, c->stride, c->Cin_p, c->Cout);
     }
     static std::map<std::string, const char*> names;
     auto it = names.find(name);
