@@ -149,3 +149,13 @@ def test_film_node_schedule_and_skip(lib, sd, tmp_path, monkeypatch):
     want = film_oracle.film_vfi(sd, frames, multiplier=2, states=InterpolationStateList([0], True))
     assert out.shape == want.shape == (3, 64, 80, 3)   # pair 0 dropped entirely (reference quirk)
     assert (out - want).abs().max().item() <= 1e-3
+
+
+def test_interpolator_vs_reference_golden(engine, golden_dir):
+    """HIP path vs the output of the reference's own film_arch.Interpolator (tests/golden/film_net.npz, written by
+    oracle/make_golden_film_m2m.py in the build container)"""
+    g = np.load(os.path.join(golden_dir, "film_net.npz"))
+    fr = torch.from_numpy(g["frames"])
+    got = engine.forward(fr[0].cuda().contiguous(), fr[1].cuda().contiguous()).cpu()
+    want = torch.from_numpy(g["out"])[0]
+    assert (got - want).abs().max().item() <= 1e-3, describe_diff(got, want, "film vs reference golden")

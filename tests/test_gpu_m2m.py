@@ -294,3 +294,40 @@ def test_m2m_node_loop(engine, sd, multiplier, states):
     assert (got - want).abs().max().item() <= TOL, describe_diff(got, want, "node")
     src = [i for i, (k, _) in enumerate(plan) if k == "src"]
     assert all(torch.equal(got[i], fr[plan[i][1]][..., :3]) for i in src), "pass-through frames must be bit-exact"
+
+
+def test_m2m_vs_reference_golden(engine, golden_dir):
+    """HIP path vs outputs of the reference's own M2M_PWC (tests/golden/m2m_net.npz, oracle/make_golden_film_m2m.py)"""
+    import os
+
+    import numpy as np
+
+    g = np.load(os.path.join(golden_dir, "m2m_net.npz"))
+    fr = torch.from_numpy(g["frames"])
+    engine.prepare(fr[0].cuda().contiguous(), fr[1].cuda().contiguous())
+    for k, t in enumerate(g["times"]):
+        got, want = engine.render(float(t)).cpu(), torch.from_numpy(g["out"][k])
+        assert (got - want).abs().max().item() <= TOL, describe_diff(got, want, f"m2m vs reference golden t={t}")
+
+
+@pytest.mark.parametrize("name,kw", [("m2", dict(multiplier=2)), ("m3_skip1", dict(multiplier=3, states=InterpolationStateList([1], True))),
+                                     ("mlist_203", dict(multiplier=[2, 0, 3])), ("mlist_120", dict(multiplier=[1, 2, 0])),
+                                     ("mlist_3_keep0", dict(multiplier=[3], states=InterpolationStateList([0], False)))])
+def test_m2m_node_vs_reference_golden(sd, golden_dir, tmp_path, monkeypatch, name, kw):
+    """The product node class end to end (checkpoint file -> M2M_VFI.vfi, RGBA input) vs the real reference node's output"""
+    import os
+
+    import numpy as np
+    from cfi_amd import m2m
+
+    g = np.load(os.path.join(golden_dir, "m2m_node.npz"))
+    pth = tmp_path / "M2M.pth"
+    torch.save(sd, pth)
+    monkeypatch.setattr(m2m, "load_file_from_github_release", lambda model_type, ckpt: str(pth))
+    frames = torch.from_numpy(g["frames"])
+    before = frames.clone()
+    out = m2m.M2M_VFI().vfi("M2M.pth", frames, multiplier=kw["multiplier"], optional_interpolation_states=kw.get("states"))[0]
+    want = torch.from_numpy(g[name])
+    assert torch.equal(frames, before), "input must not be mutated"
+    assert out.shape == want.shape and out.device.type == "cpu" and out.dtype == torch.float32
+    assert (out - want).abs().max().item() <= TOL, describe_diff(out, want, "node vs reference golden")

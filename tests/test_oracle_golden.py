@@ -70,3 +70,64 @@ def test_oracle_bit_exact_vs_live_reference():
         a = net(i0, i1, ts, [8, 4, 2, 1], False, False)
         b = rife_oracle.ifnet47_forward(sd, i0, i1, ts)
     assert torch.equal(a, b)
+
+
+# ---- FILM / M2M: goldens written by oracle/make_golden_film_m2m.py from the reference's film_arch.Interpolator,
+# M2M_arch.M2M_PWC and the real M2M_VFI node (the two cupy ops through their C restatement) ------------------------------
+
+def test_film_interpolator_matches_reference_golden(golden_dir):
+    from oracle import film_oracle
+
+    g = np.load(os.path.join(golden_dir, "film_net.npz"))
+    x = torch.from_numpy(g["frames"]).permute(0, 3, 1, 2)
+    with torch.inference_mode():
+        out = film_oracle.film_forward(synth.film_synth_state_dict(1234), x[0:1], x[1:2]).permute(0, 2, 3, 1)
+    assert out.shape == g["out"].shape
+    assert np.abs(out.numpy() - g["out"]).max() <= TOL * max(1.0, np.abs(g["out"]).max())
+
+
+def test_m2m_model_matches_reference_golden(golden_dir):
+    from oracle import m2m_model_oracle as mo
+
+    g = np.load(os.path.join(golden_dir, "m2m_net.npz"))
+    x = torch.from_numpy(g["frames"]).permute(0, 3, 1, 2)
+    ts = [torch.tensor([float(t)]).view(1, 1, 1, 1) for t in g["times"]]
+    with torch.inference_mode():
+        outs = mo.m2m_forward(synth.m2m_synth_state_dict(1234), x[0:1], x[1:2], ts)
+    out = torch.cat(outs, 0).permute(0, 2, 3, 1)
+    assert out.shape == g["out"].shape
+    assert np.abs(out.numpy() - g["out"]).max() <= 5 * TOL
+
+
+M2M_NODE_CASES = {
+    "m2": dict(multiplier=2),
+    "m3_skip1": dict(multiplier=3, states=InterpolationStateList([1], True)),
+    "mlist_203": dict(multiplier=[2, 0, 3]),
+    "mlist_120": dict(multiplier=[1, 2, 0]),
+    "mlist_3_keep0": dict(multiplier=[3], states=InterpolationStateList([0], False)),
+}
+
+
+@pytest.mark.parametrize("name", list(M2M_NODE_CASES))
+def test_m2m_node_matches_reference_golden(golden_dir, name):
+    """The oracle's restatement of generic_frame_loop (incl. the m == 0 and local-skip-index quirks) vs the real node"""
+    from oracle import m2m_model_oracle as mo
+
+    g = np.load(os.path.join(golden_dir, "m2m_node.npz"))
+    out = mo.m2m_vfi(synth.m2m_synth_state_dict(1234), torch.from_numpy(g["frames"]), **M2M_NODE_CASES[name])
+    assert out.shape == g[name].shape
+    assert np.abs(out.numpy() - g[name]).max() <= 5 * TOL
+
+
+@pytest.mark.parametrize("name", list(M2M_NODE_CASES))
+def test_m2m_plan_matches_reference_golden(golden_dir, name):
+    """Host logic of the product node: the output plan must reproduce the reference's frame count and pass-through slots"""
+    from cfi_amd.schedule import generic_output_plan
+
+    g = np.load(os.path.join(golden_dir, "m2m_node.npz"))
+    kw = M2M_NODE_CASES[name]
+    plan, tasks = generic_output_plan(len(g["frames"]), kw["multiplier"], kw.get("states"))
+    assert len(plan) == len(g[name])
+    for i, (kind, idx) in enumerate(plan):
+        if kind == "src":
+            assert np.array_equal(g[name][i], g["frames"][idx][..., :3])
