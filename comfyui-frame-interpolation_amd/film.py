@@ -308,17 +308,35 @@ class FILM_VFI:
             lo, hi = shard_tasks(pairs, rank, ws)
             per_pair = [multipliers[i] for i in pairs]           # output frames contributed by each kept pair
             counts = [sum(per_pair[slice(*shard_tasks(pairs, r, ws))]) for r in range(ws)]
-            local = torch.empty((counts[rank], H, W, 3), dtype=torch.float32, device=dev)
-            pos = 0
-            for i in pairs[lo:hi]:
+            # host side (hostpipe.py): new frames and pass-through frames land in their rows of the output tensor in the
+            # background while the next pair computes
+            from .hostpipe import OutputWriter
+            wr = OutputWriter(sum(per_pair) + 1, H, W, dev)
+            row0 = [0]
+            for m in per_pair:
+                row0.append(row0[-1] + m)          # first output row of each kept pair
+            local = torch.empty((counts[rank], H, W, 3), dtype=torch.float32, device=dev) if ws > 1 else None
+            keep, pos = [], 0
+            for j in range(lo, hi):
+                i = pairs[j]
                 res = {0: frames[i].to(dev, torch.float32).contiguous(),
                        multipliers[i]: frames[i + 1].to(dev, torch.float32).contiguous()}
                 for (l, r, new) in film_schedule(multipliers[i] - 1):
                     res[new] = engine.forward(res[l], res[r], clamp=True)
-                for k in sorted(res)[:-1]:
-                    local[pos] = res[k]      # res[0] is the uploaded original: bit-exact round trip
+                for n_k, k in enumerate(sorted(res)[:-1]):
+                    if ws > 1:
+                        local[pos] = res[k]      # res[0] is the uploaded original: bit-exact round trip
+                    elif k == 0:
+                        wr.put_host(row0[j] + n_k, frames[i])
+                    else:
+                        wr.put_dev(row0[j] + n_k, res[k])
+                        keep.append(res[k])      # alive until the copy-back has read it
                     pos += 1
-            allf = all_gather_frames(local, counts).cpu()
-            return (torch.cat([allf, frames[-1:].to(torch.float32)], 0),)
+            if ws > 1:
+                allf = all_gather_frames(local, counts)
+                for k in range(allf.shape[0]):
+                    wr.put_dev(k, allf[k])
+            wr.put_host(sum(per_pair), frames[-1])
+            return (wr.finish(),)
         finally:
             engine.close()

@@ -1,0 +1,267 @@
+"""Host <-> device frame pipeline for the node classes.
+
+The node contract is host tensors in, a host tensor out (vfi_models/rife/__init__.py:195-207,225-239 moves every
+batch with blocking ``.to(device)`` / ``.cpu()`` calls).  At ~2 ms of device time per 1080p frame those blocking pageable
+copies — and the first-touch page faults of the freshly allocated output tensor — are what bounds the node, so:
+
+  * uploads:   worker threads copy frame f into a pinned staging slot (this also performs the alpha drop for RGBA
+               clips), then issue the H2D DMA on an upload stream, several frames ahead of the compute stream;
+  * downloads: the compute stream's results are DMA'd into pinned slots on a download stream; worker threads move
+               them into their final rows of the output tensor (parallel first-touch) while the next batch computes;
+  * pass-through frames are copied by a third pool concurrently with everything else.
+
+torch is used for what it is here for: pinned allocations, streams, events.  Pinned rings are cached per
+(device, frame shape) for the life of the process — pinning costs about as much as the copies it saves.
+"""
+import ctypes
+import os
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+import torch
+
+_ring_cache = {}
+_pools = {}
+# worker threads per pool (upload staging, download drain, pass-through copies)
+WORKERS = tuple(int(x) for x in os.environ.get("VFI_HOST_WORKERS", "2,4,2,6").split(","))
+
+
+# optional wall-clock accounting per phase (VFI_HOST_PROFILE=1): seconds summed over worker / main-thread calls
+PROFILE = os.environ.get("VFI_HOST_PROFILE", "0") == "1"
+stats = {}
+_stats_lock = threading.Lock()
+
+
+class _T:
+    def __init__(self, key):
+        self.key = key
+
+    def __enter__(self):
+        if PROFILE:
+            import time
+            self.t0 = time.perf_counter()
+
+    def __exit__(self, *a):
+        if PROFILE:
+            import time
+            dt = time.perf_counter() - self.t0
+            with _stats_lock:
+                c = stats.setdefault(self.key, [0, 0.0])
+                c[0] += 1
+                c[1] += dt
+
+
+POLL = os.environ.get("VFI_HOST_POLL", "0") == "1"
+
+
+def _wait(ev):
+    """Wait for a device event from a worker thread."""
+    if POLL:
+        import time
+        while not ev.query():
+            time.sleep(0.0002)
+    else:
+        ev.synchronize()
+
+
+def host_copy(dst, src):
+    """dst.copy_(src) for host tensors without torch's intra-op thread team: from a worker thread every torch copy
+    would spin up its own OpenMP team (hundreds of threads on a big host); a plain memmove releases the GIL and lets
+    the pools provide the parallelism.  Falls back to copy_ for strided sources (RGBA clips: the alpha drop)."""
+    if dst.is_contiguous() and src.is_contiguous() and dst.dtype == src.dtype and dst.numel() == src.numel():
+        ctypes.memmove(dst.data_ptr(), src.data_ptr(), dst.numel() * dst.element_size())
+    else:
+        dst.copy_(src)
+
+
+def _pool(name, n):
+    if name not in _pools:
+        _pools[name] = ThreadPoolExecutor(max_workers=n, thread_name_prefix="vfi-" + name)
+    return _pools[name]
+
+
+def _rings(device, shape, n_up, n_down):
+    """Pinned / device staging rings for this (device, frame shape); each ring only ever grows."""
+    r = _ring_cache.setdefault((str(device), tuple(shape)), {"up_host": [], "up_dev": [], "down_host": []})
+    while len(r["up_host"]) < n_up:
+        r["up_host"].append(torch.empty(shape, dtype=torch.float32, pin_memory=True))
+        r["up_dev"].append(torch.empty(shape, dtype=torch.float32, device=device))
+    while len(r["down_host"]) < n_down:
+        r["down_host"].append(torch.empty(shape, dtype=torch.float32, pin_memory=True))
+    return r
+
+
+class Uploader:
+    """Stages ``frames[order[i]]`` (host, [H,W,C>=3]) to the device ahead of use.  ``get(i)`` returns a device tensor
+    [H,W,3] valid on ``main`` until ``release(i)``; items must be consumed in order."""
+
+    def __init__(self, frames, order, device, main, depth=6, workers=WORKERS[0]):
+        self.frames, self.order, self.device, self.main = frames, list(order), device, main
+        H, W = frames.shape[1:3]
+        self.depth = depth
+        r = _rings(device, (H, W, 3), depth, 0)
+        self.host, self.dev = r["up_host"][:depth], r["up_dev"][:depth]
+        self.stream = torch.cuda.Stream(device)
+        self.freed = [threading.Event() for _ in self.order]      # slot of item i may be overwritten
+        self.consumed = [None] * len(self.order)                  # cuda event: main stream finished reading item i
+        pool = _pool("up", workers)
+        self.futs = [pool.submit(self._stage, i) for i in range(len(self.order))]
+
+    def _stage(self, i):
+        s = i % self.depth
+        if i >= self.depth:
+            with _T("up.wait_slot"):
+                self.freed[i - self.depth].wait()
+                _wait(self.consumed[i - self.depth])
+        with _T("up.memcpy_to_pinned"):
+            host_copy(self.host[s], self.frames[self.order[i]][..., :3])   # pageable -> pinned (drops alpha, makes contiguous)
+        ev = torch.cuda.Event()
+        with _T("up.enqueue_h2d"), torch.cuda.stream(self.stream):
+            self.dev[s].copy_(self.host[s], non_blocking=True)
+            ev.record(self.stream)
+        return ev
+
+    def get(self, i):
+        with _T("main.wait_upload"):
+            ev = self.futs[i].result()
+        self.main.wait_event(ev)
+        return self.dev[i % self.depth]
+
+    def release(self, i):
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        self.consumed[i] = ev
+        self.freed[i].set()
+
+    def close(self):
+        for i, f in enumerate(self.futs):   # unblock and surface worker errors
+            if self.consumed[i] is None:
+                self.consumed[i] = torch.cuda.Event()
+                self.consumed[i].record(self.main)
+            self.freed[i].set()
+        for f in self.futs:
+            f.result()
+
+
+class Downloader:
+    """Moves device frames [H,W,3] into rows of a host tensor through pinned slots, off the critical path."""
+
+    def __init__(self, device, shape, main, depth=16, workers=WORKERS[1]):
+        self.device, self.main, self.depth = device, main, depth
+        self.host = _rings(device, shape, 0, depth)["down_host"][:depth]
+        self.stream = torch.cuda.Stream(device)
+        self.pool = _pool("down", workers)
+        self.slot_fut = [None] * depth
+        self.n = 0
+        self.futs = []
+
+    def _finish(self, ev, s, dst):
+        with _T("down.wait_d2h"):
+            _wait(ev)
+        with _T("down.memcpy_to_out"):
+            host_copy(dst, self.host[s])
+
+    def push(self, ready_event, dev_frames, dst_rows):
+        """After ``ready_event`` (recorded on the compute stream), copy dev_frames[i] -> dst_rows[i].
+        Returns a cuda event that fires when the device buffer has been read completely."""
+        evs = []
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ready_event)
+            for i, dst in enumerate(dst_rows):
+                s = self.n % self.depth
+                if self.slot_fut[s] is not None:
+                    with _T("main.wait_down_slot"):
+                        self.slot_fut[s].result()      # slot still being drained by a worker
+                self.host[s].copy_(dev_frames[i], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+                f = self.pool.submit(self._finish, ev, s, dst)
+                self.slot_fut[s] = f
+                self.futs.append(f)
+                self.n += 1
+                evs.append(ev)
+        return evs[-1] if evs else ready_event
+
+    def close(self):
+        with _T("main.wait_down_close"):
+            for f in self.futs:
+                f.result()
+        self.futs = []
+
+
+def copy_rows_async(out, rows, frames, idx, workers=WORKERS[2]):
+    """out[rows[i]] = frames[idx[i]][..., :3] on a background pool (pass-through frames); returns futures."""
+    pool = _pool("pass", workers)
+
+    def one(r, j):
+        with _T("pass.memcpy"):
+            host_copy(out[r], frames[j][..., :3])
+
+    return [pool.submit(one, r, j) for r, j in zip(rows, idx)]
+
+
+# ---- first-touch of the output tensor --------------------------------------------------------------------------
+# A fresh torch.empty() of N_out x 24.9 MB is untouched anonymous memory: every 4 KiB written for the first time is a
+# page fault (measured 2.9 GB/s per thread on the GPU box = 8.5 ms per 1080p frame, 4x the device time).  The output
+# is therefore populated up front by a few threads with madvise(MADV_HUGEPAGE) + madvise(MADV_POPULATE_WRITE)
+# (Linux >= 5.14; falls back to a memset), overlapping the uploads and the first batches.
+_MADV_HUGEPAGE, _MADV_POPULATE_WRITE = 14, 23
+_libc = None
+
+
+def _madvise(addr, nbytes, advice):
+    global _libc
+    if _libc is None:
+        _libc = ctypes.CDLL(None, use_errno=True)
+        _libc.madvise.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    a = (addr + 4095) & ~4095
+    n = (addr + nbytes - a) & ~4095
+    return (a, n, _libc.madvise(a, n, advice)) if n > 0 else (a, 0, 0)
+
+
+def _populate(addr, nbytes):
+    with _T("prefault"):
+        a, n, rc = _madvise(addr, nbytes, _MADV_POPULATE_WRITE)
+        if n > 0 and rc != 0:      # old kernel: touch the pages the slow way
+            ctypes.memset(a, 0, n)
+
+
+def prefault_async(t, chunk=16 << 20, workers=None):
+    """Populate the pages of host tensor ``t`` (contents undefined afterwards, like torch.empty) in the background,
+    in address order.  MADV_HUGEPAGE changes VMA flags (mmap write lock), so it is issued once, up front; the
+    populate calls only take the read side and are kept short (16 MiB) so that other threads' faults and the HIP
+    runtime's own mappings are not held up behind them."""
+    workers = workers if workers is not None else (WORKERS[3] if len(WORKERS) > 3 else 6)
+    if workers <= 0 or not t.is_contiguous() or t.device.type != "cpu":
+        return []
+    pool = _pool("fault", workers)
+    base, n = t.data_ptr(), t.numel() * t.element_size()
+    _madvise(base, n, _MADV_HUGEPAGE)   # best effort (THP may be disabled)
+    return [pool.submit(_populate, base + off, min(chunk, n - off)) for off in range(0, n, chunk)]
+
+
+class OutputWriter:
+    """The node's output tensor [rows,H,W,3] (host, fp32) filled in the background: pass-through frames from host
+    tensors, new frames from device tensors.  ``finish()`` waits for everything and returns the tensor."""
+
+    def __init__(self, rows, H, W, device, depth=8):
+        self.out = torch.empty((rows, H, W, 3), dtype=torch.float32)
+        self.futs = prefault_async(self.out)
+        self.device = device
+        self.main = torch.cuda.current_stream(device)
+        self.down = Downloader(device, (H, W, 3), self.main, depth=depth)
+
+    def put_host(self, row, frame):
+        self.futs += copy_rows_async(self.out, [row], frame[None], [0])
+
+    def put_dev(self, row, dev_frame):
+        """dev_frame [H,W,3] must stay untouched until the returned event has fired (the D2H read it)."""
+        ready = torch.cuda.Event()
+        ready.record(self.main)
+        return self.down.push(ready, dev_frame[None], [self.out[row]])
+
+    def finish(self):
+        self.down.close()
+        for f in self.futs:
+            f.result()
+        return self.out

@@ -309,29 +309,72 @@ def _load_state_dict(path):
 
 
 def run_plan(engine, frames, plan, tasks):
-    """Shared by the node and the tests.  frames: [N,H,W,C] (cpu or device); plan/tasks from generic_output_plan."""
+    """Shared by the node and the tests.  frames: [N,H,W,C] host tensor; plan/tasks from generic_output_plan.
+
+    Pairs are independent: the (pair, timesteps) tasks are block-partitioned over ranks and the new frames
+    all-gathered.  Host side (hostpipe.py): every needed frame is uploaded once through pinned staging ahead of the
+    compute stream; new frames and pass-through frames land in their final rows of the output tensor in the background."""
     if not plan:  # list multiplier of zeros: the reference fails in torch.cat of an empty list (vfi_utils.py:386)
         raise RuntimeError("M2M VFI: every frame pair was dropped (multiplier 0 everywhere) - nothing to output")
     dev = engine.device
     frames = frames[..., :3]
     H, W = frames.shape[1:3]
-    # pairs are independent: block-partition the (pair, timesteps) tasks over ranks, all-gather the new frames
     rank, ws = world()
     lo, hi = shard_tasks(tasks, rank, ws)
     counts = [sum(len(ts) for _, ts in tasks[slice(*shard_tasks(tasks, r, ws))]) for r in range(ws)]
-    local = torch.empty((counts[rank], H, W, 3), dtype=torch.float32, device=dev)
-    pos = 0
-    for pair, ts in tasks[lo:hi]:
-        engine.prepare(frames[pair].to(dev, torch.float32).contiguous(), frames[pair + 1].to(dev, torch.float32).contiguous())
-        for t in ts:
-            engine.render(t, local[pos])
-            pos += 1
-    new = all_gather_frames(local, counts).cpu()
-    src = frames.to("cpu", torch.float32)
-    out = torch.empty((len(plan), H, W, 3), dtype=torch.float32)
+    if dev.type != "cuda":  # stand-in engines of the CPU tests: same control flow without the device pipeline
+        local = torch.empty((counts[rank], H, W, 3), dtype=torch.float32, device=dev)
+        pos = 0
+        for pair, ts in tasks[lo:hi]:
+            engine.prepare(frames[pair].to(dev, torch.float32).contiguous(), frames[pair + 1].to(dev, torch.float32).contiguous())
+            for t in ts:
+                engine.render(t, local[pos])
+                pos += 1
+        new = all_gather_frames(local, counts).cpu()
+        src = frames.to("cpu", torch.float32)
+        out = torch.empty((len(plan), H, W, 3), dtype=torch.float32)
+        for i, (kind, idx) in enumerate(plan):
+            out[i] = src[idx] if kind == "src" else new[idx]
+        return out
+
+    from .hostpipe import OutputWriter, Uploader
+    main = torch.cuda.current_stream(dev)
+    wr = OutputWriter(len(plan), H, W, dev)
+    new_row = {}
     for i, (kind, idx) in enumerate(plan):
-        out[i] = src[idx] if kind == "src" else new[idx]
-    return out
+        if kind == "src":
+            wr.put_host(i, frames[idx])
+        else:
+            new_row[idx] = i
+    mine = tasks[lo:hi]
+    order = sorted({f for pair, _ in mine for f in (pair, pair + 1)})
+    up = Uploader(frames, order, dev, main, depth=min(4, len(order)) or 1)
+    item_of = {f: i for i, f in enumerate(order)}
+    local = torch.empty((counts[rank], H, W, 3), dtype=torch.float32, device=dev)
+    first_new = sum(counts[:rank])
+    try:
+        pos, held, released = 0, {}, 0
+        for pair, ts in mine:
+            for f in (pair, pair + 1):
+                if f not in held:
+                    held[f] = up.get(item_of[f])
+            engine.prepare(held[pair], held[pair + 1])
+            while released < item_of[pair + 1]:       # frames before pair+1 are never needed again (tasks ascend)
+                up.release(released)
+                held.pop(order[released], None)
+                released += 1
+            for t in ts:
+                engine.render(t, local[pos])
+                if ws == 1:
+                    wr.put_dev(new_row[first_new + pos], local[pos])
+                pos += 1
+        if ws > 1:
+            new = all_gather_frames(local, counts)
+            for k in range(new.shape[0]):
+                wr.put_dev(new_row[k], new[k])
+    finally:
+        up.close()
+    return wr.finish()
 
 
 class M2M_VFI:

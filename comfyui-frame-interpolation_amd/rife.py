@@ -108,14 +108,14 @@ class RifeEngine:
 
 
 class _FrameSlots:
-    """Device frame cache: frame index -> slot, evicting frames no longer needed."""
+    """Device frame cache bookkeeping: frame index -> slot, evicting frames no longer needed."""
 
-    def __init__(self, engine, frames_cpu, n_slots):
-        self.engine, self.frames, self.n_slots = engine, frames_cpu, n_slots
+    def __init__(self, n_slots):
         self.slot_of = {}
         self.free = list(range(n_slots))
 
-    def ensure(self, needed):
+    def assign(self, needed):
+        """Make every frame of ``needed`` resident; returns the [(frame, slot)] that have to be (re)loaded, in order."""
         needed = list(dict.fromkeys(needed))
         missing = [f for f in needed if f not in self.slot_of]
         if len(missing) > len(self.free):  # recycle slots of frames this batch does not use
@@ -123,13 +123,20 @@ class _FrameSlots:
                 self.free.append(self.slot_of.pop(f))
         if len(missing) > len(self.free):
             raise RuntimeError("frame cache too small for this batch")
+        loads = []
         for f in missing:
-            slot = self.free.pop()
-            # same stream as the library's launches, so slot reuse is ordered behind earlier readers
-            dev = self.frames[f].to(self.engine.device, dtype=torch.float32).contiguous()
-            self.engine.load_frame(slot, dev)
-            self.slot_of[f] = slot
-        return self.slot_of
+            self.slot_of[f] = self.free.pop()
+            loads.append((f, self.slot_of[f]))
+        return loads
+
+
+def _batches(tasks, bs):
+    for pos in range(0, len(tasks), bs):
+        bt = tasks[pos:pos + bs]
+        need = []
+        for p, _ in bt:
+            need += [p, p + 1]
+        yield pos, bt, need
 
 
 # (ckpt_name) -> RifeEngine; the reference caches by (ckpt, dtype, torch_compile), rife/__init__.py:31
@@ -137,18 +144,20 @@ _model_cache: typing.Dict[typing.Tuple, RifeEngine] = {}
 
 
 def run_tasks(engine, frames_cpu, tasks, batch_size, scale_factor=1.0, out_device=False, out=None, out_rows=None):
-    """Interpolate ``tasks`` = [(pair, t), ...] over CPU frames [N,H,W,C].
+    """Interpolate ``tasks`` = [(pair, t), ...] over host frames [N,H,W,C].
 
     Returns [len(tasks),H,W,3] (CPU tensor, or device tensor when ``out_device``).  With ``out``/``out_rows`` the
     new frame of task i is written straight into ``out[out_rows[i]]`` (the node's final output tensor) instead.
 
-    Host pipeline: device outputs are double-buffered and batch k is copied back on a side stream while
-    batch k+1 computes; each input frame is uploaded once and its pad/encode result cached on the device."""
+    Host pipeline (hostpipe.py): each input frame is uploaded once, through pinned staging and several frames ahead of
+    the compute stream, and its pad/encode result is cached on the device; device outputs are double-buffered and
+    batch k is moved to its final host rows by worker threads while batch k+1 computes."""
+    from .hostpipe import Downloader, Uploader, _T
+
     n, H, W, _ = frames_cpu.shape
     bs = max(1, min(int(batch_size), MAX_LIB_BATCH))
     n_slots = 2 * bs + 2
     engine.configure(H, W, bs, n_slots, scale_factor)
-    slots = _FrameSlots(engine, frames_cpu, n_slots)
     dev = engine.device
     if out_device:
         res = torch.empty((len(tasks), H, W, 3), dtype=torch.float32, device=dev)
@@ -158,38 +167,63 @@ def run_tasks(engine, frames_cpu, tasks, batch_size, scale_factor=1.0, out_devic
     else:
         res = out
     main = torch.cuda.current_stream(dev)
-    copy_stream = torch.cuda.Stream(dev)
+    sim = _FrameSlots(n_slots)   # dry run of the cache: the exact upload sequence, known before the first launch
+    order = [f for _, _, need in _batches(tasks, bs) for f, _ in sim.assign(need)]
+    slots = _FrameSlots(n_slots)
+    up = Uploader(frames_cpu, order, dev, main, depth=min(len(order), bs + 4) or 1)
+    down = None if out_device else Downloader(dev, (H, W, 3), main, depth=2 * bs)
     bufs = [torch.empty((bs, H, W, 3), dtype=torch.float32, device=dev) for _ in range(2)] if not out_device else None
-    done = [torch.cuda.Event(), torch.cuda.Event()]
-    pending = None  # (buffer index, first task, count) of the batch whose copy-back is outstanding
-
-    def drain(p):
-        k, first, cnt = p
-        with torch.cuda.stream(copy_stream):
-            copy_stream.wait_event(done[k])
-            for i in range(cnt):
-                out[out_rows[first + i]].copy_(bufs[k][i])  # device -> host, directly into its final row
-        copy_stream.synchronize()
-
-    pos = 0
-    k = 0
-    while pos < len(tasks):
-        bt = tasks[pos:pos + bs]
-        need = []
-        for p, _ in bt:
-            need += [p, p + 1]
-        m = slots.ensure(need)
-        buf = res[pos:pos + len(bt)] if out_device else bufs[k][:len(bt)]
-        engine.interpolate([m[p] for p, _ in bt], [m[p + 1] for p, _ in bt], [t for _, t in bt], buf)
-        if not out_device:
-            done[k].record(main)
-            if pending is not None:
-                drain(pending)  # overlaps with the batch just enqueued
-            pending = (k, pos, len(bt))
-            k ^= 1
-        pos += len(bt)
-    if pending is not None:
-        drain(pending)
+    buf_free = [None, None]
+    import os, time
+    tl = [] if os.environ.get("VFI_HOST_TIMELINE") == "1" else None
+    if tl is not None:
+        t_base = time.perf_counter()
+        ev_base = torch.cuda.Event(enable_timing=True)
+        ev_base.record(main)
+    try:
+        item, k = 0, 0
+        for pos, bt, need in _batches(tasks, bs):
+            if tl is not None:
+                t_a = time.perf_counter() - t_base
+            for f, slot in slots.assign(need):
+                assert order[item] == f
+                src = up.get(item)
+                with _T("main.load_frame"):
+                    engine.load_frame(slot, src)
+                up.release(item)
+                item += 1
+            m = slots.slot_of
+            if out_device:
+                buf = res[pos:pos + len(bt)]
+            else:
+                buf = bufs[k][:len(bt)]
+                if buf_free[k] is not None:
+                    main.wait_event(buf_free[k])   # the copy-back of two batches ago has left this buffer
+            if tl is not None:
+                t_b = time.perf_counter() - t_base
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record(main)
+            with _T("main.interpolate"):
+                engine.interpolate([m[p] for p, _ in bt], [m[p + 1] for p, _ in bt], [t for _, t in bt], buf)
+            if tl is not None:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record(main)
+                tl.append((t_a, t_b, time.perf_counter() - t_base, e0, e1))
+            if not out_device:
+                done = torch.cuda.Event()
+                done.record(main)
+                with _T("main.push"):
+                    buf_free[k] = down.push(done, buf, [out[out_rows[pos + i]] for i in range(len(bt))])
+                k ^= 1
+    finally:
+        up.close()
+        if down is not None:
+            down.close()
+    if tl is not None:
+        torch.cuda.synchronize()
+        print("   batch: host[begin, uploads ready, enqueued] ms | device[start, end] ms (device clock zeroed at host 0)")
+        for i, (a, b, c, e0, e1) in enumerate(tl):
+            print(f"   {i:3d}: host {a * 1e3:7.1f} {b * 1e3:7.1f} {c * 1e3:7.1f} | device {ev_base.elapsed_time(e0):7.1f} {ev_base.elapsed_time(e1):7.1f}")
     return res
 
 
@@ -261,17 +295,31 @@ class RIFE_VFI:
         for i, (kind, idx) in enumerate(plan):
             if kind == "new":
                 new_rows[idx] = i
-        # pass-through frames: one vectorised copy (bit-exact), alpha already dropped
-        out.index_copy_(0, torch.tensor(src_rows, dtype=torch.long), frames.index_select(0, torch.tensor(src_idx, dtype=torch.long)).to(torch.float32))
+        # pass-through frames (bit-exact, alpha already dropped): copied by background threads while the GPU works
+        from .hostpipe import copy_rows_async, prefault_async
+        # first touch of the fresh output tensor by a few background threads (see hostpipe.py), in address order and
+        # ahead of the copies that fill it
+        passthrough = prefault_async(out)
+        passthrough += copy_rows_async(out, src_rows, frames, src_idx)
         rank, ws = world()
         if ws > 1:
             lo, hi = shard_tasks(tasks, rank, ws)
             counts = [shard_tasks(tasks, r, ws)[1] - shard_tasks(tasks, r, ws)[0] for r in range(ws)]
             local = run_tasks(engine, frames, tasks[lo:hi], batch_size, scale_factor, out_device=True)
             new_frames = all_gather_frames(local, counts)
-            for i in range(len(tasks)):
-                out[new_rows[i]].copy_(new_frames[i])
+            from .hostpipe import Downloader
+            main = torch.cuda.current_stream(engine.device)
+            down = Downloader(engine.device, tuple(frames.shape[1:3]) + (3,), main, depth=16)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            for c in range(0, len(tasks), 8):
+                down.push(ready, new_frames[c:c + 8], [out[new_rows[i]] for i in range(c, min(c + 8, len(tasks)))])
+            down.close()
         else:
             run_tasks(engine, frames, tasks, batch_size, scale_factor, out=out, out_rows=new_rows)
+        from .hostpipe import _T
+        with _T("main.wait_pass"):
+            for f in passthrough:
+                f.result()
         print(f"Comfy-VFI done! {len(plan)} frames generated")
         return (out,)

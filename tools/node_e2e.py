@@ -27,9 +27,25 @@ if __name__ == "__main__":
         frames = base[torch.arange(n) % 3].contiguous()
         node = R.RIFE_VFI()
         node.vfi("rife47.pth", frames[:3], multiplier=2, batch_size=bs)  # warm-up (model load, workspace)
-        for rep in range(2):
+        from cfi_amd import _lib
+        lib = _lib.load()
+        trace = os.environ.get("TRACE", "0") == "1"
+        for rep in range(int(os.environ.get('REPS', '4'))):
+            if trace:
+                lib.vfi_trace_reset(); lib.vfi_trace_enable(1)
             t0 = time.perf_counter()
-            (out,) = node.vfi("rife47.pth", frames, multiplier=2, batch_size=bs)
+            res = node.vfi("rife47.pth", frames, multiplier=2, batch_size=bs)
             dt = time.perf_counter() - t0
+            if trace:
+                lib.vfi_trace_enable(0)
+                rep_ = _lib.trace_report()
+                print(f"   device kernels: {sum(v[1] for v in rep_.values()):.1f} ms busy of {dt * 1e3:.1f} ms wall; "
+                      + ", ".join(f"{k} {v[1]:.1f}" for k, v in sorted(rep_.items(), key=lambda kv: -kv[1][1])[:6]), flush=True)
+            out = res[0]    # the previous result is released here, outside the timed region (munmap of 1.6 GB)
+            del res
             print(f"node e2e: {n} frames 1080p -> {out.shape[0]} frames, batch_size={bs}: {dt:.3f} s, "
                   f"{(n - 1) / dt:.1f} interpolated frames/s (host tensor in, host tensor out)", flush=True)
+            from cfi_amd import hostpipe
+            if hostpipe.PROFILE:
+                print("   " + "; ".join(f"{k} n={v[0]} {v[1] * 1e3:.0f}ms" for k, v in sorted(hostpipe.stats.items())), flush=True)
+                hostpipe.stats.clear()
