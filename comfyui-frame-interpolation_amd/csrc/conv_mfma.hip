@@ -306,7 +306,7 @@ int conv_launch(const ConvArgs& a, int stride, bool grouped, int variant, hipStr
                 const char* trace_name) {
     if (variant < 0 && grouped) {  // experiment hook: force a grouped (transposed-conv) tile variant
         static const char* env = getenv("VFI_GROUPED_VARIANT");
-        if (env) variant = atoi(env);
+        if (env && *env) variant = atoi(env);
     }
     if (variant < 0) variant = conv_pick_variant(a, stride, grouped);
     const ConvVariant* vp = conv_variant_lookup(variant);

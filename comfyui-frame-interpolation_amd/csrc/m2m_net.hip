@@ -151,31 +151,27 @@ __global__ void warp_m2m_kernel(const float* __restrict__ in, int in_cs, int in_
     }
 }
 
-// ---- pooled means for the cube (adaptive_avg_pool2d to 1x1, Hx1, 1xW) -----------------------------------------
-// mode 0: out[n, 0, c] over all pixels; 1: out[n, y, c] over x; 2: out[n, x, c] over y.   One thread per output.
-__global__ void pool_mean_kernel(const float* __restrict__ in, int in_cs, float* __restrict__ out, int out_cs, int N, int H,
-                                 int W, int C, int mode) {
-    const int L = mode == 0 ? 1 : (mode == 1 ? H : W);
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)N * L * C) return;
-    const int c = idx % C;
-    const int l = (idx / C) % L;
-    const int n = idx / ((long)C * L);
-    const float* b = in + (size_t)n * H * W * in_cs + c;
-    double s = 0.0;
-    if (mode == 0) {
-        for (long p = 0; p < (long)H * W; ++p) s += b[p * in_cs];
-        s /= (double)H * W;
-    } else if (mode == 1) {
-        for (int x = 0; x < W; ++x) s += b[((size_t)l * W + x) * in_cs];
-        s /= W;
-    } else {
-        for (int y = 0; y < H; ++y) s += b[((size_t)y * W + l) * in_cs];
-        s /= H;
+// ---- pooled means for the cube (adaptive_avg_pool2d to Hx1, 1xW, 1x1) ----------------------------------------------
+// One block per output row of the pooled tensor, one thread per channel (coalesced over channels), double accumulation.
+// mode 1: out[n, y, c] = mean_x in[n,y,x,c];  mode 2: out[n, x, c] = mean_y in[n,y,x,c];  mode 0: out[n, 0, c] = mean_yx.
+__global__ void pool_mean_kernel(const float* __restrict__ in, int in_cs, float* __restrict__ out, int out_cs, int H, int W,
+                                 int C, int mode) {
+    const int L = mode == 1 ? H : W;
+    const int n = blockIdx.x / L, l = blockIdx.x - n * L;
+    const float* b = in + (size_t)n * H * W * in_cs;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double s = 0.0;
+        if (mode == 1) {
+            for (int x = 0; x < W; ++x) s += b[((size_t)l * W + x) * in_cs + c];
+            s /= W;
+        } else {
+            for (int y = 0; y < H; ++y) s += b[((size_t)y * W + l) * in_cs + c];
+            s /= H;
+        }
+        out[((size_t)n * L + l) * out_cs + c] = (float)s;
     }
-    out[((size_t)n * L + l) * out_cs + c] = (float)s;
 }
-// global pool with one block per (n, channel group): coalesced over channels, LDS reduce over pixel strips
+// global pool: one block per (n, 64-channel group); 4 pixel strips per block reduced through LDS
 __global__ __launch_bounds__(256) void pool_global_kernel(const float* __restrict__ in, int in_cs, float* __restrict__ out,
                                                           int out_cs, int H, int W, int C) {
     __shared__ double red[4][64];
@@ -359,8 +355,8 @@ int vfi_pool_mean(const float* in_dev, int in_cs, float* out_dev, int out_cs, in
     if (mode == 0) {
         hipLaunchKernelGGL(pool_global_kernel, dim3((C + 63) / 64, N), dim3(256), 0, s, in_dev, in_cs, out_dev, out_cs, H, W, C);
     } else {
-        const long n = (long)N * (mode == 1 ? H : W) * C;
-        hipLaunchKernelGGL(pool_mean_kernel, dim3(nblk(n)), dim3(256), 0, s, in_dev, in_cs, out_dev, out_cs, N, H, W, C, mode);
+        hipLaunchKernelGGL(pool_mean_kernel, dim3(N * (mode == 1 ? H : W)), dim3(C < 256 ? 64 * ((C + 63) / 64) : 256), 0, s, in_dev,
+                           in_cs, out_dev, out_cs, H, W, C, mode);
     }
     VFI_CHECK_HIP(hipGetLastError());
     return 0;

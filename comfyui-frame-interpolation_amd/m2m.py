@@ -275,8 +275,10 @@ class M2MEngine:
     def _cube(self):
         lib, st = self.lib, _lib.stream_ptr()
         h, w = self.ench[3]
-        for mode, dst in ((0, self.pc), (1, self.ph), (2, self.pw)):
+        for mode, dst in ((1, self.ph), (2, self.pw)):
             _lib.check(lib.vfi_pool_mean(_p(self.s3), 256, _p(dst), 256, 2, h, w, 256, mode, st), "vfi_pool_mean")
+        # global mean = mean over rows of the row means (every row has w pixels): 68 values per channel instead of 8160
+        _lib.check(lib.vfi_pool_mean(_p(self.ph), 256, _p(self.pc), 256, 2, h, 1, 256, 0, st), "vfi_pool_mean")
         self.cube[0](self.pc, 0, self.cc, 0, 4)
         self.cube[1](self.ph, 0, self.ch, 0, 4)
         self.cube[2](self.pw, 0, self.cw, 0, 4)

@@ -94,6 +94,16 @@ def main():
             R._model_cache[("rife47.pth", "float32", False)] = Dummy()
             o = R.RIFE_VFI().vfi("rife47.pth", tf, **kw)[0]
             kat[name] = [round(float(v) * 4, 5) for v in o[:, 0, 0, 0]]
+        # ---- BASELINE.json configs[0]: the node on the full demo_frames/anime0+anime1 pair (540x960), 2x.
+        # Inputs are stored as the PNG's uint8 pixels (frames = u8 / 255), the output as the synthesised middle frame.
+        from PIL import Image
+        u8 = np.stack([np.asarray(Image.open(os.path.join(ref_import.REFERENCE, "demo_frames", n)).convert("RGB"))
+                       for n in ("anime0.png", "anime1.png")])
+        fr = torch.from_numpy(u8.astype(np.float32) / 255.0)
+        R._model_cache.clear()
+        o = R.RIFE_VFI().vfi("rife47.pth", fr, multiplier=2)[0]
+        assert o.shape[0] == 3 and torch.equal(o[0], fr[0]) and torch.equal(o[2], fr[1])
+        np.savez_compressed(os.path.join(OUT, "rife47_node_anime540.npz"), frames_u8=u8, mid=o[1].numpy())
     np.savez_compressed(os.path.join(OUT, "rife47_node.npz"), frames=frames.numpy(), **node_out)
     with open(os.path.join(OUT, "rife_schedule_kat.json"), "w") as f:
         json.dump(kat, f, indent=1)

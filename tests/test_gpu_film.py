@@ -159,3 +159,13 @@ def test_interpolator_vs_reference_golden(engine, golden_dir):
     got = engine.forward(fr[0].cuda().contiguous(), fr[1].cuda().contiguous()).cpu()
     want = torch.from_numpy(g["out"])[0]
     assert (got - want).abs().max().item() <= 1e-3, describe_diff(got, want, "film vs reference golden")
+
+
+def test_config2_film_1080p(engine, sd):
+    """BASELINE.json configs[2]: FILM 2x at 1080x1920 (one Interpolator call), against the oracle (~35 s on the host)."""
+    fr = synth.smooth_frames(2, 1080, 1920, seed=2, shift=4.0)
+    x = fr.permute(0, 3, 1, 2).contiguous()
+    with torch.inference_mode():
+        want = film_oracle.film_forward(sd, x[0:1], x[1:2])[0].permute(1, 2, 0)
+    got = engine.forward(fr[0].cuda().contiguous(), fr[1].cuda().contiguous()).cpu()
+    assert (got - want).abs().max().item() <= 1e-3, describe_diff(got, want, "film 1080p")

@@ -196,3 +196,36 @@ def test_node_rejects_unsupported(hip_lib, sd, tmp_path, monkeypatch):
         R.RIFE_VFI().vfi("nope.pth", torch.zeros(2, 8, 8, 3))
     with pytest.raises(NotImplementedError):
         R.RifeEngine(sd, "4.26")
+
+
+def test_config0_anime_pair_vs_reference_node(hip_lib, sd, golden_dir, tmp_path, monkeypatch):
+    """BASELINE.json configs[0]: the node on the full demo pair anime0+anime1 (540x960), 2x, against the frame the
+    reference node synthesised on torch-CPU (tests/golden/rife47_node_anime540.npz, oracle/make_golden.py)."""
+    import cfi_amd.rife as R
+
+    pth = tmp_path / "rife47.pth"
+    torch.save(sd, pth)
+    monkeypatch.setattr(R, "load_file_from_github_release", lambda model_type, ckpt: str(pth))
+    g = np.load(os.path.join(golden_dir, "rife47_node_anime540.npz"))
+    frames = torch.from_numpy(g["frames_u8"].astype(np.float32) / 255.0)
+    (out,) = R.RIFE_VFI().vfi("rife47.pth", frames, multiplier=2)
+    assert out.shape == (3, 540, 960, 3) and torch.equal(out[0], frames[0]) and torch.equal(out[2], frames[1])
+    want = torch.from_numpy(g["mid"])
+    assert (out[1] - want).abs().max().item() <= TOL, describe_diff(out[1], want, "anime 540p node")
+
+
+def test_config3_rife49_4k_x4(hip_lib, sd, tmp_path, monkeypatch):
+    """BASELINE.json configs[3] on one rank: rife49.pth (runs as arch 4.7, rife/__init__.py:10-20), 4x multiplier on a
+    4K pair (2160x3840, padded 2176x3840), through the node, against the oracle (3 forwards, ~15 s on the host)."""
+    import cfi_amd.rife as R
+
+    pth = tmp_path / "rife49.pth"
+    torch.save(sd, pth)
+    monkeypatch.setattr(R, "load_file_from_github_release", lambda model_type, ckpt: str(pth))
+    R._model_cache.clear()
+    frames = synth.smooth_frames(2, 2160, 3840, seed=6, shift=6.0)
+    (out,) = R.RIFE_VFI().vfi("rife49.pth", frames, multiplier=4, batch_size=3)
+    R._model_cache.clear()
+    assert out.shape == (5, 2160, 3840, 3) and torch.equal(out[0], frames[0]) and torch.equal(out[4], frames[1])
+    want, _ = _oracle_mid(sd, frames, [(0, 0.25), (0, 0.5), (0, 0.75)])
+    assert (out[1:4] - want).abs().max().item() <= TOL, describe_diff(out[1:4], want, "4K x4")

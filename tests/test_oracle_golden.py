@@ -131,3 +131,12 @@ def test_m2m_plan_matches_reference_golden(golden_dir, name):
     for i, (kind, idx) in enumerate(plan):
         if kind == "src":
             assert np.array_equal(g[name][i], g["frames"][idx][..., :3])
+
+
+def test_config0_anime_pair_matches_reference_node(golden_dir):
+    """BASELINE.json configs[0] on the CPU: oracle node loop vs the reference node's output on the full demo pair"""
+    g = np.load(os.path.join(golden_dir, "rife47_node_anime540.npz"))
+    frames = torch.from_numpy(g["frames_u8"].astype(np.float32) / 255.0)
+    out = rife_oracle.rife_vfi(synth.rife47_synth_state_dict(1234), frames, multiplier=2)
+    assert out.shape == (3, 540, 960, 3) and torch.equal(out[0], frames[0]) and torch.equal(out[2], frames[1])
+    assert np.abs(out[1].numpy() - g["mid"]).max() <= TOL
