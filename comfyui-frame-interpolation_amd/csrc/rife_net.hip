@@ -58,9 +58,11 @@ struct vfi_rife {
     DevBuf enc_w0, enc_b0, enc_w1, enc_b1;
     // geometry
     int H = 0, W = 0, Hp = 0, Wp = 0, max_batch = 0, n_slots = 0;
-    int scales[4] = {8, 4, 2, 1};
+    int scales[4] = {8, 4, 2, 1};  // integer block scales (1 where the block scale is fractional)
+    int up[4] = {1, 1, 1, 1};      // 1/scale for fractional block scales 0.5 / 0.25 (scale_factor 2 / 4)
     // workspace
     DevBuf Ppool, E, F, M, X, A0, A1, A2, T;
+    DevBuf X1, T1;  // frame-resolution staging around blocks that run above the frame resolution
     DevBuf Fdbg[4], Xdbg[4];
     bool keep = false;
     int last_B = 0;
@@ -195,7 +197,7 @@ void vfi_rife_destroy(vfi_rife_t* net) {
         net->Xdbg[b].release();
     }
     for (DevBuf* d : {&net->enc_w0, &net->enc_b0, &net->enc_w1, &net->enc_b1, &net->Ppool, &net->E, &net->F, &net->M,
-                      &net->X, &net->A0, &net->A1, &net->A2, &net->T})
+                      &net->X, &net->A0, &net->A1, &net->A2, &net->T, &net->X1, &net->T1})
         d->release();
     delete net;
 }
@@ -205,21 +207,36 @@ int vfi_rife_configure(vfi_rife_t* net, int H, int W, int max_batch, int n_slots
     VFI_REQUIRE(H > 0 && W > 0 && max_batch >= 1 && max_batch <= kMaxTasks && n_slots >= 2,
                 "vfi_rife_configure: bad arguments H=%d W=%d max_batch=%d (1..%d) n_slots=%d", H, W, max_batch,
                 kMaxTasks, n_slots);
-    // scale_list = [8,4,2,1] / scale_factor (rife/__init__.py:157-160); integer scales only for now
+    // scale_list = [8,4,2,1] / scale_factor (rife/__init__.py:157-160).  Block scales >= 1 must be 1 or even integers
+    // (the down-resize then is the centre-2x2 mean); block scales 0.5 / 0.25 run the block above the frame resolution.
     const float base[4] = {8.f, 4.f, 2.f, 1.f};
-    int sc[4];
+    int sc[4], up[4];
     for (int i = 0; i < 4; ++i) {
         const float s = base[i] / scale_factor;
-        sc[i] = (int)s;
-        VFI_REQUIRE((float)sc[i] == s && (sc[i] == 1 || sc[i] % 2 == 0),
-                    "vfi_rife_configure: scale_factor %g gives non-integer block scale %g (supported: 1.0, 0.5)",
-                    scale_factor, s);
+        if (s >= 1.f) {
+            sc[i] = (int)s;
+            up[i] = 1;
+            VFI_REQUIRE((float)sc[i] == s && (sc[i] == 1 || sc[i] % 2 == 0),
+                        "vfi_rife_configure: scale_factor %g gives block scale %g (supported scale_factor: 0.25, 0.5, 1, 2, 4)",
+                        scale_factor, s);
+        } else {
+            sc[i] = 1;
+            up[i] = (int)(1.f / s);
+            VFI_REQUIRE((up[i] == 2 || up[i] == 4) && 1.f / (float)up[i] == s && i > 0,
+                        "vfi_rife_configure: scale_factor %g gives block scale %g (supported scale_factor: 0.25, 0.5, 1, 2, 4)",
+                        scale_factor, s);
+        }
     }
     const int Hp = round_up(H, 64), Wp = round_up(W, 64);
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
         VFI_REQUIRE(Hp % (4 * sc[i]) == 0 && Wp % (4 * sc[i]) == 0,
                     "vfi_rife_configure: padded size %dx%d not divisible by 4*scale %d (the reference fails here too, "
                     "SURVEY.md App. C6)", Hp, Wp, sc[i]);
+        // the block input of an up-scaled block is addressed with 32-bit element offsets
+        VFI_REQUIRE((double)Hp * Wp * up[i] * up[i] * 24 < 2147483647.0,
+                    "vfi_rife_configure: %dx%d is too large for scale_factor %g (block input above 2^31 elements)", H, W,
+                    scale_factor);
+    }
     net->H = H;
     net->W = W;
     net->Hp = Hp;
@@ -227,10 +244,11 @@ int vfi_rife_configure(vfi_rife_t* net, int H, int W, int max_batch, int n_slots
     net->max_batch = max_batch;
     net->n_slots = n_slots;
     memcpy(net->scales, sc, sizeof(sc));
+    memcpy(net->up, up, sizeof(up));
     const size_t full = (size_t)Hp * Wp, B = max_batch;
     size_t x = 0, a0 = 0, a1 = 0, t = 0;
     for (int i = 0; i < 4; ++i) {
-        const size_t px = full / ((size_t)sc[i] * sc[i]);
+        const size_t px = full / ((size_t)sc[i] * sc[i]) * ((size_t)up[i] * up[i]);
         const size_t cx = i == 0 ? 16 : 24;
         x = std::max(x, px * cx);
         a0 = std::max(a0, px / 4 * (kBlockC[i] / 2));
@@ -242,6 +260,7 @@ int vfi_rife_configure(vfi_rife_t* net, int H, int W, int max_batch, int n_slots
         net->M.ensure(B * full) || net->X.ensure(B * x) || net->A0.ensure(B * a0) || net->A1.ensure(B * a1) ||
         net->A2.ensure(B * a1) || net->T.ensure(B * t))
         return -1;
+    if ((up[2] > 1 || up[3] > 1 || up[1] > 1) && (net->X1.ensure(B * full * 24) || net->T1.ensure(B * full * 8))) return -1;
     return 0;
 }
 
@@ -294,17 +313,18 @@ int vfi_rife_interpolate(vfi_rife_t* net, int B, const int* slot0, const int* sl
     static const char* kLastName[4] = {"lastconv_b0", "lastconv_b1", "lastconv_b2", "lastconv_b3"};
     bool fused_prev = false;
     for (int i = 0; i < 4; ++i) {
-        const int s = net->scales[i];
-        const int Hs = Hp / s, Ws = Wp / s;
+        const int s = net->scales[i], u = net->up[i];
+        const int Hs = Hp / s * u, Ws = Wp / s * u;
         const int c = kBlockC[i];
         const int CX = i == 0 ? 16 : 24;
         // X of this block: block 0 has no flow yet; later blocks get X from the fused transition kernel of the
         // previous iteration when the scale list allows it (standard [8,4,2,1]), else from stage_in.
         const bool x_ready = i > 0 && fused_prev;
         if (!x_ready &&
-            stage_in_launch(net->Ppool.p, net->pack_stride(), tasks, B, net->F.p, net->M.p, net->X.p, Hp, Wp, s, CX,
-                            i > 0, st))
+            stage_in_launch(net->Ppool.p, net->pack_stride(), tasks, B, net->F.p, net->M.p, u > 1 ? net->X1.p : net->X.p, Hp, Wp,
+                            s, CX, i > 0, st))
             return -1;
+        if (u > 1 && planar4_up_launch(net->X1.p, net->X.p, B, Hp, Wp, u, CX, /*flow plane*/ 4, st)) return -1;
         if (net->keep) {
             const size_t n = (size_t)B * Hs * Ws * CX;
             if (net->Xdbg[i].ensure(n)) return -1;
@@ -343,14 +363,19 @@ int vfi_rife_interpolate(vfi_rife_t* net, int B, const int* slot0, const int* sl
         a.out_mode = 1;  // PixelShuffle(2) resolved by the epilogue: T is planar4 [B][2][Hs][Ws][4]
         deconv4x4_taps(a);
         if (conv_launch(a, 1, true, -1, st, kLastName[i])) return -1;
+        const float* Tsrc = net->T.p;
+        if (u > 1) {  // interpolate(tmp, scale) and flow * scale: back to the frame resolution, then as a scale-1 block
+            if (t_down_launch(net->T.p, net->T1.p, B, Hp, Wp, u, st)) return -1;
+            Tsrc = net->T1.p;
+        }
         if (i < 3) {
             const int sn = net->scales[i + 1];
-            fused_prev = s == 2 * sn && (sn == 4 || sn == 2 || sn == 1);
+            fused_prev = u == 1 && net->up[i + 1] == 1 && s == 2 * sn && (sn == 4 || sn == 2 || sn == 1);
             if (fused_prev) {
-                if (stage_trans_launch(net->Ppool.p, net->pack_stride(), tasks, B, net->T.p, net->F.p, net->X.p, Hp, Wp,
+                if (stage_trans_launch(net->Ppool.p, net->pack_stride(), tasks, B, Tsrc, net->F.p, net->X.p, Hp, Wp,
                                        s, sn, i > 0, st))
                     return -1;
-            } else if (flow_up_launch(net->T.p, net->F.p, net->M.p, B, Hp, Wp, s, i > 0, st)) {
+            } else if (flow_up_launch(Tsrc, net->F.p, net->M.p, B, Hp, Wp, s, i > 0, st)) {
                 return -1;
             }
             if (net->keep) {
@@ -366,7 +391,7 @@ int vfi_rife_interpolate(vfi_rife_t* net, int B, const int* slot0, const int* sl
                 VFI_CHECK_HIP(hipMemsetAsync(net->Fdbg[i].p, 0, n * sizeof(float), st));
                 fd = net->Fdbg[i].p;
             }
-            if (final_blend_launch(net->Ppool.p, net->pack_stride(), tasks, B, net->T.p, net->F.p, out_dev, fd, net->H,
+            if (final_blend_launch(net->Ppool.p, net->pack_stride(), tasks, B, Tsrc, net->F.p, out_dev, fd, net->H,
                                    net->W, Hp, Wp, s, st))
                 return -1;
         }
@@ -392,9 +417,9 @@ int64_t vfi_rife_debug_read(vfi_rife_t* net, int what, int stage, float* host_bu
         src = net->Fdbg[stage].p;
         n = (size_t)net->last_B * net->Hp * net->Wp * 4;
     } else if (what == 1 && stage >= 0 && stage < 4) {
-        const int s = net->scales[stage];
+        const int s = net->scales[stage], u = net->up[stage];
         src = net->Xdbg[stage].p;
-        n = (size_t)net->last_B * (net->Hp / s) * (net->Wp / s) * (stage == 0 ? 16 : 24);
+        n = (size_t)net->last_B * (net->Hp / s * u) * (net->Wp / s * u) * (stage == 0 ? 16 : 24);
     } else if (what == 2 && stage >= 0 && stage < net->n_slots) {
         src = net->Ppool.p + (size_t)stage * net->pack_stride();
         n = net->pack_stride();
@@ -416,7 +441,7 @@ int vfi_rife_work(vfi_rife_t* net, double* conv_flop_per_task, double* hbm_bytes
     const double full = (double)net->Hp * net->Wp;
     double mac = 0;
     for (int i = 0; i < 4; ++i) {
-        const double px = full / ((double)net->scales[i] * net->scales[i]);
+        const double px = full / ((double)net->scales[i] * net->scales[i]) * ((double)net->up[i] * net->up[i]);
         const double c = kBlockC[i];
         mac += px / 4 * (c / 2) * kBlockIn[i] * 9;   // conv0.0
         mac += px / 16 * c * (c / 2) * 9;            // conv0.1

@@ -21,6 +21,8 @@ int stage_trans_launch(const float* Ppool, size_t pack_stride, const RifeTasks& 
                        float* X, int Hp, int Wp, int s_prev, int s_next, bool has_prev, hipStream_t st);
 int final_blend_launch(const float* Ppool, size_t pack_stride, const RifeTasks& tasks, int B, const float* T,
                        const float* F, float* out, float* Fdbg, int H, int W, int Hp, int Wp, int s, hipStream_t st);
+int planar4_up_launch(const float* X1, float* X, int B, int Hp, int Wp, int u, int CX, int flow_plane, hipStream_t st);
+int t_down_launch(const float* T, float* T1, int B, int Hp, int Wp, int u, hipStream_t st);
 int t_to_nhwc_launch(const float* T, float* out, int N, int Hq, int Wq, int C4, hipStream_t st);
 
 }  // namespace vfi

@@ -605,6 +605,76 @@ int final_blend_launch(const float* Ppool, size_t pack_stride, const RifeTasks& 
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------
+// Fractional block scales (node widget scale_factor 2 / 4 -> block scales 0.5 / 0.25): the block runs ABOVE the
+// frame resolution.  IFBlock.forward (rife_arch.py:237-276) then up-samples its input by u = 1/scale
+// (flow channels additionally * u) and down-samples its output by scale (flow * scale).  Both resizes are plain
+// bilinear align_corners=False; they are done on the assembled planar4 tensors around the unchanged block kernels:
+//   stage_in(scale 1) -> X1 --planar4_up--> X (u*Hp x u*Wp) -> convs -> T (u*Hp x u*Wp) --t_down--> T1 (Hp x Wp, scale 1)
+// ---------------------------------------------------------------------------------------
+__global__ void planar4_up_kernel(const float* __restrict__ X1, float* __restrict__ Xo, int Hp, int Wp, int u, int nplanes,
+                                  int flow_plane) {
+    const int Hs = Hp * u, Ws = Wp * u;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)Hs * Ws) return;
+    const int pl = blockIdx.y, b = blockIdx.z;
+    const int X = idx % Ws, Y = idx / Ws;
+    const float rs = 1.0f / (float)u;
+    const Bil by = bil_index(Y, rs, Hp), bx = bil_index(X, rs, Wp);
+    const float4* src = (const float4*)X1 + ((size_t)b * nplanes + pl) * Hp * Wp;
+    const float4 a = src[(size_t)by.i0 * Wp + bx.i0], bb = src[(size_t)by.i0 * Wp + bx.i1];
+    const float4 c = src[(size_t)by.i1 * Wp + bx.i0], d = src[(size_t)by.i1 * Wp + bx.i1];
+    const float wy0 = by.w0, wy1 = by.w1, wx0 = bx.w0, wx1 = bx.w1;
+#define VFI_BL(A, B, C, D) \
+    __fadd_rn(__fmul_rn(wy0, __fadd_rn(__fmul_rn(wx0, A), __fmul_rn(wx1, B))), __fmul_rn(wy1, __fadd_rn(__fmul_rn(wx0, C), __fmul_rn(wx1, D))))
+    float4 r;
+    r.x = VFI_BL(a.x, bb.x, c.x, d.x);
+    r.y = VFI_BL(a.y, bb.y, c.y, d.y);
+    r.z = VFI_BL(a.z, bb.z, c.z, d.z);
+    r.w = VFI_BL(a.w, bb.w, c.w, d.w);
+#undef VFI_BL
+    if (pl == flow_plane) {  // interpolate(flow, 1/scale) * 1.0 / scale: the factor is a power of two, exact
+        const float fu = (float)u;
+        r = make_float4(r.x * fu, r.y * fu, r.z * fu, r.w * fu);
+    }
+    ((float4*)Xo)[((size_t)b * nplanes + pl) * Hs * Ws + idx] = r;
+}
+
+int planar4_up_launch(const float* X1, float* X, int B, int Hp, int Wp, int u, int CX, int flow_plane, hipStream_t st) {
+    VFI_REQUIRE(u == 2 || u == 4, "planar4_up: factor %d", u);
+    dim3 grid(cdiv((long)Hp * u * Wp * u, 256), CX / 4, B);
+    TraceScope ts("stage_up", st);
+    hipLaunchKernelGGL(planar4_up_kernel, grid, dim3(256), 0, st, X1, X, Hp, Wp, u, CX / 4, flow_plane);
+    VFI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// T [B][2][u*Hp][u*Wp][4] -> T1 [B][2][Hp][Wp][4]: interpolate(tmp, scale_factor=1/u); flow components * (1/u)
+__global__ void t_down_kernel(const float* __restrict__ T, float* __restrict__ T1, int Hp, int Wp, int u) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Hp * Wp) return;
+    const int b = blockIdx.y;
+    const int X = idx % Wp, Y = idx / Wp;
+    const int Hs = Hp * u, Ws = Wp * u;
+    const float* Tb = T + (size_t)b * Hs * Ws * 8;
+    const Bil by = bil_index(Y, (float)u, Hs), bx = bil_index(X, (float)u, Ws);
+    const TVal v = t_bilerp(t_read(Tb, Hs, Ws, by.i0, bx.i0), t_read(Tb, Hs, Ws, by.i0, bx.i1), t_read(Tb, Hs, Ws, by.i1, bx.i0),
+                            t_read(Tb, Hs, Ws, by.i1, bx.i1), by.w0, by.w1, bx.w0, bx.w1);
+    const float sc = 1.0f / (float)u;
+    float* o = T1 + (size_t)b * Hp * Wp * 8;
+    ((float4*)o)[idx] = make_float4(v.f.x * sc, v.f.y * sc, v.f.z * sc, v.f.w * sc);
+    ((float4*)o)[(size_t)Hp * Wp + idx] = make_float4(v.m, 0.f, 0.f, 0.f);
+}
+
+int t_down_launch(const float* T, float* T1, int B, int Hp, int Wp, int u, hipStream_t st) {
+    VFI_REQUIRE(u == 2 || u == 4, "t_down: factor %d", u);
+    dim3 grid(cdiv(Hp * Wp, 256), B);
+    TraceScope ts("t_down", st);
+    hipLaunchKernelGGL(t_down_kernel, grid, dim3(256), 0, st, T, T1, Hp, Wp, u);
+    VFI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // deconv+PixelShuffle result in plain NHWC [N,4H,4W,C4] from the planar4 T layout (test entry, C4 <= 6)
 __global__ void t_to_nhwc_kernel(const float* __restrict__ T, float* __restrict__ out, int N, int Hq, int Wq, int C4) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;

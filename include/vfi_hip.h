@@ -187,7 +187,8 @@ void vfi_rife_destroy(vfi_rife_t* net);
 
 /* (Re)size the workspace: frames of H x W (unpadded), up to `max_batch` tasks per forward and
  * `n_slots` cached frames.  scale_factor as in the node widget (scale_list = [8,4,2,1]/sf,
- * vfi_models/rife/__init__.py:157-160); only values giving integer scales are accepted. */
+ * vfi_models/rife/__init__.py:157-160): 0.25, 0.5, 1, 2, 4 — block scales >= 1 must divide the padded size,
+ * block scales 0.5 / 0.25 (sf 2 / 4) run the block at 2x / 4x the frame resolution (rife_arch.py:237-276). */
 int vfi_rife_configure(vfi_rife_t* net, int H, int W, int max_batch, int n_slots, float scale_factor);
 
 /* Upload-side half of IFNet.forward for ONE input frame: clamp to [0,1], zero-pad to x64

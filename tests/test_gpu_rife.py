@@ -133,7 +133,24 @@ def test_scale_factor_half(engine, sd):
                                            (16.0, 8.0, 4.0, 2.0)).clamp(0, 1).permute(0, 2, 3, 1)
     assert (got - want).abs().max().item() <= TOL, describe_diff(got, want, "scale_factor 0.5")
     with pytest.raises(RuntimeError):
-        run_tasks(engine, frames, tasks, batch_size=1, scale_factor=2.0)   # fractional block scale: not implemented
+        run_tasks(engine, frames, tasks, batch_size=1, scale_factor=3.0)   # not one of the widget's values
+
+
+@pytest.mark.parametrize("sf,h,w", [(2.0, 120, 200), (4.0, 70, 100), (2.0, 270, 480)])
+def test_scale_factor_above_one(engine, sd, sf, h, w):
+    """scale_factor 2 / 4 -> block scales [4,2,1,0.5] / [2,1,0.5,0.25]: the last block(s) run above the frame resolution
+    (IFBlock up-samples its input by 1/scale and down-samples its output, rife_arch.py:237-276)."""
+    from cfi_amd.rife import run_tasks
+
+    frames = synth.smooth_frames(2, h, w, seed=8, shift=3.0)
+    tasks = [(0, 0.5), (0, 0.3)]
+    got = run_tasks(engine, frames, tasks, batch_size=2, scale_factor=sf)
+    x = frames.permute(0, 3, 1, 2)
+    ts = torch.tensor([0.5, 0.3]).view(-1, 1, 1, 1)
+    with torch.inference_mode():
+        want = rife_oracle.ifnet47_forward(sd, x[0:1].repeat(2, 1, 1, 1), x[1:2].repeat(2, 1, 1, 1), ts,
+                                           tuple(b / sf for b in (8.0, 4.0, 2.0, 1.0))).clamp(0, 1).permute(0, 2, 3, 1)
+    assert (got - want).abs().max().item() <= TOL, describe_diff(got, want, f"scale_factor {sf}")
 
 
 def test_full_size_1080p(engine, sd):
