@@ -49,13 +49,21 @@ struct ConvLayer {
 };
 
 const int kBlockC[4] = {192, 128, 96, 64};
-const int kBlockIn[4] = {15, 20, 20, 20};
 
 }  // namespace
 
 struct vfi_rife {
     ConvLayer conv00[4], conv01[4], res[4][8], last[4];
     DevBuf enc_w0, enc_b0, enc_w1, enc_b1;
+    // architecture: feature planes of the frame pack (4 channels each), width of the head, its activation / mid convs
+    //   4.7  : encode = Conv(3,16,s2) -> Deconv(16,4)                                   rife_arch.py:414-416
+    //   4.17 : Head_417 = Conv(3,32,s2) lrelu Conv(32,32) lrelu Conv(32,32) lrelu Deconv(32,8)   :355-375
+    int arch = 47, NF = 1, CM = 16, CF = 4, n_mid = 0;
+    bool enc_act = false;
+    ConvLayer enc_mid[2];
+    DevBuf E2;
+    int block_in(int i) const { return i == 0 ? 7 + 8 * NF : 12 + 8 * NF; }   // IFBlock in_planes, rife_arch.py:410-421
+    int CX(int i) const { return round_up(block_in(i), 8); }
     // geometry
     int H = 0, W = 0, Hp = 0, Wp = 0, max_batch = 0, n_slots = 0;
     int scales[4] = {8, 4, 2, 1};  // integer block scales (1 where the block scale is fractional)
@@ -66,7 +74,7 @@ struct vfi_rife {
     DevBuf Fdbg[4], Xdbg[4];
     bool keep = false;
     int last_B = 0;
-    size_t pack_stride() const { return (size_t)Hp * Wp * 8; }
+    size_t pack_stride() const { return (size_t)Hp * Wp * 4 * (1 + NF); }
 };
 
 static int make_conv3x3(ConvLayer& L, const float* w, const float* b, const float* beta, int Cout, int Cin,
@@ -104,16 +112,26 @@ static int make_conv3x3(ConvLayer& L, const float* w, const float* b, const floa
 extern "C" {
 
 vfi_rife_t* vfi_rife_create(int arch_ver_x10, const float* const* tensors, const int64_t* numels, int n_tensors) {
-    if (arch_ver_x10 != 47) {
-        set_error("vfi_rife_create: architecture %d.%d not implemented (4.7 = rife47/rife49 only)", arch_ver_x10 / 10,
-                  arch_ver_x10 % 10);
+    if (arch_ver_x10 != 47 && arch_ver_x10 != 417) {
+        set_error("vfi_rife_create: architecture code %d not implemented (47 = \"4.7\": rife47/rife49, 417 = \"4.17\": rife417)",
+                  arch_ver_x10);
         return nullptr;
     }
-    if (n_tensors != 124) {
-        set_error("vfi_rife_create: expected 124 state_dict tensors for arch 4.7, got %d", n_tensors);
+    const int want_tensors = arch_ver_x10 == 47 ? 124 : 128;
+    if (n_tensors != want_tensors) {
+        set_error("vfi_rife_create: expected %d state_dict tensors for architecture code %d, got %d", want_tensors, arch_ver_x10,
+                  n_tensors);
         return nullptr;
     }
     vfi_rife* net = new vfi_rife();
+    net->arch = arch_ver_x10;
+    if (arch_ver_x10 == 417) {
+        net->NF = 2;
+        net->CM = 32;
+        net->CF = 8;
+        net->n_mid = 2;
+        net->enc_act = true;
+    }
     int k = 0;
     auto next = [&](int64_t want) -> const float* {
         if (k >= n_tensors || numels[k] != want) {
@@ -125,7 +143,7 @@ vfi_rife_t* vfi_rife_create(int arch_ver_x10, const float* const* tensors, const
     };
     bool ok = true;
     for (int b = 0; b < 4 && ok; ++b) {
-        const int c = kBlockC[b], cin = kBlockIn[b];
+        const int c = kBlockC[b], cin = net->block_in(b);
         const int cin_p = round_up(cin, 8);
         const float* w = next((int64_t)(c / 2) * cin * 9);
         const float* bi = w ? next(c / 2) : nullptr;
@@ -155,20 +173,27 @@ vfi_rife_t* vfi_rife_create(int arch_ver_x10, const float* const* tensors, const
         }
     }
     if (ok) {
-        const float* w0 = next(16 * 3 * 9);
-        const float* b0 = w0 ? next(16) : nullptr;
-        const float* w1 = b0 ? next(16 * 4 * 16) : nullptr;
-        const float* b1 = w1 ? next(4) : nullptr;
-        ok = b1 != nullptr;
+        const int CM = net->CM, CF = net->CF;
+        const float* w0 = next((int64_t)CM * 3 * 9);
+        const float* b0 = w0 ? next(CM) : nullptr;
+        ok = b0 != nullptr;
+        for (int m = 0; m < net->n_mid && ok; ++m) {   // Head.cnn1 / cnn2: 3x3, LeakyReLU(0.2) applied at launch
+            const float* w = next((int64_t)CM * CM * 9);
+            const float* bi = w ? next(CM) : nullptr;
+            ok = bi && !make_conv3x3(net->enc_mid[m], w, bi, nullptr, CM, CM, CM);
+        }
+        const float* w1 = ok ? next((int64_t)CM * CF * 16) : nullptr;
+        const float* b1 = w1 ? next(CF) : nullptr;
+        ok = ok && b1 != nullptr;
         if (ok) {
-            std::vector<float> p0(9 * 48), p1(16 * 64);
-            for (int co = 0; co < 16; ++co)
+            std::vector<float> p0((size_t)9 * 3 * CM), p1((size_t)16 * CM * CF);
+            for (int co = 0; co < CM; ++co)
                 for (int ci = 0; ci < 3; ++ci)
-                    for (int t = 0; t < 9; ++t) p0[t * 48 + ci * 16 + co] = w0[(co * 3 + ci) * 9 + t];
-            for (int ci = 0; ci < 16; ++ci)
-                for (int co = 0; co < 4; ++co)
-                    for (int t = 0; t < 16; ++t) p1[(t * 16 + ci) * 4 + co] = w1[(ci * 4 + co) * 16 + t];
-            std::vector<float> vb0(b0, b0 + 16), vb1(b1, b1 + 4);
+                    for (int t = 0; t < 9; ++t) p0[((size_t)t * 3 + ci) * CM + co] = w0[(co * 3 + ci) * 9 + t];
+            for (int ci = 0; ci < CM; ++ci)
+                for (int co = 0; co < CF; ++co)
+                    for (int t = 0; t < 16; ++t) p1[((size_t)t * CM + ci) * CF + co] = w1[(ci * CF + co) * 16 + t];
+            std::vector<float> vb0(b0, b0 + CM), vb1(b1, b1 + CF);
             ok = !upload(net->enc_w0, p0) && !upload(net->enc_b0, vb0) && !upload(net->enc_w1, p1) &&
                  !upload(net->enc_b1, vb1);
         }
@@ -196,6 +221,11 @@ void vfi_rife_destroy(vfi_rife_t* net) {
         net->Fdbg[b].release();
         net->Xdbg[b].release();
     }
+    for (ConvLayer& L : net->enc_mid) {
+        L.w.release();
+        L.bias.release();
+    }
+    net->E2.release();
     for (DevBuf* d : {&net->enc_w0, &net->enc_b0, &net->enc_w1, &net->enc_b1, &net->Ppool, &net->E, &net->F, &net->M,
                       &net->X, &net->A0, &net->A1, &net->A2, &net->T, &net->X1, &net->T1})
         d->release();
@@ -233,7 +263,7 @@ int vfi_rife_configure(vfi_rife_t* net, int H, int W, int max_batch, int n_slots
                     "vfi_rife_configure: padded size %dx%d not divisible by 4*scale %d (the reference fails here too, "
                     "SURVEY.md App. C6)", Hp, Wp, sc[i]);
         // the block input of an up-scaled block is addressed with 32-bit element offsets
-        VFI_REQUIRE((double)Hp * Wp * up[i] * up[i] * 24 < 2147483647.0,
+        VFI_REQUIRE((double)Hp * Wp * up[i] * up[i] * net->CX(i) < 2147483647.0,
                     "vfi_rife_configure: %dx%d is too large for scale_factor %g (block input above 2^31 elements)", H, W,
                     scale_factor);
     }
@@ -249,27 +279,20 @@ int vfi_rife_configure(vfi_rife_t* net, int H, int W, int max_batch, int n_slots
     size_t x = 0, a0 = 0, a1 = 0, t = 0;
     for (int i = 0; i < 4; ++i) {
         const size_t px = full / ((size_t)sc[i] * sc[i]) * ((size_t)up[i] * up[i]);
-        const size_t cx = i == 0 ? 16 : 24;
+        const size_t cx = net->CX(i);
         x = std::max(x, px * cx);
         a0 = std::max(a0, px / 4 * (kBlockC[i] / 2));
         a1 = std::max(a1, px / 16 * kBlockC[i]);
         t = std::max(t, px * 8);
     }
     // T plane 1 holds only the mask (+1 unused channel): components 2,3 are never written; keep them defined
-    if (net->Ppool.ensure(full * 8 * n_slots) || net->E.ensure(full / 4 * 16) || net->F.ensure(B * full * 4) ||
+    if (net->Ppool.ensure(net->pack_stride() * n_slots) || net->E.ensure(full / 4 * net->CM) ||
+        (net->n_mid && net->E2.ensure(full / 4 * net->CM)) || net->F.ensure(B * full * 4) ||
         net->M.ensure(B * full) || net->X.ensure(B * x) || net->A0.ensure(B * a0) || net->A1.ensure(B * a1) ||
         net->A2.ensure(B * a1) || net->T.ensure(B * t))
         return -1;
-    if ((up[2] > 1 || up[3] > 1 || up[1] > 1) && (net->X1.ensure(B * full * 24) || net->T1.ensure(B * full * 8))) return -1;
+    if ((up[2] > 1 || up[3] > 1 || up[1] > 1) && (net->X1.ensure(B * full * net->CX(3)) || net->T1.ensure(B * full * 8))) return -1;
     return 0;
-}
-
-int vfi_rife_load_frame(vfi_rife_t* net, int slot, const float* frame_dev, int C, void* stream) {
-    VFI_REQUIRE(net && net->Hp > 0, "vfi_rife_load_frame: network not configured");
-    VFI_REQUIRE(slot >= 0 && slot < net->n_slots && C >= 3, "vfi_rife_load_frame: bad slot %d / channels %d", slot, C);
-    return prep_frame_launch(frame_dev, net->Ppool.p + (size_t)slot * net->pack_stride(), net->E.p, net->enc_w0.p,
-                             net->enc_b0.p, net->enc_w1.p, net->enc_b1.p, net->H, net->W, C, net->Hp, net->Wp,
-                             (hipStream_t)stream);
 }
 
 static void fill_args(ConvArgs& a, const ConvLayer& L, const float* in, int in_cs, float* out, int out_cs, int N,
@@ -289,6 +312,28 @@ static void fill_args(ConvArgs& a, const ConvLayer& L, const float* in, int in_c
     a.Cin_p = L.Cin_p;
     a.Cout_p = L.Cout_p;
     a.Cout = L.Cout;
+}
+
+int vfi_rife_load_frame(vfi_rife_t* net, int slot, const float* frame_dev, int C, void* stream) {
+    VFI_REQUIRE(net && net->Hp > 0, "vfi_rife_load_frame: network not configured");
+    VFI_REQUIRE(slot >= 0 && slot < net->n_slots && C >= 3, "vfi_rife_load_frame: bad slot %d / channels %d", slot, C);
+    hipStream_t st = (hipStream_t)stream;
+    float* P = net->Ppool.p + (size_t)slot * net->pack_stride();
+    const int Hp = net->Hp, Wp = net->Wp;
+    if (prep_frame_launch(frame_dev, P, net->H, net->W, C, Hp, Wp, st)) return -1;
+    if (encode_conv_launch(P, net->E.p, net->enc_w0.p, net->enc_b0.p, net->CM, net->enc_act, Hp, Wp, st)) return -1;
+    float* cur = net->E.p;
+    float* nxt = net->E2.p;
+    for (int m = 0; m < net->n_mid; ++m) {
+        ConvArgs a;
+        fill_args(a, net->enc_mid[m], cur, net->CM, nxt, net->CM, 1, Hp / 2, Wp / 2, 1);
+        conv3x3_taps(a);
+        a.act = 1;
+        a.slope = 0.2f;
+        if (conv_launch(a, 1, false, -1, st, "encode_mid")) return -1;
+        std::swap(cur, nxt);
+    }
+    return encode_deconv_launch(cur, P, net->enc_w1.p, net->enc_b1.p, net->CM, net->CF, Hp, Wp, st);
 }
 
 int vfi_rife_interpolate(vfi_rife_t* net, int B, const int* slot0, const int* slot1, const float* timestep,
@@ -316,15 +361,15 @@ int vfi_rife_interpolate(vfi_rife_t* net, int B, const int* slot0, const int* sl
         const int s = net->scales[i], u = net->up[i];
         const int Hs = Hp / s * u, Ws = Wp / s * u;
         const int c = kBlockC[i];
-        const int CX = i == 0 ? 16 : 24;
+        const int CX = net->CX(i), NF = net->NF;
         // X of this block: block 0 has no flow yet; later blocks get X from the fused transition kernel of the
         // previous iteration when the scale list allows it (standard [8,4,2,1]), else from stage_in.
         const bool x_ready = i > 0 && fused_prev;
         if (!x_ready &&
             stage_in_launch(net->Ppool.p, net->pack_stride(), tasks, B, net->F.p, net->M.p, u > 1 ? net->X1.p : net->X.p, Hp, Wp,
-                            s, CX, i > 0, st))
+                            s, CX, NF, i > 0, st))
             return -1;
-        if (u > 1 && planar4_up_launch(net->X1.p, net->X.p, B, Hp, Wp, u, CX, /*flow plane*/ 4, st)) return -1;
+        if (u > 1 && planar4_up_launch(net->X1.p, net->X.p, B, Hp, Wp, u, CX, /*flow plane*/ 2 + 2 * NF, st)) return -1;
         if (net->keep) {
             const size_t n = (size_t)B * Hs * Ws * CX;
             if (net->Xdbg[i].ensure(n)) return -1;
@@ -373,7 +418,7 @@ int vfi_rife_interpolate(vfi_rife_t* net, int B, const int* slot0, const int* sl
             fused_prev = u == 1 && net->up[i + 1] == 1 && s == 2 * sn && (sn == 4 || sn == 2 || sn == 1);
             if (fused_prev) {
                 if (stage_trans_launch(net->Ppool.p, net->pack_stride(), tasks, B, Tsrc, net->F.p, net->X.p, Hp, Wp,
-                                       s, sn, i > 0, st))
+                                       s, sn, NF, i > 0, st))
                     return -1;
             } else if (flow_up_launch(Tsrc, net->F.p, net->M.p, B, Hp, Wp, s, i > 0, st)) {
                 return -1;
@@ -419,7 +464,7 @@ int64_t vfi_rife_debug_read(vfi_rife_t* net, int what, int stage, float* host_bu
     } else if (what == 1 && stage >= 0 && stage < 4) {
         const int s = net->scales[stage], u = net->up[stage];
         src = net->Xdbg[stage].p;
-        n = (size_t)net->last_B * (net->Hp / s * u) * (net->Wp / s * u) * (stage == 0 ? 16 : 24);
+        n = (size_t)net->last_B * (net->Hp / s * u) * (net->Wp / s * u) * net->CX(stage);
     } else if (what == 2 && stage >= 0 && stage < net->n_slots) {
         src = net->Ppool.p + (size_t)stage * net->pack_stride();
         n = net->pack_stride();
@@ -443,13 +488,13 @@ int vfi_rife_work(vfi_rife_t* net, double* conv_flop_per_task, double* hbm_bytes
     for (int i = 0; i < 4; ++i) {
         const double px = full / ((double)net->scales[i] * net->scales[i]) * ((double)net->up[i] * net->up[i]);
         const double c = kBlockC[i];
-        mac += px / 4 * (c / 2) * kBlockIn[i] * 9;   // conv0.0
+        mac += px / 4 * (c / 2) * net->block_in(i) * 9;   // conv0.0
         mac += px / 16 * c * (c / 2) * 9;            // conv0.1
         mac += 8 * px / 16 * c * c * 9;              // ResConv x8
         mac += px / 16 * c * 24 * 16;                // ConvTranspose2d: in_numel * Cout * k*k
     }
     // encode, both frames of the pair (the reference recomputes it per task; rife_arch.py:501-503)
-    mac += 2 * (full / 4 * 16 * 3 * 9 + full / 4 * 16 * 4 * 16);
+    mac += 2 * (full / 4 * net->CM * 3 * 9 + net->n_mid * full / 4 * net->CM * net->CM * 9 + full / 4 * net->CM * net->CF * 16);
     if (conv_flop_per_task) *conv_flop_per_task = 2 * mac;
     if (hbm_bytes_per_task) {
         // 14 warps (8 of C=3, 6 of C=4): (2C+2)*4 B per pixel; 11 resizes in+out

@@ -12,13 +12,19 @@ struct RifeTasks {
 };
 
 int warp_border_launch(const float* in, const float* flow, float* out, int N, int H, int W, int C, hipStream_t s);
-int prep_frame_launch(const float* src, float* P, float* E, const float* w0, const float* b0, const float* w1,
-                      const float* b1, int H, int W, int C, int Hp, int Wp, hipStream_t s);
+int prep_frame_launch(const float* src, float* P, int H, int W, int C, int Hp, int Wp, hipStream_t s);
+// Head: first conv 3 -> CM (stride 2, optional LeakyReLU) into E [Hp/2][Wp/2][CM]; last layer CM -> CF transposed conv
+// into pack planes 1..CF/4.  (CM, CF, act) = (16, 4, false) for 4.7, (32, 8, true) for 4.17.
+int encode_conv_launch(const float* P, float* E, const float* w0, const float* b0, int CM, bool act, int Hp, int Wp,
+                       hipStream_t s);
+int encode_deconv_launch(const float* E, float* P, const float* w1, const float* b1, int CM, int CF, int Hp, int Wp,
+                         hipStream_t s);
+// NF = feature planes of the frame pack (1: 4 feature channels, 2: 8); CX = round_up(7 + 8*NF (+5 with flow), 8)
 int stage_in_launch(const float* Ppool, size_t pack_stride, const RifeTasks& tasks, int B, const float* F,
-                    const float* M, float* X, int Hp, int Wp, int s, int CX, bool has_flow, hipStream_t st);
+                    const float* M, float* X, int Hp, int Wp, int s, int CX, int NF, bool has_flow, hipStream_t st);
 int flow_up_launch(const float* T, float* F, float* M, int B, int Hp, int Wp, int s, bool has_prev, hipStream_t st);
 int stage_trans_launch(const float* Ppool, size_t pack_stride, const RifeTasks& tasks, int B, const float* T, float* F,
-                       float* X, int Hp, int Wp, int s_prev, int s_next, bool has_prev, hipStream_t st);
+                       float* X, int Hp, int Wp, int s_prev, int s_next, int NF, bool has_prev, hipStream_t st);
 int final_blend_launch(const float* Ppool, size_t pack_stride, const RifeTasks& tasks, int B, const float* T,
                        const float* F, float* out, float* Fdbg, int H, int W, int Hp, int Wp, int s, hipStream_t st);
 int planar4_up_launch(const float* X1, float* X, int B, int Hp, int Wp, int u, int CX, int flow_plane, hipStream_t st);

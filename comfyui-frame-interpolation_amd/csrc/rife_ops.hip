@@ -84,16 +84,31 @@ __device__ static inline float4 lerp4(const float4 a, const float4 b, const floa
     return r;
 }
 
-// Sample the frame pack: lo = plane 0 (rgb,0), hi = plane 1 (features) at offset hi_off floats.
-template <bool WANT_HI>
+// Sample the frame pack: lo = plane 0 (rgb,0), hi[j] = feature plane 1+j (plane stride hi_off floats).
+template <int NHI>
 __device__ static inline void sample_pack(const float* __restrict__ P, size_t hi_off, const Tap4& t, float4& lo,
-                                          float4& hi) {
+                                          float4* hi) {
     const float4* q = (const float4*)P;
     lo = lerp4(q[t.o00], q[t.o01], q[t.o10], q[t.o11], t);
-    if (WANT_HI) {
-        const float4* h = (const float4*)(P + hi_off);
-        hi = lerp4(h[t.o00], h[t.o01], h[t.o10], h[t.o11], t);
+#pragma unroll
+    for (int j = 0; j < NHI; ++j) {
+        const float4* h = (const float4*)(P + (size_t)(1 + j) * hi_off);
+        hi[j] = lerp4(h[t.o00], h[t.o01], h[t.o10], h[t.o11], t);
     }
+}
+// channel order of the reference's torch.cat: (img0 3, img1 3, f0 4*NF, f1 4*NF, timestep[, mask, flow 4])
+template <int NF>
+__device__ static inline void cat_inputs(float* o, const float4& a_lo, const float4& b_lo, const float4* a_hi, const float4* b_hi,
+                                         float tstep) {
+    o[0] = a_lo.x; o[1] = a_lo.y; o[2] = a_lo.z;
+    o[3] = b_lo.x; o[4] = b_lo.y; o[5] = b_lo.z;
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        o[6 + 4 * j] = a_hi[j].x; o[7 + 4 * j] = a_hi[j].y; o[8 + 4 * j] = a_hi[j].z; o[9 + 4 * j] = a_hi[j].w;
+        o[6 + 4 * NF + 4 * j] = b_hi[j].x; o[7 + 4 * NF + 4 * j] = b_hi[j].y;
+        o[8 + 4 * NF + 4 * j] = b_hi[j].z; o[9 + 4 * NF + 4 * j] = b_hi[j].w;
+    }
+    o[6 + 8 * NF] = tstep;
 }
 
 // generic NHWC warp (C arbitrary) — parity-test entry point and building block for other nodes
@@ -142,16 +157,19 @@ __global__ void prep_frame_kernel(const float* __restrict__ src, float* __restri
     *(float4*)(P + (size_t)idx * 4) = v;
 }
 
-// encode.0: Conv2d(3,16,3,stride 2,pad 1), no activation.   weights [tap][ci][co] (uniform -> SGPRs)
+// Head, first layer: Conv2d(3,CM,3,stride 2,pad 1) (+ LeakyReLU(0.2) for the Head / Head_417 variants).
+// weights [tap][ci][co] (uniform -> SGPRs).  4.7: encode.0 (CM 16, no activation) rife_arch.py:414-416;
+// 4.17: Head_417.cnn0 (CM 32) :355-375; 4.26: Head.cnn0 (CM 16) :378-398.
+template <int CM, bool ACT>
 __global__ void encode_conv_kernel(const float* __restrict__ P, const float* __restrict__ w,
                                    const float* __restrict__ bias, float* __restrict__ E, int Hp, int Wp) {
     const int He = Hp / 2, We = Wp / 2;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= He * We) return;
     const int x = idx % We, y = idx / We;
-    float acc[16];
+    float acc[CM];
 #pragma unroll
-    for (int co = 0; co < 16; ++co) acc[co] = 0.f;
+    for (int co = 0; co < CM; ++co) acc[co] = 0.f;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
         const int iy = 2 * y - 1 + ky;
@@ -160,32 +178,41 @@ __global__ void encode_conv_kernel(const float* __restrict__ P, const float* __r
             const int ix = 2 * x - 1 + kx;
             float4 v = {0.f, 0.f, 0.f, 0.f};
             if (iy >= 0 && iy < Hp && ix >= 0 && ix < Wp) v = *(const float4*)(P + ((size_t)iy * Wp + ix) * 4);
-            const float* wt = w + (ky * 3 + kx) * 48;
+            const float* wt = w + (ky * 3 + kx) * 3 * CM;
 #pragma unroll
-            for (int co = 0; co < 16; ++co)
-                acc[co] = fmaf(v.z, wt[32 + co], fmaf(v.y, wt[16 + co], fmaf(v.x, wt[co], acc[co])));
+            for (int co = 0; co < CM; ++co)
+                acc[co] = fmaf(v.z, wt[2 * CM + co], fmaf(v.y, wt[CM + co], fmaf(v.x, wt[co], acc[co])));
         }
     }
-    float4* o = (float4*)(E + (size_t)idx * 16);
+    float4* o = (float4*)(E + (size_t)idx * CM);
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-        o[q] = make_float4(acc[4 * q] + bias[4 * q], acc[4 * q + 1] + bias[4 * q + 1], acc[4 * q + 2] + bias[4 * q + 2],
-                           acc[4 * q + 3] + bias[4 * q + 3]);
+    for (int q = 0; q < CM / 4; ++q) {
+        float4 r = make_float4(acc[4 * q] + bias[4 * q], acc[4 * q + 1] + bias[4 * q + 1], acc[4 * q + 2] + bias[4 * q + 2],
+                               acc[4 * q + 3] + bias[4 * q + 3]);
+        if (ACT) {
+            r.x = r.x > 0.f ? r.x : r.x * 0.2f;
+            r.y = r.y > 0.f ? r.y : r.y * 0.2f;
+            r.z = r.z > 0.f ? r.z : r.z * 0.2f;
+            r.w = r.w > 0.f ? r.w : r.w * 0.2f;
+        }
+        o[q] = r;
+    }
 }
 
-// encode.1: ConvTranspose2d(16,4,4,stride 2,pad 1), no activation; one thread = one E pixel = a 2x2
-// output quad (all 4 parities).  weights [ky][kx][ci][co(4)]; result goes to pack plane 1.
+// Head, last layer: ConvTranspose2d(CM,CF,4,stride 2,pad 1), no activation; one thread = one E pixel = a 2x2
+// output quad (all 4 parities).  weights [ky][kx][ci][co(CF)]; result goes to pack planes 1..CF/4.
+template <int CM, int CF>
 __global__ void encode_deconv_kernel(const float* __restrict__ E, const float* __restrict__ w,
                                      const float* __restrict__ bias, float* __restrict__ P, int Hp, int Wp) {
     const int He = Hp / 2, We = Wp / 2;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= He * We) return;
     const int x = idx % We, y = idx / We;
-    float acc[4][4];
+    float acc[4][CF];
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int co = 0; co < 4; ++co) acc[g][co] = bias[co];
+        for (int co = 0; co < CF; ++co) acc[g][co] = bias[co];
 #pragma unroll
     for (int dy = -1; dy <= 1; ++dy) {
         const int iy = y + dy;
@@ -193,32 +220,28 @@ __global__ void encode_deconv_kernel(const float* __restrict__ E, const float* _
         for (int dx = -1; dx <= 1; ++dx) {
             const int ix = x + dx;
             const bool ok = iy >= 0 && iy < He && ix >= 0 && ix < We;
-            const float4* e = (const float4*)(E + ((size_t)(ok ? iy : y) * We + (ok ? ix : x)) * 16);
-            float ev[16];
+            const float4* e = (const float4*)(E + ((size_t)(ok ? iy : y) * We + (ok ? ix : x)) * CM);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < CM / 4; ++q) {   // 4 input channels at a time: keeps the live set small for CM = 32
                 float4 t = e[q];
                 if (!ok) t = make_float4(0.f, 0.f, 0.f, 0.f);
-                ev[4 * q] = t.x;
-                ev[4 * q + 1] = t.y;
-                ev[4 * q + 2] = t.z;
-                ev[4 * q + 3] = t.w;
-            }
-            // parity (py,px) uses input offset dy in {py-1, py} with ky = py + 1 - 2*dy
+                const float ev[4] = {t.x, t.y, t.z, t.w};
+                // parity (py,px) uses input offset dy in {py-1, py} with ky = py + 1 - 2*dy
 #pragma unroll
-            for (int py = 0; py < 2; ++py) {
-                if (dy < py - 1 || dy > py) continue;
-                const int ky = py + 1 - 2 * dy;
+                for (int py = 0; py < 2; ++py) {
+                    if (dy < py - 1 || dy > py) continue;
+                    const int ky = py + 1 - 2 * dy;
 #pragma unroll
-                for (int px = 0; px < 2; ++px) {
-                    if (dx < px - 1 || dx > px) continue;
-                    const int kx = px + 1 - 2 * dx;
-                    const float* wt = w + (ky * 4 + kx) * 64;
+                    for (int px = 0; px < 2; ++px) {
+                        if (dx < px - 1 || dx > px) continue;
+                        const int kx = px + 1 - 2 * dx;
+                        const float* wt = w + ((ky * 4 + kx) * CM + 4 * q) * CF;
 #pragma unroll
-                    for (int ci = 0; ci < 16; ++ci)
+                        for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
-                        for (int co = 0; co < 4; ++co)
-                            acc[py * 2 + px][co] = fmaf(ev[ci], wt[ci * 4 + co], acc[py * 2 + px][co]);
+                            for (int co = 0; co < CF; ++co)
+                                acc[py * 2 + px][co] = fmaf(ev[ci], wt[ci * CF + co], acc[py * 2 + px][co]);
+                    }
                 }
             }
         }
@@ -226,27 +249,47 @@ __global__ void encode_deconv_kernel(const float* __restrict__ E, const float* _
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int Y = 2 * y + (g >> 1), X = 2 * x + (g & 1);
-        *(float4*)(P + (size_t)Hp * Wp * 4 + ((size_t)Y * Wp + X) * 4) = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
+#pragma unroll
+        for (int q = 0; q < CF / 4; ++q)
+            *(float4*)(P + (size_t)(1 + q) * Hp * Wp * 4 + ((size_t)Y * Wp + X) * 4) =
+                make_float4(acc[g][4 * q], acc[g][4 * q + 1], acc[g][4 * q + 2], acc[g][4 * q + 3]);
     }
 }
 
-int prep_frame_launch(const float* src, float* P, float* E, const float* w0, const float* b0, const float* w1,
-                      const float* b1, int H, int W, int C, int Hp, int Wp, hipStream_t s) {
-    {
-        TraceScope ts("prep_frame", s);
-        hipLaunchKernelGGL(prep_frame_kernel, dim3(cdiv(Hp * Wp, 256)), dim3(256), 0, s, src, P, H, W, C, Hp, Wp);
-        VFI_CHECK_HIP(hipGetLastError());
-    }
-    {
-        TraceScope ts("encode_conv", s);
-        hipLaunchKernelGGL(encode_conv_kernel, dim3(cdiv(Hp / 2 * (Wp / 2), 128)), dim3(128), 0, s, P, w0, b0, E, Hp, Wp);
-        VFI_CHECK_HIP(hipGetLastError());
-    }
-    {
-        TraceScope ts("encode_deconv", s);
-        hipLaunchKernelGGL(encode_deconv_kernel, dim3(cdiv(Hp / 2 * (Wp / 2), 128)), dim3(128), 0, s, E, w1, b1, P, Hp, Wp);
-        VFI_CHECK_HIP(hipGetLastError());
-    }
+int prep_frame_launch(const float* src, float* P, int H, int W, int C, int Hp, int Wp, hipStream_t s) {
+    TraceScope ts("prep_frame", s);
+    hipLaunchKernelGGL(prep_frame_kernel, dim3(cdiv(Hp * Wp, 256)), dim3(256), 0, s, src, P, H, W, C, Hp, Wp);
+    VFI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int encode_conv_launch(const float* P, float* E, const float* w0, const float* b0, int CM, bool act, int Hp, int Wp,
+                       hipStream_t s) {
+    TraceScope ts("encode_conv", s);
+    const dim3 grid(cdiv(Hp / 2 * (Wp / 2), 128));
+    if (CM == 16 && !act)
+        hipLaunchKernelGGL((encode_conv_kernel<16, false>), grid, dim3(128), 0, s, P, w0, b0, E, Hp, Wp);
+    else if (CM == 16 && act)
+        hipLaunchKernelGGL((encode_conv_kernel<16, true>), grid, dim3(128), 0, s, P, w0, b0, E, Hp, Wp);
+    else if (CM == 32 && act)
+        hipLaunchKernelGGL((encode_conv_kernel<32, true>), grid, dim3(128), 0, s, P, w0, b0, E, Hp, Wp);
+    else
+        VFI_REQUIRE(false, "encode_conv: unsupported head (CM=%d act=%d)", CM, (int)act);
+    VFI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int encode_deconv_launch(const float* E, float* P, const float* w1, const float* b1, int CM, int CF, int Hp, int Wp,
+                         hipStream_t s) {
+    TraceScope ts("encode_deconv", s);
+    const dim3 grid(cdiv(Hp / 2 * (Wp / 2), 128));
+    if (CM == 16 && CF == 4)
+        hipLaunchKernelGGL((encode_deconv_kernel<16, 4>), grid, dim3(128), 0, s, E, w1, b1, P, Hp, Wp);
+    else if (CM == 32 && CF == 8)
+        hipLaunchKernelGGL((encode_deconv_kernel<32, 8>), grid, dim3(128), 0, s, E, w1, b1, P, Hp, Wp);
+    else
+        VFI_REQUIRE(false, "encode_deconv: unsupported head (CM=%d CF=%d)", CM, CF);
+    VFI_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
@@ -255,7 +298,7 @@ int prep_frame_launch(const float* src, float* P, float* E, const float* w0, con
 // Down-resizing by an even integer s with align_corners=False samples exactly the centre 2x2 of
 // every s x s cell with weights 1/2, so only those pixels are warped at all.
 // ---------------------------------------------------------------------------------------
-template <bool HAS_FLOW, int NP>
+template <bool HAS_FLOW, int NP, int NF>
 __global__ __launch_bounds__(128) void stage_in_kernel(const float* __restrict__ Ppool, size_t pack_stride,
                                                        RifeTasks tasks, const float* __restrict__ F,
                                                        const float* __restrict__ M, float* __restrict__ Xo, int Hp,
@@ -272,26 +315,28 @@ __global__ __launch_bounds__(128) void stage_in_kernel(const float* __restrict__
     const WarpGeo g = make_warp_geo(Wp, Hp);
     const int off = NP == 1 ? 0 : s / 2 - 1;
     const float inv_s = 1.0f / (float)s;
-    constexpr int NC = HAS_FLOW ? 20 : 15;
+    constexpr int NI = 7 + 8 * NF;               // images + features + timestep
+    constexpr int NC = HAS_FLOW ? NI + 5 : NI;   // + mask + flow
+    constexpr int NR = (NC + 7) / 8 * 8;         // X channels (zero padded)
 
     // torch upsample_bilinear2d order: wy0*(wx0*a + wx1*b) + wy1*(wx0*c + wx1*d), all weights 0.5
-    float r[24], row[NC], o[NC];
+    float r[NR], row[NC], o[NC];
 #pragma unroll
-    for (int c = 0; c < 24; ++c) r[c] = 0.f;
+    for (int c = 0; c < NR; ++c) r[c] = 0.f;
 #pragma unroll 1
     for (int k = 0; k < NP * NP; ++k) {  // rolled on purpose: keeps the gather's register footprint small
         const int dy = k / NP, dx = k % NP;
         {
             const int Y = yl * s + off + dy, X = xl * s + off + dx;
             const size_t p = (size_t)Y * Wp + X;
-            float4 a_lo, a_hi, b_lo, b_hi;
+            float4 a_lo, b_lo, a_hi[NF], b_hi[NF];
             if (HAS_FLOW) {
                 const size_t pb = (size_t)b * Hp * Wp + p;
                 const float4 f = ((const float4*)F)[pb];
                 const Tap4 t0 = warp_taps(g, X, Y, f.x, f.y);
                 const Tap4 t1 = warp_taps(g, X, Y, f.z, f.w);
-                sample_pack<true>(P0, hi_off, t0, a_lo, a_hi);
-                sample_pack<true>(P1, hi_off, t1, b_lo, b_hi);
+                sample_pack<NF>(P0, hi_off, t0, a_lo, a_hi);
+                sample_pack<NF>(P1, hi_off, t1, b_lo, b_hi);
                 o[NC - 5] = M[pb];
                 o[NC - 4] = f.x;
                 o[NC - 3] = f.y;
@@ -299,15 +344,14 @@ __global__ __launch_bounds__(128) void stage_in_kernel(const float* __restrict__
                 o[NC - 1] = f.w;
             } else {
                 a_lo = ((const float4*)P0)[p];
-                a_hi = ((const float4*)(P0 + hi_off))[p];
                 b_lo = ((const float4*)P1)[p];
-                b_hi = ((const float4*)(P1 + hi_off))[p];
+#pragma unroll
+                for (int j = 0; j < NF; ++j) {
+                    a_hi[j] = ((const float4*)(P0 + (size_t)(1 + j) * hi_off))[p];
+                    b_hi[j] = ((const float4*)(P1 + (size_t)(1 + j) * hi_off))[p];
+                }
             }
-            o[0] = a_lo.x; o[1] = a_lo.y; o[2] = a_lo.z;
-            o[3] = b_lo.x; o[4] = b_lo.y; o[5] = b_lo.z;
-            o[6] = a_hi.x; o[7] = a_hi.y; o[8] = a_hi.z; o[9] = a_hi.w;
-            o[10] = b_hi.x; o[11] = b_hi.y; o[12] = b_hi.z; o[13] = b_hi.w;
-            o[14] = tstep;
+            cat_inputs<NF>(o, a_lo, b_lo, a_hi, b_hi, tstep);
 #pragma unroll
             for (int c = 0; c < NC; ++c) row[c] = dx == 0 ? o[c] : __fadd_rn(0.5f * row[c], 0.5f * o[c]);
         }
@@ -318,28 +362,32 @@ __global__ __launch_bounds__(128) void stage_in_kernel(const float* __restrict__
     }
     if (HAS_FLOW) {
 #pragma unroll
-        for (int c = 16; c < 20; ++c) r[c] = r[c] * inv_s;  // interpolate(flow) * 1.0 / scale
+        for (int c = NC - 4; c < NC; ++c) r[c] = r[c] * inv_s;  // interpolate(flow) * 1.0 / scale
     }
     float4* op = (float4*)Xo + (size_t)b * (CX / 4) * Hs * Ws + idx;
 #pragma unroll
-    for (int q = 0; q < 6; ++q)
+    for (int q = 0; q < NR / 4; ++q)
         if (q < CX / 4) op[(size_t)q * Hs * Ws] = make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
 }
 
 int stage_in_launch(const float* Ppool, size_t pack_stride, const RifeTasks& tasks, int B, const float* F,
-                    const float* M, float* X, int Hp, int Wp, int s, int CX, bool has_flow, hipStream_t st) {
+                    const float* M, float* X, int Hp, int Wp, int s, int CX, int NF, bool has_flow, hipStream_t st) {
     const int Hs = Hp / s, Ws = Wp / s;
     VFI_REQUIRE(s == 1 || s % 2 == 0, "stage_in: scale %d must be 1 or even", s);
-    VFI_REQUIRE(CX % 4 == 0 && CX >= (has_flow ? 20 : 16) && CX <= 24, "stage_in: bad CX %d", CX);
+    VFI_REQUIRE((NF == 1 || NF == 2) && CX == round_up(7 + 8 * NF + (has_flow ? 5 : 0), 8), "stage_in: bad CX %d for %d feature planes",
+                CX, NF);
     dim3 grid(cdiv(Hs * Ws, 128), B);
     TraceScope ts(has_flow ? "stage_in_warp" : "stage_in0", st);
-#define VFI_SI(HF, NPV) \
-    hipLaunchKernelGGL((stage_in_kernel<HF, NPV>), grid, dim3(128), 0, st, Ppool, pack_stride, tasks, F, M, X, Hp, Wp, s, CX)
+#define VFI_SI(HF, NPV, NFV) \
+    hipLaunchKernelGGL((stage_in_kernel<HF, NPV, NFV>), grid, dim3(128), 0, st, Ppool, pack_stride, tasks, F, M, X, Hp, Wp, s, CX)
+#define VFI_SI2(HF, NPV) \
+    do { if (NF == 1) VFI_SI(HF, NPV, 1); else VFI_SI(HF, NPV, 2); } while (0)
     if (has_flow) {
-        if (s == 1) VFI_SI(true, 1); else VFI_SI(true, 2);
+        if (s == 1) VFI_SI2(true, 1); else VFI_SI2(true, 2);
     } else {
-        if (s == 1) VFI_SI(false, 1); else VFI_SI(false, 2);
+        if (s == 1) VFI_SI2(false, 1); else VFI_SI2(false, 2);
     }
+#undef VFI_SI2
 #undef VFI_SI
     VFI_CHECK_HIP(hipGetLastError());
     return 0;
@@ -445,7 +493,7 @@ int flow_up_launch(const float* T, float* F, float* M, int B, int Hp, int Wp, in
 // once per thread; the mask never goes to memory and the flow is read+written exactly once.
 // Thread blocks are 16x16 cells (2-D) so that warp taps of vertically adjacent pixels share L2 lines.
 // ---------------------------------------------------------------------------------------
-template <int SP, bool HAS_PREV>
+template <int SP, bool HAS_PREV, int NF>
 __global__ __launch_bounds__(256) void stage_trans_kernel(const float* __restrict__ Ppool, size_t pack_stride,
                                                           RifeTasks tasks, const float* __restrict__ T,
                                                           float* __restrict__ F, float* __restrict__ Xo, int Hp,
@@ -495,9 +543,11 @@ __global__ __launch_bounds__(256) void stage_trans_kernel(const float* __restric
     const size_t hi_off = (size_t)Hp * Wp * 4;
     const float tstep = tasks.t[b];
     const WarpGeo g = make_warp_geo(Wp, Hp);
-    float r[24], row[20], o[20];
+    constexpr int NC = 12 + 8 * NF;          // images, features, timestep, mask, flow
+    constexpr int NR = (NC + 7) / 8 * 8;     // X channels (zero padded)
+    float r[NR], row[NC], o[NC];
 #pragma unroll
-    for (int c = 0; c < 24; ++c) r[c] = 0.f;
+    for (int c = 0; c < NR; ++c) r[c] = 0.f;
 #pragma unroll 1
     for (int k = 0; k < NP * NP; ++k) {  // rolled on purpose (register footprint of the gathers)
         const int dy = k / NP, dx = k % NP;
@@ -513,48 +563,47 @@ __global__ __launch_bounds__(256) void stage_trans_kernel(const float* __restric
         const int Y = yl * SP + OFF + dy, X = xl * SP + OFF + dx;
         const Tap4 t0 = warp_taps(g, X, Y, f.x, f.y);
         const Tap4 t1 = warp_taps(g, X, Y, f.z, f.w);
-        float4 a_lo, a_hi, b_lo, b_hi;
-        sample_pack<true>(P0, hi_off, t0, a_lo, a_hi);
-        sample_pack<true>(P1, hi_off, t1, b_lo, b_hi);
-        o[0] = a_lo.x; o[1] = a_lo.y; o[2] = a_lo.z;
-        o[3] = b_lo.x; o[4] = b_lo.y; o[5] = b_lo.z;
-        o[6] = a_hi.x; o[7] = a_hi.y; o[8] = a_hi.z; o[9] = a_hi.w;
-        o[10] = b_hi.x; o[11] = b_hi.y; o[12] = b_hi.z; o[13] = b_hi.w;
-        o[14] = tstep;
-        o[15] = m;
-        o[16] = f.x; o[17] = f.y; o[18] = f.z; o[19] = f.w;
+        float4 a_lo, b_lo, a_hi[NF], b_hi[NF];
+        sample_pack<NF>(P0, hi_off, t0, a_lo, a_hi);
+        sample_pack<NF>(P1, hi_off, t1, b_lo, b_hi);
+        cat_inputs<NF>(o, a_lo, b_lo, a_hi, b_hi, tstep);
+        o[NC - 5] = m;
+        o[NC - 4] = f.x; o[NC - 3] = f.y; o[NC - 2] = f.z; o[NC - 1] = f.w;
 #pragma unroll
-        for (int c = 0; c < 20; ++c) row[c] = dx == 0 ? o[c] : __fadd_rn(0.5f * row[c], 0.5f * o[c]);
+        for (int c = 0; c < NC; ++c) row[c] = dx == 0 ? o[c] : __fadd_rn(0.5f * row[c], 0.5f * o[c]);
         if (dx == NP - 1) {
 #pragma unroll
-            for (int c = 0; c < 20; ++c) r[c] = dy == 0 ? row[c] : __fadd_rn(0.5f * r[c], 0.5f * row[c]);
+            for (int c = 0; c < NC; ++c) r[c] = dy == 0 ? row[c] : __fadd_rn(0.5f * r[c], 0.5f * row[c]);
         }
     }
     const float inv_s = 1.0f / (float)SP;
 #pragma unroll
-    for (int c = 16; c < 20; ++c) r[c] = r[c] * inv_s;  // interpolate(flow) * 1.0 / scale
-    float4* op = (float4*)Xo + (size_t)b * 6 * Hs * Ws + (size_t)yl * Ws + xl;
+    for (int c = NC - 4; c < NC; ++c) r[c] = r[c] * inv_s;  // interpolate(flow) * 1.0 / scale
+    float4* op = (float4*)Xo + (size_t)b * (NR / 4) * Hs * Ws + (size_t)yl * Ws + xl;
 #pragma unroll
-    for (int q = 0; q < 6; ++q) op[(size_t)q * Hs * Ws] = make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
+    for (int q = 0; q < NR / 4; ++q) op[(size_t)q * Hs * Ws] = make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
 }
 
 int stage_trans_launch(const float* Ppool, size_t pack_stride, const RifeTasks& tasks, int B, const float* T, float* F,
-                       float* X, int Hp, int Wp, int s_prev, int s_next, bool has_prev, hipStream_t st) {
-    VFI_REQUIRE(s_prev == 2 * s_next && (s_next == 4 || s_next == 2 || s_next == 1),
-                "stage_trans: scales %d -> %d not on the fused path", s_prev, s_next);
+                       float* X, int Hp, int Wp, int s_prev, int s_next, int NF, bool has_prev, hipStream_t st) {
+    VFI_REQUIRE(s_prev == 2 * s_next && (s_next == 4 || s_next == 2 || s_next == 1) && (NF == 1 || NF == 2),
+                "stage_trans: scales %d -> %d (%d feature planes) not on the fused path", s_prev, s_next, NF);
     const int Hs = Hp / s_next, Ws = Wp / s_next;
     const int tiles_x = cdiv(Ws, 16), tiles_y = cdiv(Hs, 16);
     dim3 grid(tiles_x * tiles_y, B);
     TraceScope ts("stage_trans", st);
-#define VFI_ST(SPV, HP) \
-    hipLaunchKernelGGL((stage_trans_kernel<SPV, HP>), grid, dim3(256), 0, st, Ppool, pack_stride, tasks, T, F, X, Hp, Wp, tiles_x)
+#define VFI_ST(SPV, HP, NFV) \
+    hipLaunchKernelGGL((stage_trans_kernel<SPV, HP, NFV>), grid, dim3(256), 0, st, Ppool, pack_stride, tasks, T, F, X, Hp, Wp, tiles_x)
+#define VFI_ST2(SPV, HP) \
+    do { if (NF == 1) VFI_ST(SPV, HP, 1); else VFI_ST(SPV, HP, 2); } while (0)
     if (s_next == 4) {
-        if (has_prev) VFI_ST(4, true); else VFI_ST(4, false);
+        if (has_prev) VFI_ST2(4, true); else VFI_ST2(4, false);
     } else if (s_next == 2) {
-        if (has_prev) VFI_ST(2, true); else VFI_ST(2, false);
+        if (has_prev) VFI_ST2(2, true); else VFI_ST2(2, false);
     } else {
-        if (has_prev) VFI_ST(1, true); else VFI_ST(1, false);
+        if (has_prev) VFI_ST2(1, true); else VFI_ST2(1, false);
     }
+#undef VFI_ST2
 #undef VFI_ST
     VFI_CHECK_HIP(hipGetLastError());
     return 0;
@@ -583,9 +632,9 @@ __global__ void final_blend_kernel(const float* __restrict__ Ppool, size_t pack_
     const WarpGeo g = make_warp_geo(Wp, Hp);
     const Tap4 t0 = warp_taps(g, X, Y, f.x, f.y);
     const Tap4 t1 = warp_taps(g, X, Y, f.z, f.w);
-    float4 a, bb, unused;
-    sample_pack<false>(Ppool + (size_t)tasks.slot0[b] * pack_stride, 0, t0, a, unused);
-    sample_pack<false>(Ppool + (size_t)tasks.slot1[b] * pack_stride, 0, t1, bb, unused);
+    float4 a, bb;
+    sample_pack<0>(Ppool + (size_t)tasks.slot0[b] * pack_stride, 0, t0, a, nullptr);
+    sample_pack<0>(Ppool + (size_t)tasks.slot1[b] * pack_stride, 0, t1, bb, nullptr);
     const float m = 1.0f / (1.0f + expf(-tv.m));
     const float om = 1.0f - m;
     float* op = out + ((size_t)b * H * W + idx) * 3;

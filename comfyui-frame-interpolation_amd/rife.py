@@ -23,7 +23,7 @@ from packaging import version
 from . import _lib
 from .ckpt import load_file_from_github_release
 from .dist import all_gather_frames, world
-from .rife_spec import CKPT_NAME_VER_DICT, SUPPORTED_ARCH, check_state_dict, rife47_keys
+from .rife_spec import ARCH_CODE, CKPT_NAME_VER_DICT, SUPPORTED_ARCH, check_state_dict, rife_shapes
 from .schedule import InterpolationStateList, rife_output_plan, rife_task_list, shard_tasks
 
 MODEL_TYPE = "rife"
@@ -32,7 +32,7 @@ MAX_LIB_BATCH = 16  # kMaxTasks in csrc/rife_ops.h
 
 
 class RifeEngine:
-    """Device-resident RIFE 4.7 network + frame cache behind the C ABI."""
+    """Device-resident RIFE network (arch 4.7 = rife47/rife49, 4.17 = rife417) + frame cache behind the C ABI."""
 
     def __init__(self, state_dict, arch_ver="4.7", device=None):
         if arch_ver not in SUPPORTED_ARCH:
@@ -43,12 +43,13 @@ class RifeEngine:
         self.lib = _lib.load()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         _lib.check(self.lib.vfi_init(self.device.index or 0), "vfi_init")
-        check_state_dict(state_dict)
-        keys = rife47_keys()
+        check_state_dict(state_dict, arch_ver)
+        self.arch_ver = arch_ver
+        keys = list(rife_shapes(arch_ver).keys())
         tensors = [state_dict[k].detach().to("cpu", torch.float32).contiguous() for k in keys]
         ptrs = (C.c_void_p * len(keys))(*[t.data_ptr() for t in tensors])
         numels = (C.c_int64 * len(keys))(*[t.numel() for t in tensors])
-        self.handle = self.lib.vfi_rife_create(47, ptrs, numels, len(keys))
+        self.handle = self.lib.vfi_rife_create(ARCH_CODE[arch_ver], ptrs, numels, len(keys))
         if not self.handle:
             raise RuntimeError("vfi_rife_create failed: " + _lib.last_error())
         self.cfg = None

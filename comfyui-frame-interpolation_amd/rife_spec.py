@@ -22,7 +22,9 @@ CKPT_NAME_VER_DICT = {
     "sudo_rife4_269.662_testV1_scale1.pth": "4.0",
 }
 # architectures the HIP path implements so far
-SUPPORTED_ARCH = ("4.7",)
+SUPPORTED_ARCH = ("4.7", "4.17")
+# architecture -> code handed to vfi_rife_create
+ARCH_CODE = {"4.7": 47, "4.17": 417}
 
 # (in_planes, c) per IFBlock, rife_arch.py:410-413
 RIFE47_BLOCKS = ((7 + 8, 192), (8 + 4 + 8, 128), (8 + 4 + 8, 96), (8 + 4 + 8, 64))
@@ -30,10 +32,8 @@ N_RESCONV = 8
 LASTCONV_OUT = 4 * 6  # ConvTranspose2d(c, 4*6, 4, 2, 1) + PixelShuffle(2), rife_arch.py:215-218
 
 
-def rife47_shapes():
-    """OrderedDict key -> shape, in reference ``state_dict`` order (124 tensors)."""
-    d = OrderedDict()
-    for b, (cin, c) in enumerate(RIFE47_BLOCKS):
+def _block_shapes(d, blocks):
+    for b, (cin, c) in enumerate(blocks):
         p = f"block{b}."
         d[p + "conv0.0.0.weight"] = (c // 2, cin, 3, 3)
         d[p + "conv0.0.0.bias"] = (c // 2,)
@@ -46,6 +46,12 @@ def rife47_shapes():
             d[q + "conv.bias"] = (c,)
         d[p + "lastconv.0.weight"] = (c, LASTCONV_OUT, 4, 4)
         d[p + "lastconv.0.bias"] = (LASTCONV_OUT,)
+
+
+def rife47_shapes():
+    """OrderedDict key -> shape, in reference ``state_dict`` order (124 tensors)."""
+    d = OrderedDict()
+    _block_shapes(d, RIFE47_BLOCKS)
     d["encode.0.weight"] = (16, 3, 3, 3)
     d["encode.0.bias"] = (16,)
     d["encode.1.weight"] = (16, 4, 4, 4)
@@ -53,18 +59,38 @@ def rife47_shapes():
     return d
 
 
+# rife_arch.py:417-421 (IFNet.__init__, arch "4.17") + Head_417 :355-375
+RIFE417_BLOCKS = ((7 + 16, 192), (8 + 4 + 16, 128), (8 + 4 + 16, 96), (8 + 4 + 16, 64))
+
+
+def rife417_shapes():
+    """rife417.pth: same IFBlocks with 8 feature channels per frame, encoder = Head_417 (128 tensors)."""
+    d = OrderedDict()
+    _block_shapes(d, RIFE417_BLOCKS)
+    for i, (co, ci) in enumerate(((32, 3), (32, 32), (32, 32))):
+        d[f"encode.cnn{i}.weight"] = (co, ci, 3, 3)
+        d[f"encode.cnn{i}.bias"] = (co,)
+    d["encode.cnn3.weight"] = (32, 8, 4, 4)
+    d["encode.cnn3.bias"] = (8,)
+    return d
+
+
+def rife_shapes(arch_ver="4.7"):
+    return {"4.7": rife47_shapes, "4.17": rife417_shapes}[arch_ver]()
+
+
 def rife47_keys():
     return list(rife47_shapes().keys())
 
 
-def check_state_dict(sd):
+def check_state_dict(sd, arch_ver="4.7"):
     """Strict key/shape check, same failure mode as ``load_state_dict(strict=True)``."""
-    want = rife47_shapes()
+    want = rife_shapes(arch_ver)
     missing = [k for k in want if k not in sd]
     unexpected = [k for k in sd if k not in want]
     if missing or unexpected:
         raise RuntimeError(
-            "Error(s) in loading state_dict for IFNet(4.7): "
+            f"Error(s) in loading state_dict for IFNet({arch_ver}): "
             f"Missing key(s): {missing}. Unexpected key(s): {unexpected}.")
     for k, shp in want.items():
         if tuple(sd[k].shape) != tuple(shp):

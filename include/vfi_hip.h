@@ -176,12 +176,13 @@ int vfi_m2m_combine(const float* splat_dev, const float* d0_dev, int d0_cs, cons
 typedef struct vfi_rife vfi_rife_t;
 
 /* Build the device-resident network from a reference checkpoint.
- * `tensors[i]` are host pointers to the state_dict tensors in the key order of
- * rife_spec.rife47_keys() (== torch state_dict order of IFNet("4.7")), each in the
- * reference's own layout; `numels[i]` their element counts (checked).
- * Replaces IFNet(arch_ver).load_state_dict(torch.load(path)) + .to(device),
+ * arch_ver_x10: 47 = architecture "4.7" (rife47.pth / rife49.pth, 124 tensors), 417 = "4.17" (rife417.pth, 128
+ * tensors: same IFBlocks on 8 feature channels per frame, encoder Head_417, rife_arch.py:355-375,417-433).
+ * `tensors[i]` are host pointers to the state_dict tensors in the key order of rife_spec.rife_shapes(arch)
+ * (== torch state_dict order of IFNet(arch)), each in the reference's own layout; `numels[i]` their element
+ * counts (checked).  Replaces IFNet(arch_ver).load_state_dict(torch.load(path)) + .to(device),
  * vfi_models/rife/__init__.py:129-135. */
-vfi_rife_t* vfi_rife_create(int arch_ver_x10 /* 47 */, const float* const* tensors,
+vfi_rife_t* vfi_rife_create(int arch_ver_x10 /* 47 | 417 */, const float* const* tensors,
                             const int64_t* numels, int n_tensors);
 void vfi_rife_destroy(vfi_rife_t* net);
 

@@ -73,10 +73,20 @@ def encode(sd, img):
     return F.conv_transpose2d(e, sd["encode.1.weight"], sd["encode.1.bias"], 2, 1)
 
 
-def ifnet47_forward(sd, img0, img1, timestep, scale_list=(8, 4, 2, 1), return_aux=False):
-    """rife_arch.py:465-732, arch "4.7", ensemble=False (the only path the node reaches, App. C1).
+def encode417(sd, img):
+    """Head_417.forward, rife_arch.py:355-375: Conv(3,32,s2) lrelu Conv(32,32) lrelu Conv(32,32) lrelu Deconv(32,8)"""
+    x = F.leaky_relu(F.conv2d(img, sd["encode.cnn0.weight"], sd["encode.cnn0.bias"], 2, 1), 0.2)
+    x = F.leaky_relu(F.conv2d(x, sd["encode.cnn1.weight"], sd["encode.cnn1.bias"], 1, 1), 0.2)
+    x = F.leaky_relu(F.conv2d(x, sd["encode.cnn2.weight"], sd["encode.cnn2.bias"], 1, 1), 0.2)
+    return F.conv_transpose2d(x, sd["encode.cnn3.weight"], sd["encode.cnn3.bias"], 2, 1)
+
+
+def ifnet47_forward(sd, img0, img1, timestep, scale_list=(8, 4, 2, 1), return_aux=False, arch="4.7"):
+    """rife_arch.py:465-732, arch "4.7" / "4.17" (same live path :501-503,543-548,629-645,698-705 — they differ in the
+    encoder and the channel counts only), ensemble=False (the only path the node reaches, App. C1).
 
     img0/img1: [B,3,H,W] f32;  timestep: [B,1,1,1] tensor.  Returns [B,3,H,W]."""
+    enc = {"4.7": encode, "4.17": encode417}[arch]
     img0 = torch.clamp(img0, 0, 1)
     img1 = torch.clamp(img1, 0, 1)
     n, c, h, w = img0.shape
@@ -86,8 +96,8 @@ def ifnet47_forward(sd, img0, img1, timestep, scale_list=(8, 4, 2, 1), return_au
     img0 = F.pad(img0, padding)
     img1 = F.pad(img1, padding)
     timestep = timestep.repeat(1, 1, img0.shape[2], img0.shape[3])
-    f0 = encode(sd, img0[:, :3])
-    f1 = encode(sd, img1[:, :3])
+    f0 = enc(sd, img0[:, :3])
+    f1 = enc(sd, img1[:, :3])
     warped_img0, warped_img1 = img0, img1
     flow = None
     mask = None
@@ -141,7 +151,7 @@ def rife_tasks(n_frames, multiplier, states=None):
     return multipliers, tasks
 
 
-def rife_vfi(sd, frames, multiplier=2, scale_factor=1.0, batch_size=1, states=None):
+def rife_vfi(sd, frames, multiplier=2, scale_factor=1.0, batch_size=1, states=None, arch="4.7"):
     """Whole-node oracle: frames [N,H,W,C] f32 CPU -> [N_out,H,W,3] f32 CPU."""
     x = frames[..., :3].permute(0, 3, 1, 2)  # preprocess_frames, vfi_utils.py:139-140
     n_pairs = len(x) - 1
@@ -155,7 +165,7 @@ def rife_vfi(sd, frames, multiplier=2, scale_factor=1.0, batch_size=1, states=No
             f0 = torch.cat([x[p : p + 1] for p, _ in bt], 0).to(torch.float32)
             f1 = torch.cat([x[p + 1 : p + 2] for p, _ in bt], 0).to(torch.float32)
             ts = torch.tensor([t for _, t in bt], dtype=torch.float32).view(-1, 1, 1, 1)
-            mid = ifnet47_forward(sd, f0, f1, ts, scale_list).clamp(0, 1)
+            mid = ifnet47_forward(sd, f0, f1, ts, scale_list, arch=arch).clamp(0, 1)
             for i, (p, _) in enumerate(bt):
                 results[p].append(mid[i : i + 1])
             pos += len(bt)

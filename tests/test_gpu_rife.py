@@ -246,3 +246,95 @@ def test_config3_rife49_4k_x4(hip_lib, sd, tmp_path, monkeypatch):
     assert out.shape == (5, 2160, 3840, 3) and torch.equal(out[0], frames[0]) and torch.equal(out[4], frames[1])
     want, _ = _oracle_mid(sd, frames, [(0, 0.25), (0, 0.5), (0, 0.75)])
     assert (out[1:4] - want).abs().max().item() <= TOL, describe_diff(out[1:4], want, "4K x4")
+
+
+# ---- arch 4.17 (rife417.pth): Head_417 encoder (3 convs + transposed conv), 8 feature channels per frame -----------
+
+@pytest.fixture(scope="module")
+def sd417():
+    return synth.rife417_synth_state_dict(1234)
+
+
+@pytest.fixture(scope="module")
+def engine417(hip_lib, sd417):
+    from cfi_amd.rife import RifeEngine
+
+    e = RifeEngine(sd417, "4.17")
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("h,w,sf", [(64, 64, 1.0), (100, 150, 1.0), (270, 480, 1.0), (120, 200, 0.5), (120, 200, 2.0)])
+def test_rife417_against_oracle(engine417, sd417, h, w, sf):
+    from cfi_amd.rife import run_tasks
+
+    frames = synth.smooth_frames(2, h, w, seed=4, shift=3.0)
+    tasks = [(0, 0.5), (0, 0.2)]
+    got = run_tasks(engine417, frames, tasks, batch_size=2, scale_factor=sf)
+    x = frames.permute(0, 3, 1, 2)
+    ts = torch.tensor([0.5, 0.2]).view(-1, 1, 1, 1)
+    with torch.inference_mode():
+        want, aux = rife_oracle.ifnet47_forward(sd417, x[0:1].repeat(2, 1, 1, 1), x[1:2].repeat(2, 1, 1, 1), ts,
+                                                tuple(b / sf for b in (8.0, 4.0, 2.0, 1.0)), return_aux=True, arch="4.17")
+    want = want.clamp(0, 1).permute(0, 2, 3, 1)
+    assert (got - want).abs().max().item() <= TOL, describe_diff(got, want, f"rife 4.17 {h}x{w} sf={sf}")
+
+
+def test_rife417_frame_pack_and_flows(engine417, sd417):
+    """debug taps: the frame pack (rgb + 8 encoder features = Head_417 output) and every stage's flow"""
+    from cfi_amd.rife import run_tasks
+
+    h, w = 100, 150
+    hp, wp = 128, 192
+    frames = synth.smooth_frames(2, h, w, seed=4, shift=3.0)
+    engine417.debug_keep(True)
+    try:
+        run_tasks(engine417, frames, [(0, 0.5)], batch_size=1)
+        x = frames.permute(0, 3, 1, 2)
+        with torch.inference_mode():
+            _, aux = rife_oracle.ifnet47_forward(sd417, x[0:1], x[1:2], torch.tensor([0.5]).view(1, 1, 1, 1), return_aux=True, arch="4.17")
+            feat = rife_oracle.encode417(sd417, torch.nn.functional.pad(x[0:1].clamp(0, 1), (0, wp - w, 0, hp - h)))
+        slot = None
+        for s_ in range(4):   # find the slot that holds frame 0 (slot assignment is an implementation detail)
+            pack = engine417.debug_read(2, s_, 3 * hp * wp * 4).view(3, hp, wp, 4)
+            if torch.equal(pack[0, :h, :w, :3], frames[0].clamp(0, 1)):
+                slot = s_
+                break
+        assert slot is not None, "frame 0 not found in any slot"
+        got_feat = torch.cat([pack[1], pack[2]], -1).permute(2, 0, 1)[None]
+        assert (got_feat - feat).abs().max().item() <= 2e-5, describe_diff(got_feat, feat, "Head_417 features", chan_last=False)
+        for i in range(4):
+            fl = engine417.debug_read(0, i, hp * wp * 4).view(1, hp, wp, 4).permute(0, 3, 1, 2)
+            wf = aux[i][0]
+            sl = (slice(None), slice(None), slice(0, h), slice(0, w)) if i == 3 else (slice(None),) * 4
+            assert (fl[sl] - wf[sl]).abs().max().item() <= 2e-4, describe_diff(fl[sl], wf[sl], f"flow after block {i}", chan_last=False)
+    finally:
+        engine417.debug_keep(False)
+
+
+def test_rife417_1080p(engine417, sd417):
+    from cfi_amd.rife import run_tasks
+
+    frames = synth.smooth_frames(2, 1080, 1920, seed=2, shift=4.0)
+    got = run_tasks(engine417, frames, [(0, 0.5)], batch_size=1)
+    x = frames.permute(0, 3, 1, 2)
+    with torch.inference_mode():
+        want = rife_oracle.ifnet47_forward(sd417, x[0:1], x[1:2], torch.tensor([0.5]).view(1, 1, 1, 1), arch="4.17")
+    want = want.clamp(0, 1).permute(0, 2, 3, 1)
+    assert (got - want).abs().max().item() <= TOL, describe_diff(got, want, "rife 4.17 1080p")
+
+
+@pytest.mark.parametrize("name,kw", [("m2", dict(multiplier=2)), ("mlist_bs2", dict(multiplier=[3, 1], batch_size=2))])
+def test_node417_against_reference_golden(hip_lib, sd417, golden_dir, tmp_path, monkeypatch, name, kw):
+    """RIFE_VFI.vfi("rife417.pth", ...) vs the reference node's own output (tests/golden/rife417_node.npz)"""
+    import cfi_amd.rife as R
+
+    pth = tmp_path / "rife417.pth"
+    torch.save(sd417, pth)
+    monkeypatch.setattr(R, "load_file_from_github_release", lambda model_type, ckpt: str(pth))
+    R._model_cache.clear()
+    g = np.load(os.path.join(golden_dir, "rife417_node.npz"))
+    (out,) = R.RIFE_VFI().vfi("rife417.pth", torch.from_numpy(g["frames"]), **kw)
+    R._model_cache.clear()
+    want = torch.from_numpy(g[name])
+    assert out.shape == want.shape and (out - want).abs().max().item() <= TOL, describe_diff(out, want, name)
