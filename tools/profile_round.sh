@@ -1,0 +1,24 @@
+#!/bin/bash
+# rocprofv3 evidence for bench.py's configuration: kernel stats, then PMC passes (one counter group per pass; never
+# combined with other trace domains).  Summaries are written under gpurun_out/prof_*/ and copied to profiles/ by hand.
+export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
+mkdir -p gpurun_out
+TAG=${1:-r01}
+CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+run() {  # name, rocprof args...
+  local name=$1; shift
+  rm -rf gpurun_out/prof_$name
+  timeout 240 rocprofv3 "$@" -d gpurun_out/prof_$name -o $name -- $CMD > gpurun_out/prof_$name.log 2>&1
+  echo "$name rc=$?"
+}
+run stats --kernel-trace --stats
+python tools/rocprof_summary.py stats "gpurun_out/prof_stats/*/*_results.db" > gpurun_out/${TAG}_kernel_stats.txt 2>&1 || python tools/rocprof_summary.py stats "gpurun_out/prof_stats/*_results.db" > gpurun_out/${TAG}_kernel_stats.txt 2>&1
+head -25 gpurun_out/${TAG}_kernel_stats.txt
+for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+  n=$(echo $c | tr ' ' '+' | cut -c1-40)
+  run pmc_$n --kernel-trace --pmc $c
+  python tools/rocprof_summary.py pmc "gpurun_out/prof_pmc_$n/*/*_results.db" > gpurun_out/${TAG}_pmc_$n.txt 2>&1 || python tools/rocprof_summary.py pmc "gpurun_out/prof_pmc_$n/*_results.db" > gpurun_out/${TAG}_pmc_$n.txt 2>&1
+  head -12 gpurun_out/${TAG}_pmc_$n.txt
+done
+rm -rf gpurun_out/prof_*/   # databases are large; the text summaries are what is kept
