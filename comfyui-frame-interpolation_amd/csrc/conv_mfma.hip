@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
                     if (GROUPED && a.out_mode == 1) {
                         const int Ws = 4 * a.Wout, Hs = 4 * a.Hout, c = co >> 2;
                         const int Yt = 4 * oy + 2 * (g >> 1) + ((co >> 1) & 1), Xt = 4 * ox + 2 * (g & 1) + (co & 1);
-                        a.out[((size_t)(n * 2 + (c >> 2)) * Hs * Ws + (size_t)Yt * Ws + Xt) * 4 + (c & 3)] = v;
+                        a.out[((size_t)(n * (a.out_planes ? a.out_planes : 2) + (c >> 2)) * Hs * Ws + (size_t)Yt * Ws + Xt) * 4 + (c & 3)] = v;
                     } else if (EXT && GROUPED && a.out_mode == 2) {
                         const size_t q2 = (size_t)(n * 2 * a.Hout + 2 * oy + (g >> 1)) * (2 * a.Wout) + 2 * ox + (g & 1);
                         a.out[q2 * a.out_cs + co] = v;
@@ -315,7 +315,8 @@ int conv_launch(const ConvArgs& a, int stride, bool grouped, int variant, hipStr
     VFI_REQUIRE(v.stride == stride && (v.grouped != 0) == grouped && v.taps == a.ntaps,
                 "conv: variant %s does not match stride %d grouped %d taps %d", v.name, stride, (int)grouped,
                 a.ntaps);
-    VFI_REQUIRE(a.out_mode != 1 || (grouped && a.Cout % 4 == 0 && a.Cout <= 32), "conv: out_mode 1 is for grouped convs");
+    VFI_REQUIRE(a.out_mode != 1 || (grouped && a.Cout % 4 == 0 && a.Cout / 4 <= 4 * (a.out_planes ? a.out_planes : 2)),
+                "conv: out_mode 1 is for grouped convs whose pixel-shuffled channels fit the planar4 output");
     VFI_REQUIRE(a.out_mode != 2 || grouped, "conv: out_mode 2 is for grouped convs");
     VFI_REQUIRE(a.act != 3 || a.prelu, "conv: act 3 needs per-channel slopes");
     VFI_REQUIRE(a.Cin_p % 8 == 0 && a.Cout_p % 32 == 0 && a.in_cs >= a.Cin_p && a.in_cs % 4 == 0,

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
                             if (GROUPED && a.out_mode == 1) {
                                 const int Ws = 4 * a.Wout, Hs = 4 * a.Hout, c = co >> 2;
                                 const int Yt = 4 * oy + 2 * (g >> 1) + ((co >> 1) & 1), Xt = 4 * ox + 2 * (g & 1) + (co & 1);
-                                a.out[((size_t)(n * 2 + (c >> 2)) * Hs * Ws + (size_t)Yt * Ws + Xt) * 4 + (c & 3)] = v;
+                                a.out[((size_t)(n * (a.out_planes ? a.out_planes : 2) + (c >> 2)) * Hs * Ws + (size_t)Yt * Ws + Xt) * 4 + (c & 3)] = v;
                             } else if (EXT && GROUPED && a.out_mode == 2) {
                                 const size_t q2 = (size_t)(n * 2 * a.Hout + 2 * oy + (g >> 1)) * (2 * a.Wout) + 2 * ox + (g & 1);
                                 a.out[q2 * a.out_cs + co] = v;

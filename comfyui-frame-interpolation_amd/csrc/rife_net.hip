@@ -48,30 +48,36 @@ struct ConvLayer {
     bool folded = false;  // residual folded into the centre tap (ResConv)
 };
 
-const int kBlockC[4] = {192, 128, 96, 64};
+const int kBlockC[5] = {192, 128, 96, 64, 32};  // IFBlock widths; the fifth block exists in arch 4.26 only
+constexpr int kMaxBlocks = 5;
 
 }  // namespace
 
 struct vfi_rife {
-    ConvLayer conv00[4], conv01[4], res[4][8], last[4];
+    ConvLayer conv00[kMaxBlocks], conv01[kMaxBlocks], res[kMaxBlocks][8], last[kMaxBlocks];
     DevBuf enc_w0, enc_b0, enc_w1, enc_b1;
     // architecture: feature planes of the frame pack (4 channels each), width of the head, its activation / mid convs
     //   4.7  : encode = Conv(3,16,s2) -> Deconv(16,4)                                   rife_arch.py:414-416
     //   4.17 : Head_417 = Conv(3,32,s2) lrelu Conv(32,32) lrelu Conv(32,32) lrelu Deconv(32,8)   :355-375
-    int arch = 47, NF = 1, CM = 16, CF = 4, n_mid = 0;
+    //   4.26 : Head (16 wide, as Head_417) + 5 IFBlocks whose lastconv also returns 8 feature channels that are carried to
+    //          the next block (NX), block scales [16,8,4,2,1]/scale_factor                        :378-398,451-457,267-273
+    int arch = 47, NF = 1, CM = 16, CF = 4, n_mid = 0, nblocks = 4, NX = 0;
     bool enc_act = false;
+    int last_out() const { return NX ? 52 : 24; }   // lastconv channels before PixelShuffle(2)
+    int tplanes() const { return NX ? 4 : 2; }      // planes of the pixel-shuffled block output T
+    DevBuf FEAT;                                     // [B][2][Hp][Wp][4] carried features at frame resolution
     ConvLayer enc_mid[2];
     DevBuf E2;
-    int block_in(int i) const { return i == 0 ? 7 + 8 * NF : 12 + 8 * NF; }   // IFBlock in_planes, rife_arch.py:410-421
+    int block_in(int i) const { return i == 0 ? 7 + 8 * NF : 12 + 8 * NF + NX; }   // IFBlock in_planes, rife_arch.py:410-456
     int CX(int i) const { return round_up(block_in(i), 8); }
     // geometry
     int H = 0, W = 0, Hp = 0, Wp = 0, max_batch = 0, n_slots = 0;
-    int scales[4] = {8, 4, 2, 1};  // integer block scales (1 where the block scale is fractional)
-    int up[4] = {1, 1, 1, 1};      // 1/scale for fractional block scales 0.5 / 0.25 (scale_factor 2 / 4)
+    int scales[kMaxBlocks] = {8, 4, 2, 1, 1};  // integer block scales (1 where the block scale is fractional)
+    int up[kMaxBlocks] = {1, 1, 1, 1, 1};      // 1/scale for fractional block scales 0.5 / 0.25 (scale_factor 2 / 4)
     // workspace
     DevBuf Ppool, E, F, M, X, A0, A1, A2, T;
     DevBuf X1, T1;  // frame-resolution staging around blocks that run above the frame resolution
-    DevBuf Fdbg[4], Xdbg[4];
+    DevBuf Fdbg[kMaxBlocks], Xdbg[kMaxBlocks];
     bool keep = false;
     int last_B = 0;
     size_t pack_stride() const { return (size_t)Hp * Wp * 4 * (1 + NF); }
@@ -112,12 +118,12 @@ static int make_conv3x3(ConvLayer& L, const float* w, const float* b, const floa
 extern "C" {
 
 vfi_rife_t* vfi_rife_create(int arch_ver_x10, const float* const* tensors, const int64_t* numels, int n_tensors) {
-    if (arch_ver_x10 != 47 && arch_ver_x10 != 417) {
-        set_error("vfi_rife_create: architecture code %d not implemented (47 = \"4.7\": rife47/rife49, 417 = \"4.17\": rife417)",
-                  arch_ver_x10);
+    if (arch_ver_x10 != 47 && arch_ver_x10 != 417 && arch_ver_x10 != 426) {
+        set_error("vfi_rife_create: architecture code %d not implemented (47 = \"4.7\": rife47/rife49, 417 = \"4.17\": rife417, "
+                  "426 = \"4.26\": rife426)", arch_ver_x10);
         return nullptr;
     }
-    const int want_tensors = arch_ver_x10 == 47 ? 124 : 128;
+    const int want_tensors = arch_ver_x10 == 47 ? 124 : (arch_ver_x10 == 417 ? 128 : 158);
     if (n_tensors != want_tensors) {
         set_error("vfi_rife_create: expected %d state_dict tensors for architecture code %d, got %d", want_tensors, arch_ver_x10,
                   n_tensors);
@@ -131,6 +137,11 @@ vfi_rife_t* vfi_rife_create(int arch_ver_x10, const float* const* tensors, const
         net->CF = 8;
         net->n_mid = 2;
         net->enc_act = true;
+    } else if (arch_ver_x10 == 426) {
+        net->n_mid = 2;
+        net->enc_act = true;
+        net->nblocks = 5;
+        net->NX = 8;
     }
     int k = 0;
     auto next = [&](int64_t want) -> const float* {
@@ -142,7 +153,8 @@ vfi_rife_t* vfi_rife_create(int arch_ver_x10, const float* const* tensors, const
         return tensors[k++];
     };
     bool ok = true;
-    for (int b = 0; b < 4 && ok; ++b) {
+    const int LO = net->last_out(), LOp = round_up(LO, 32);
+    for (int b = 0; b < net->nblocks && ok; ++b) {
         const int c = kBlockC[b], cin = net->block_in(b);
         const int cin_p = round_up(cin, 8);
         const float* w = next((int64_t)(c / 2) * cin * 9);
@@ -159,16 +171,16 @@ vfi_rife_t* vfi_rife_create(int arch_ver_x10, const float* const* tensors, const
             ok = ok && bi && !make_conv3x3(net->res[b][i], w, bi, beta, c, c, c);
         }
         if (!ok) break;
-        w = next((int64_t)c * 24 * 16);
-        bi = w ? next(24) : nullptr;
+        w = next((int64_t)c * LO * 16);
+        bi = w ? next(LO) : nullptr;
         ok = ok && bi;
         if (ok) {
             ConvLayer& L = net->last[b];
             L.Cin = L.Cin_p = c;
-            L.Cout = 24;
-            L.Cout_p = 32;
+            L.Cout = LO;
+            L.Cout_p = LOp;
             std::vector<float> wp, bp;
-            pack_deconv4x4(w, bi, c, 24, c, 32, wp, bp);
+            pack_deconv4x4(w, bi, c, LO, c, LOp, wp, bp);
             ok = !upload(L.w, wp) && !upload(L.bias, bp);
         }
     }
@@ -207,7 +219,7 @@ vfi_rife_t* vfi_rife_create(int arch_ver_x10, const float* const* tensors, const
 
 void vfi_rife_destroy(vfi_rife_t* net) {
     if (!net) return;
-    for (int b = 0; b < 4; ++b) {
+    for (int b = 0; b < kMaxBlocks; ++b) {
         for (ConvLayer* L : {&net->conv00[b], &net->conv01[b], &net->last[b]}) {
             L->w.release();
             L->bias.release();
@@ -227,7 +239,7 @@ void vfi_rife_destroy(vfi_rife_t* net) {
     }
     net->E2.release();
     for (DevBuf* d : {&net->enc_w0, &net->enc_b0, &net->enc_w1, &net->enc_b1, &net->Ppool, &net->E, &net->F, &net->M,
-                      &net->X, &net->A0, &net->A1, &net->A2, &net->T, &net->X1, &net->T1})
+                      &net->X, &net->A0, &net->A1, &net->A2, &net->T, &net->X1, &net->T1, &net->FEAT})
         d->release();
     delete net;
 }
@@ -239,9 +251,12 @@ int vfi_rife_configure(vfi_rife_t* net, int H, int W, int max_batch, int n_slots
                 kMaxTasks, n_slots);
     // scale_list = [8,4,2,1] / scale_factor (rife/__init__.py:157-160).  Block scales >= 1 must be 1 or even integers
     // (the down-resize then is the centre-2x2 mean); block scales 0.5 / 0.25 run the block above the frame resolution.
-    const float base[4] = {8.f, 4.f, 2.f, 1.f};
-    int sc[4], up[4];
-    for (int i = 0; i < 4; ++i) {
+    // arch 4.26: [16,8,4,2,1] / scale_factor (rife/__init__.py:155-156)
+    const int NB = net->nblocks;
+    const float base4[kMaxBlocks] = {8.f, 4.f, 2.f, 1.f, 1.f}, base5[kMaxBlocks] = {16.f, 8.f, 4.f, 2.f, 1.f};
+    const float* base = NB == 5 ? base5 : base4;
+    int sc[kMaxBlocks] = {1, 1, 1, 1, 1}, up[kMaxBlocks] = {1, 1, 1, 1, 1};
+    for (int i = 0; i < NB; ++i) {
         const float s = base[i] / scale_factor;
         if (s >= 1.f) {
             sc[i] = (int)s;
@@ -258,7 +273,7 @@ int vfi_rife_configure(vfi_rife_t* net, int H, int W, int max_batch, int n_slots
         }
     }
     const int Hp = round_up(H, 64), Wp = round_up(W, 64);
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NB; ++i) {
         VFI_REQUIRE(Hp % (4 * sc[i]) == 0 && Wp % (4 * sc[i]) == 0,
                     "vfi_rife_configure: padded size %dx%d not divisible by 4*scale %d (the reference fails here too, "
                     "SURVEY.md App. C6)", Hp, Wp, sc[i]);
@@ -277,13 +292,15 @@ int vfi_rife_configure(vfi_rife_t* net, int H, int W, int max_batch, int n_slots
     memcpy(net->up, up, sizeof(up));
     const size_t full = (size_t)Hp * Wp, B = max_batch;
     size_t x = 0, a0 = 0, a1 = 0, t = 0;
-    for (int i = 0; i < 4; ++i) {
+    bool any_up = false;
+    for (int i = 0; i < NB; ++i) {
+        any_up = any_up || up[i] > 1;
         const size_t px = full / ((size_t)sc[i] * sc[i]) * ((size_t)up[i] * up[i]);
         const size_t cx = net->CX(i);
         x = std::max(x, px * cx);
         a0 = std::max(a0, px / 4 * (kBlockC[i] / 2));
         a1 = std::max(a1, px / 16 * kBlockC[i]);
-        t = std::max(t, px * 8);
+        t = std::max(t, px * 4 * net->tplanes());
     }
     // T plane 1 holds only the mask (+1 unused channel): components 2,3 are never written; keep them defined
     if (net->Ppool.ensure(net->pack_stride() * n_slots) || net->E.ensure(full / 4 * net->CM) ||
@@ -291,7 +308,8 @@ int vfi_rife_configure(vfi_rife_t* net, int H, int W, int max_batch, int n_slots
         net->M.ensure(B * full) || net->X.ensure(B * x) || net->A0.ensure(B * a0) || net->A1.ensure(B * a1) ||
         net->A2.ensure(B * a1) || net->T.ensure(B * t))
         return -1;
-    if ((up[2] > 1 || up[3] > 1 || up[1] > 1) && (net->X1.ensure(B * full * net->CX(3)) || net->T1.ensure(B * full * 8))) return -1;
+    if (any_up && (net->X1.ensure(B * full * net->CX(1)) || net->T1.ensure(B * full * 4 * net->tplanes()))) return -1;
+    if (net->NX && net->FEAT.ensure(B * full * 8)) return -1;
     return 0;
 }
 
@@ -352,12 +370,14 @@ int vfi_rife_interpolate(vfi_rife_t* net, int B, const int* slot0, const int* sl
         tasks.t[b] = timestep[b];
     }
     const int Hp = net->Hp, Wp = net->Wp;
-    static const char* kResName[4] = {"resconv_c192", "resconv_c128", "resconv_c96", "resconv_c64"};
-    static const char* kC00Name[4] = {"conv0a_b0", "conv0a_b1", "conv0a_b2", "conv0a_b3"};
-    static const char* kC01Name[4] = {"conv0b_b0", "conv0b_b1", "conv0b_b2", "conv0b_b3"};
-    static const char* kLastName[4] = {"lastconv_b0", "lastconv_b1", "lastconv_b2", "lastconv_b3"};
+    static const char* kResName[kMaxBlocks] = {"resconv_c192", "resconv_c128", "resconv_c96", "resconv_c64", "resconv_c32"};
+    static const char* kC00Name[kMaxBlocks] = {"conv0a_b0", "conv0a_b1", "conv0a_b2", "conv0a_b3", "conv0a_b4"};
+    static const char* kC01Name[kMaxBlocks] = {"conv0b_b0", "conv0b_b1", "conv0b_b2", "conv0b_b3", "conv0b_b4"};
+    static const char* kLastName[kMaxBlocks] = {"lastconv_b0", "lastconv_b1", "lastconv_b2", "lastconv_b3", "lastconv_b4"};
+    const int NB = net->nblocks, TP = net->tplanes();
+    const float* feat = net->NX ? net->FEAT.p : nullptr;
     bool fused_prev = false;
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NB; ++i) {
         const int s = net->scales[i], u = net->up[i];
         const int Hs = Hp / s * u, Ws = Wp / s * u;
         const int c = kBlockC[i];
@@ -366,10 +386,10 @@ int vfi_rife_interpolate(vfi_rife_t* net, int B, const int* slot0, const int* sl
         // previous iteration when the scale list allows it (standard [8,4,2,1]), else from stage_in.
         const bool x_ready = i > 0 && fused_prev;
         if (!x_ready &&
-            stage_in_launch(net->Ppool.p, net->pack_stride(), tasks, B, net->F.p, net->M.p, u > 1 ? net->X1.p : net->X.p, Hp, Wp,
-                            s, CX, NF, i > 0, st))
+            stage_in_launch(net->Ppool.p, net->pack_stride(), tasks, B, net->F.p, net->M.p, i > 0 ? feat : nullptr,
+                            u > 1 ? net->X1.p : net->X.p, Hp, Wp, s, CX, NF, i > 0, st))
             return -1;
-        if (u > 1 && planar4_up_launch(net->X1.p, net->X.p, B, Hp, Wp, u, CX, /*flow plane*/ 2 + 2 * NF, st)) return -1;
+        if (u > 1 && planar4_up_launch(net->X1.p, net->X.p, B, Hp, Wp, u, CX, /*flow plane*/ 2 + 2 * NF + net->NX / 4, st)) return -1;
         if (net->keep) {
             const size_t n = (size_t)B * Hs * Ws * CX;
             if (net->Xdbg[i].ensure(n)) return -1;
@@ -403,25 +423,28 @@ int vfi_rife_interpolate(vfi_rife_t* net, int B, const int* slot0, const int* sl
             if (conv_launch(a, 1, false, -1, st, kResName[i])) return -1;
             std::swap(cur, nxt);
         }
-        // lastconv: ConvTranspose2d(c,24,4,2,1) as 4 parity groups -> T[.,4,32]
+        // lastconv: ConvTranspose2d(c, 24 | 52, 4, 2, 1) as 4 parity groups
         fill_args(a, net->last[i], cur, c, net->T.p, 128, B, Hs / 4, Ws / 4, 1);
-        a.out_mode = 1;  // PixelShuffle(2) resolved by the epilogue: T is planar4 [B][2][Hs][Ws][4]
+        a.out_mode = 1;  // PixelShuffle(2) resolved by the epilogue: T is planar4 [B][TP][Hs][Ws][4]
+        a.out_planes = TP;
         deconv4x4_taps(a);
         if (conv_launch(a, 1, true, -1, st, kLastName[i])) return -1;
         const float* Tsrc = net->T.p;
         if (u > 1) {  // interpolate(tmp, scale) and flow * scale: back to the frame resolution, then as a scale-1 block
-            if (t_down_launch(net->T.p, net->T1.p, B, Hp, Wp, u, st)) return -1;
+            if (t_down_launch(net->T.p, net->T1.p, B, Hp, Wp, u, TP, st)) return -1;
             Tsrc = net->T1.p;
         }
-        if (i < 3) {
+        if (i < NB - 1) {
             const int sn = net->scales[i + 1];
-            fused_prev = u == 1 && net->up[i + 1] == 1 && s == 2 * sn && (sn == 4 || sn == 2 || sn == 1);
+            // the fused transition kernel covers the 6-channel block output (flow + mask) of arch 4.7 / 4.17
+            fused_prev = !net->NX && u == 1 && net->up[i + 1] == 1 && s == 2 * sn && (sn == 4 || sn == 2 || sn == 1);
             if (fused_prev) {
                 if (stage_trans_launch(net->Ppool.p, net->pack_stride(), tasks, B, Tsrc, net->F.p, net->X.p, Hp, Wp,
                                        s, sn, NF, i > 0, st))
                     return -1;
-            } else if (flow_up_launch(Tsrc, net->F.p, net->M.p, B, Hp, Wp, s, i > 0, st)) {
-                return -1;
+            } else {
+                if (flow_up_launch(Tsrc, net->F.p, net->M.p, B, Hp, Wp, s, TP, i > 0, st)) return -1;
+                if (net->NX && feat_up_launch(Tsrc, net->FEAT.p, B, Hp, Wp, s, st)) return -1;
             }
             if (net->keep) {
                 const size_t n = (size_t)B * Hp * Wp * 4;
@@ -437,7 +460,7 @@ int vfi_rife_interpolate(vfi_rife_t* net, int B, const int* slot0, const int* sl
                 fd = net->Fdbg[i].p;
             }
             if (final_blend_launch(net->Ppool.p, net->pack_stride(), tasks, B, Tsrc, net->F.p, out_dev, fd, net->H,
-                                   net->W, Hp, Wp, s, st))
+                                   net->W, Hp, Wp, s, TP, st))
                 return -1;
         }
     }
@@ -458,10 +481,10 @@ int64_t vfi_rife_debug_read(vfi_rife_t* net, int what, int stage, float* host_bu
     }
     const float* src = nullptr;
     size_t n = 0;
-    if (what == 0 && stage >= 0 && stage < 4) {
+    if (what == 0 && stage >= 0 && stage < net->nblocks) {
         src = net->Fdbg[stage].p;
         n = (size_t)net->last_B * net->Hp * net->Wp * 4;
-    } else if (what == 1 && stage >= 0 && stage < 4) {
+    } else if (what == 1 && stage >= 0 && stage < net->nblocks) {
         const int s = net->scales[stage], u = net->up[stage];
         src = net->Xdbg[stage].p;
         n = (size_t)net->last_B * (net->Hp / s * u) * (net->Wp / s * u) * net->CX(stage);
@@ -485,13 +508,13 @@ int vfi_rife_work(vfi_rife_t* net, double* conv_flop_per_task, double* hbm_bytes
     VFI_REQUIRE(net && net->Hp > 0, "vfi_rife_work: network not configured");
     const double full = (double)net->Hp * net->Wp;
     double mac = 0;
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < net->nblocks; ++i) {
         const double px = full / ((double)net->scales[i] * net->scales[i]) * ((double)net->up[i] * net->up[i]);
         const double c = kBlockC[i];
         mac += px / 4 * (c / 2) * net->block_in(i) * 9;   // conv0.0
         mac += px / 16 * c * (c / 2) * 9;            // conv0.1
         mac += 8 * px / 16 * c * c * 9;              // ResConv x8
-        mac += px / 16 * c * 24 * 16;                // ConvTranspose2d: in_numel * Cout * k*k
+        mac += px / 16 * c * net->last_out() * 16;   // ConvTranspose2d: in_numel * Cout * k*k
     }
     // encode, both frames of the pair (the reference recomputes it per task; rife_arch.py:501-503)
     mac += 2 * (full / 4 * net->CM * 3 * 9 + net->n_mid * full / 4 * net->CM * net->CM * 9 + full / 4 * net->CM * net->CF * 16);

@@ -20,15 +20,19 @@ int encode_conv_launch(const float* P, float* E, const float* w0, const float* b
 int encode_deconv_launch(const float* E, float* P, const float* w1, const float* b1, int CM, int CF, int Hp, int Wp,
                          hipStream_t s);
 // NF = feature planes of the frame pack (1: 4 feature channels, 2: 8); CX = round_up(7 + 8*NF (+5 with flow), 8)
+// FEAT (nullable): [B][2][Hp][Wp][4] features carried from the previous block (arch 4.26), inserted before the flow
 int stage_in_launch(const float* Ppool, size_t pack_stride, const RifeTasks& tasks, int B, const float* F,
-                    const float* M, float* X, int Hp, int Wp, int s, int CX, int NF, bool has_flow, hipStream_t st);
-int flow_up_launch(const float* T, float* F, float* M, int B, int Hp, int Wp, int s, bool has_prev, hipStream_t st);
+                    const float* M, const float* FEAT, float* X, int Hp, int Wp, int s, int CX, int NF, bool has_flow,
+                    hipStream_t st);
+// tp = planes of T per task (2: flow+mask, 4: arch 4.26 with 8 carried feature channels)
+int flow_up_launch(const float* T, float* F, float* M, int B, int Hp, int Wp, int s, int tp, bool has_prev, hipStream_t st);
+int feat_up_launch(const float* T, float* FEAT, int B, int Hp, int Wp, int s, hipStream_t st);
 int stage_trans_launch(const float* Ppool, size_t pack_stride, const RifeTasks& tasks, int B, const float* T, float* F,
                        float* X, int Hp, int Wp, int s_prev, int s_next, int NF, bool has_prev, hipStream_t st);
 int final_blend_launch(const float* Ppool, size_t pack_stride, const RifeTasks& tasks, int B, const float* T,
-                       const float* F, float* out, float* Fdbg, int H, int W, int Hp, int Wp, int s, hipStream_t st);
+                       const float* F, float* out, float* Fdbg, int H, int W, int Hp, int Wp, int s, int tp, hipStream_t st);
 int planar4_up_launch(const float* X1, float* X, int B, int Hp, int Wp, int u, int CX, int flow_plane, hipStream_t st);
-int t_down_launch(const float* T, float* T1, int B, int Hp, int Wp, int u, hipStream_t st);
+int t_down_launch(const float* T, float* T1, int B, int Hp, int Wp, int u, int tp, hipStream_t st);
 int t_to_nhwc_launch(const float* T, float* out, int N, int Hq, int Wq, int C4, hipStream_t st);
 
 }  // namespace vfi

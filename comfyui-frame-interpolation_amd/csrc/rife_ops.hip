@@ -298,11 +298,11 @@ int encode_deconv_launch(const float* E, float* P, const float* w1, const float*
 // Down-resizing by an even integer s with align_corners=False samples exactly the centre 2x2 of
 // every s x s cell with weights 1/2, so only those pixels are warped at all.
 // ---------------------------------------------------------------------------------------
-template <bool HAS_FLOW, int NP, int NF>
+template <bool HAS_FLOW, int NP, int NF, int NX>
 __global__ __launch_bounds__(128) void stage_in_kernel(const float* __restrict__ Ppool, size_t pack_stride,
                                                        RifeTasks tasks, const float* __restrict__ F,
-                                                       const float* __restrict__ M, float* __restrict__ Xo, int Hp,
-                                                       int Wp, int s, int CX) {
+                                                       const float* __restrict__ M, const float* __restrict__ FEAT,
+                                                       float* __restrict__ Xo, int Hp, int Wp, int s, int CX) {
     const int Hs = Hp / s, Ws = Wp / s;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= Hs * Ws) return;
@@ -315,8 +315,9 @@ __global__ __launch_bounds__(128) void stage_in_kernel(const float* __restrict__
     const WarpGeo g = make_warp_geo(Wp, Hp);
     const int off = NP == 1 ? 0 : s / 2 - 1;
     const float inv_s = 1.0f / (float)s;
-    constexpr int NI = 7 + 8 * NF;               // images + features + timestep
-    constexpr int NC = HAS_FLOW ? NI + 5 : NI;   // + mask + flow
+    constexpr int NI = 7 + 8 * NF;                    // images + features + timestep
+    constexpr int NC = HAS_FLOW ? NI + 5 + NX : NI;   // + mask (+ NX carried block features, arch 4.26) + flow
+    static_assert(NX == 0 || (NX == 8 && HAS_FLOW), "carried features come with a flow");
     constexpr int NR = (NC + 7) / 8 * 8;         // X channels (zero padded)
 
     // torch upsample_bilinear2d order: wy0*(wx0*a + wx1*b) + wy1*(wx0*c + wx1*d), all weights 0.5
@@ -337,7 +338,13 @@ __global__ __launch_bounds__(128) void stage_in_kernel(const float* __restrict__
                 const Tap4 t1 = warp_taps(g, X, Y, f.z, f.w);
                 sample_pack<NF>(P0, hi_off, t0, a_lo, a_hi);
                 sample_pack<NF>(P1, hi_off, t1, b_lo, b_hi);
-                o[NC - 5] = M[pb];
+                o[NI] = M[pb];
+                if (NX == 8) {
+                    const float4 g0 = ((const float4*)FEAT)[(size_t)b * 2 * Hp * Wp + p];
+                    const float4 g1 = ((const float4*)FEAT)[((size_t)b * 2 + 1) * Hp * Wp + p];
+                    o[NI + 1] = g0.x; o[NI + 2] = g0.y; o[NI + 3] = g0.z; o[NI + 4] = g0.w;
+                    o[NI + 5] = g1.x; o[NI + 6] = g1.y; o[NI + 7] = g1.z; o[NI + 8] = g1.w;
+                }
                 o[NC - 4] = f.x;
                 o[NC - 3] = f.y;
                 o[NC - 2] = f.z;
@@ -371,18 +378,22 @@ __global__ __launch_bounds__(128) void stage_in_kernel(const float* __restrict__
 }
 
 int stage_in_launch(const float* Ppool, size_t pack_stride, const RifeTasks& tasks, int B, const float* F,
-                    const float* M, float* X, int Hp, int Wp, int s, int CX, int NF, bool has_flow, hipStream_t st) {
+                    const float* M, const float* FEAT, float* X, int Hp, int Wp, int s, int CX, int NF, bool has_flow,
+                    hipStream_t st) {
     const int Hs = Hp / s, Ws = Wp / s;
+    const int NX = FEAT && has_flow ? 8 : 0;
     VFI_REQUIRE(s == 1 || s % 2 == 0, "stage_in: scale %d must be 1 or even", s);
-    VFI_REQUIRE((NF == 1 || NF == 2) && CX == round_up(7 + 8 * NF + (has_flow ? 5 : 0), 8), "stage_in: bad CX %d for %d feature planes",
-                CX, NF);
+    VFI_REQUIRE((NF == 1 || NF == 2) && (NX == 0 || NF == 1) && CX == round_up(7 + 8 * NF + (has_flow ? 5 + NX : 0), 8),
+                "stage_in: bad CX %d for %d feature planes (+%d carried)", CX, NF, NX);
     dim3 grid(cdiv(Hs * Ws, 128), B);
     TraceScope ts(has_flow ? "stage_in_warp" : "stage_in0", st);
-#define VFI_SI(HF, NPV, NFV) \
-    hipLaunchKernelGGL((stage_in_kernel<HF, NPV, NFV>), grid, dim3(128), 0, st, Ppool, pack_stride, tasks, F, M, X, Hp, Wp, s, CX)
+#define VFI_SI(HF, NPV, NFV, NXV) \
+    hipLaunchKernelGGL((stage_in_kernel<HF, NPV, NFV, NXV>), grid, dim3(128), 0, st, Ppool, pack_stride, tasks, F, M, FEAT, X, Hp, Wp, s, CX)
 #define VFI_SI2(HF, NPV) \
-    do { if (NF == 1) VFI_SI(HF, NPV, 1); else VFI_SI(HF, NPV, 2); } while (0)
-    if (has_flow) {
+    do { if (NF == 1) VFI_SI(HF, NPV, 1, 0); else VFI_SI(HF, NPV, 2, 0); } while (0)
+    if (NX == 8) {
+        if (s == 1) VFI_SI(true, 1, 1, 8); else VFI_SI(true, 2, 1, 8);
+    } else if (has_flow) {
         if (s == 1) VFI_SI2(true, 1); else VFI_SI2(true, 2);
     } else {
         if (s == 1) VFI_SI2(false, 1); else VFI_SI2(false, 2);
@@ -454,13 +465,13 @@ __device__ static inline TVal t_upsample(const float* __restrict__ Tb, int Hs, i
 
 template <bool HAS_PREV>
 __global__ void flow_up_kernel(const float* __restrict__ T, float* __restrict__ F, float* __restrict__ M, int Hp,
-                               int Wp, int s) {
+                               int Wp, int s, int tp) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= Hp * Wp) return;
     const int b = blockIdx.y;
     const int X = idx % Wp, Y = idx / Wp;
     const int Hs = Hp / s, Ws = Wp / s;
-    const float* Tb = T + (size_t)b * Hs * Ws * 8;
+    const float* Tb = T + (size_t)b * Hs * Ws * 4 * tp;
     const TVal v = t_upsample(Tb, Hs, Ws, s, Y, X);
     const size_t pb = (size_t)b * Hp * Wp + idx;
     const float fs = (float)s;
@@ -473,14 +484,14 @@ __global__ void flow_up_kernel(const float* __restrict__ T, float* __restrict__ 
     M[pb] = v.m;
 }
 
-int flow_up_launch(const float* T, float* F, float* M, int B, int Hp, int Wp, int s, bool has_prev,
+int flow_up_launch(const float* T, float* F, float* M, int B, int Hp, int Wp, int s, int tp, bool has_prev,
                    hipStream_t st) {
     dim3 grid(cdiv(Hp * Wp, 256), B);
     TraceScope ts("flow_up", st);
     if (has_prev)
-        hipLaunchKernelGGL(flow_up_kernel<true>, grid, dim3(256), 0, st, T, F, M, Hp, Wp, s);
+        hipLaunchKernelGGL(flow_up_kernel<true>, grid, dim3(256), 0, st, T, F, M, Hp, Wp, s, tp);
     else
-        hipLaunchKernelGGL(flow_up_kernel<false>, grid, dim3(256), 0, st, T, F, M, Hp, Wp, s);
+        hipLaunchKernelGGL(flow_up_kernel<false>, grid, dim3(256), 0, st, T, F, M, Hp, Wp, s, tp);
     VFI_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -616,13 +627,13 @@ int stage_trans_launch(const float* Ppool, size_t pack_stride, const RifeTasks& 
 // ---------------------------------------------------------------------------------------
 __global__ void final_blend_kernel(const float* __restrict__ Ppool, size_t pack_stride, RifeTasks tasks,
                                    const float* __restrict__ T, const float* __restrict__ F, float* __restrict__ out,
-                                   float* __restrict__ Fdbg, int H, int W, int Hp, int Wp, int s) {
+                                   float* __restrict__ Fdbg, int H, int W, int Hp, int Wp, int s, int tp) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= H * W) return;
     const int b = blockIdx.y;
     const int X = idx % W, Y = idx / W;
     const int Hs = Hp / s, Ws = Wp / s;
-    const float* Tb = T + (size_t)b * Hs * Ws * 8;
+    const float* Tb = T + (size_t)b * Hs * Ws * 4 * tp;
     const TVal tv = t_upsample(Tb, Hs, Ws, s, Y, X);
     const size_t pb = (size_t)b * Hp * Wp + (size_t)Y * Wp + X;
     const float fs = (float)s;
@@ -644,12 +655,12 @@ __global__ void final_blend_kernel(const float* __restrict__ Ppool, size_t pack_
 }
 
 int final_blend_launch(const float* Ppool, size_t pack_stride, const RifeTasks& tasks, int B, const float* T,
-                       const float* F, float* out, float* Fdbg, int H, int W, int Hp, int Wp, int s,
+                       const float* F, float* out, float* Fdbg, int H, int W, int Hp, int Wp, int s, int tp,
                        hipStream_t st) {
     dim3 grid(cdiv(H * W, 256), B);
     TraceScope ts("final_blend", st);
     hipLaunchKernelGGL(final_blend_kernel, grid, dim3(256), 0, st, Ppool, pack_stride, tasks, T, F, out, Fdbg, H, W,
-                       Hp, Wp, s);
+                       Hp, Wp, s, tp);
     VFI_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -698,28 +709,80 @@ int planar4_up_launch(const float* X1, float* X, int B, int Hp, int Wp, int u, i
     return 0;
 }
 
-// T [B][2][u*Hp][u*Wp][4] -> T1 [B][2][Hp][Wp][4]: interpolate(tmp, scale_factor=1/u); flow components * (1/u)
-__global__ void t_down_kernel(const float* __restrict__ T, float* __restrict__ T1, int Hp, int Wp, int u) {
+// T [B][tp][u*Hp][u*Wp][4] -> T1 [B][tp][Hp][Wp][4]: interpolate(tmp, scale_factor=1/u); plane 0 (flow) * (1/u)
+__global__ void t_down_kernel(const float* __restrict__ T, float* __restrict__ T1, int Hp, int Wp, int u, int tp) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Hp * Wp) return;
+    const int pl = blockIdx.y, b = blockIdx.z;
+    const int X = idx % Wp, Y = idx / Wp;
+    const int Hs = Hp * u, Ws = Wp * u;
+    const float4* src = (const float4*)T + ((size_t)b * tp + pl) * Hs * Ws;
+    const Bil by = bil_index(Y, (float)u, Hs), bx = bil_index(X, (float)u, Ws);
+    const float4 a = src[(size_t)by.i0 * Ws + bx.i0], bb = src[(size_t)by.i0 * Ws + bx.i1];
+    const float4 c = src[(size_t)by.i1 * Ws + bx.i0], d = src[(size_t)by.i1 * Ws + bx.i1];
+    const float wy0 = by.w0, wy1 = by.w1, wx0 = bx.w0, wx1 = bx.w1;
+#define VFI_BL(A, B, C, D) \
+    __fadd_rn(__fmul_rn(wy0, __fadd_rn(__fmul_rn(wx0, A), __fmul_rn(wx1, B))), __fmul_rn(wy1, __fadd_rn(__fmul_rn(wx0, C), __fmul_rn(wx1, D))))
+    float4 r;
+    r.x = VFI_BL(a.x, bb.x, c.x, d.x);
+    r.y = VFI_BL(a.y, bb.y, c.y, d.y);
+    r.z = VFI_BL(a.z, bb.z, c.z, d.z);
+    r.w = VFI_BL(a.w, bb.w, c.w, d.w);
+#undef VFI_BL
+    if (pl == 0) {
+        const float sc = 1.0f / (float)u;
+        r = make_float4(r.x * sc, r.y * sc, r.z * sc, r.w * sc);
+    }
+    ((float4*)T1)[((size_t)b * tp + pl) * Hp * Wp + idx] = r;
+}
+
+int t_down_launch(const float* T, float* T1, int B, int Hp, int Wp, int u, int tp, hipStream_t st) {
+    VFI_REQUIRE(u == 2 || u == 4, "t_down: factor %d", u);
+    dim3 grid(cdiv(Hp * Wp, 256), tp, B);
+    TraceScope ts("t_down", st);
+    hipLaunchKernelGGL(t_down_kernel, grid, dim3(256), 0, st, T, T1, Hp, Wp, u, tp);
+    VFI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// arch 4.26: the block also returns 8 feature channels (tmp[:, 5:13] after interpolate(tmp, scale), rife_arch.py:267-273)
+// that are fed to the next block.  T has 4 planes: (flow 4 | mask, f0, f1, f2 | f3..f6 | f7, -, -, -);
+// FEAT [B][2][Hp][Wp][4] = those 8 channels up-resized by s.
+__global__ void feat_up_kernel(const float* __restrict__ T, float* __restrict__ FEAT, int Hp, int Wp, int s) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= Hp * Wp) return;
     const int b = blockIdx.y;
     const int X = idx % Wp, Y = idx / Wp;
-    const int Hs = Hp * u, Ws = Wp * u;
-    const float* Tb = T + (size_t)b * Hs * Ws * 8;
-    const Bil by = bil_index(Y, (float)u, Hs), bx = bil_index(X, (float)u, Ws);
-    const TVal v = t_bilerp(t_read(Tb, Hs, Ws, by.i0, bx.i0), t_read(Tb, Hs, Ws, by.i0, bx.i1), t_read(Tb, Hs, Ws, by.i1, bx.i0),
-                            t_read(Tb, Hs, Ws, by.i1, bx.i1), by.w0, by.w1, bx.w0, bx.w1);
-    const float sc = 1.0f / (float)u;
-    float* o = T1 + (size_t)b * Hp * Wp * 8;
-    ((float4*)o)[idx] = make_float4(v.f.x * sc, v.f.y * sc, v.f.z * sc, v.f.w * sc);
-    ((float4*)o)[(size_t)Hp * Wp + idx] = make_float4(v.m, 0.f, 0.f, 0.f);
+    const int Hs = Hp / s, Ws = Wp / s;
+    const float4* src = (const float4*)T + (size_t)b * 4 * Hs * Ws;
+    const size_t ps = (size_t)Hs * Ws;
+    const float rs = 1.0f / (float)s;
+    const Bil by = s == 1 ? Bil{Y, Y, 1.f, 0.f} : bil_index(Y, rs, Hs);
+    const Bil bx = s == 1 ? Bil{X, X, 1.f, 0.f} : bil_index(X, rs, Ws);
+    const size_t o00 = (size_t)by.i0 * Ws + bx.i0, o01 = (size_t)by.i0 * Ws + bx.i1;
+    const size_t o10 = (size_t)by.i1 * Ws + bx.i0, o11 = (size_t)by.i1 * Ws + bx.i1;
+    const float wy0 = by.w0, wy1 = by.w1, wx0 = bx.w0, wx1 = bx.w1;
+    float v[12];
+#define VFI_BL(A, B, C, D) \
+    (s == 1 ? (A) : __fadd_rn(__fmul_rn(wy0, __fadd_rn(__fmul_rn(wx0, A), __fmul_rn(wx1, B))), __fmul_rn(wy1, __fadd_rn(__fmul_rn(wx0, C), __fmul_rn(wx1, D)))))
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        const float4 a = src[(1 + pl) * ps + o00], bb = src[(1 + pl) * ps + o01], c = src[(1 + pl) * ps + o10], d = src[(1 + pl) * ps + o11];
+        v[4 * pl] = VFI_BL(a.x, bb.x, c.x, d.x);
+        v[4 * pl + 1] = VFI_BL(a.y, bb.y, c.y, d.y);
+        v[4 * pl + 2] = VFI_BL(a.z, bb.z, c.z, d.z);
+        v[4 * pl + 3] = VFI_BL(a.w, bb.w, c.w, d.w);
+    }
+#undef VFI_BL
+    float4* o = (float4*)FEAT + (size_t)b * 2 * Hp * Wp + idx;
+    o[0] = make_float4(v[1], v[2], v[3], v[4]);
+    o[(size_t)Hp * Wp] = make_float4(v[5], v[6], v[7], v[8]);
 }
 
-int t_down_launch(const float* T, float* T1, int B, int Hp, int Wp, int u, hipStream_t st) {
-    VFI_REQUIRE(u == 2 || u == 4, "t_down: factor %d", u);
+int feat_up_launch(const float* T, float* FEAT, int B, int Hp, int Wp, int s, hipStream_t st) {
     dim3 grid(cdiv(Hp * Wp, 256), B);
-    TraceScope ts("t_down", st);
-    hipLaunchKernelGGL(t_down_kernel, grid, dim3(256), 0, st, T, T1, Hp, Wp, u);
+    TraceScope ts("feat_up", st);
+    hipLaunchKernelGGL(feat_up_kernel, grid, dim3(256), 0, st, T, FEAT, Hp, Wp, s);
     VFI_CHECK_HIP(hipGetLastError());
     return 0;
 }

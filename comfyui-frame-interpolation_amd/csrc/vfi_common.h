@@ -70,6 +70,7 @@ struct ConvArgs {
     int out_mode;          // 0: NHWC store; 1 (grouped only): PixelShuffle(2) of the transposed conv, planar4
                            //    [N][2][4*Hout][4*Wout][4] (channel c of Cout/4 -> plane c/4, component c%4);
                            //    2 (grouped only): plain transposed-conv output, NHWC [N][2*Hout][2*Wout][out_cs]
+    int out_planes;        // out_mode 1: planes per image of the planar4 output (0 = 2)
     int pad_replicate;     // 0: zero padding; 1: replicate (edge clamp) padding of the input
     const float* prelu;    // [Cout_p] per-channel negative slopes (act == 3)
     float post_scale, post_shift;  // y = act(...) * post_scale + post_shift  (post_scale == 0 means "not set" = 1, 0)

@@ -32,7 +32,7 @@ MAX_LIB_BATCH = 16  # kMaxTasks in csrc/rife_ops.h
 
 
 class RifeEngine:
-    """Device-resident RIFE network (arch 4.7 = rife47/rife49, 4.17 = rife417) + frame cache behind the C ABI."""
+    """Device-resident RIFE network (arch 4.7 = rife47/rife49, 4.17 = rife417, 4.26 = rife426) + frame cache behind the C ABI."""
 
     def __init__(self, state_dict, arch_ver="4.7", device=None):
         if arch_ver not in SUPPORTED_ARCH:

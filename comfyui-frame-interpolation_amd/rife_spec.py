@@ -22,9 +22,9 @@ CKPT_NAME_VER_DICT = {
     "sudo_rife4_269.662_testV1_scale1.pth": "4.0",
 }
 # architectures the HIP path implements so far
-SUPPORTED_ARCH = ("4.7", "4.17")
+SUPPORTED_ARCH = ("4.7", "4.17", "4.26")
 # architecture -> code handed to vfi_rife_create
-ARCH_CODE = {"4.7": 47, "4.17": 417}
+ARCH_CODE = {"4.7": 47, "4.17": 417, "4.26": 426}
 
 # (in_planes, c) per IFBlock, rife_arch.py:410-413
 RIFE47_BLOCKS = ((7 + 8, 192), (8 + 4 + 8, 128), (8 + 4 + 8, 96), (8 + 4 + 8, 64))
@@ -32,7 +32,8 @@ N_RESCONV = 8
 LASTCONV_OUT = 4 * 6  # ConvTranspose2d(c, 4*6, 4, 2, 1) + PixelShuffle(2), rife_arch.py:215-218
 
 
-def _block_shapes(d, blocks):
+def _block_shapes(d, blocks, last_out=None):
+    last_out = last_out or LASTCONV_OUT
     for b, (cin, c) in enumerate(blocks):
         p = f"block{b}."
         d[p + "conv0.0.0.weight"] = (c // 2, cin, 3, 3)
@@ -44,8 +45,8 @@ def _block_shapes(d, blocks):
             d[q + "beta"] = (1, c, 1, 1)
             d[q + "conv.weight"] = (c, c, 3, 3)
             d[q + "conv.bias"] = (c,)
-        d[p + "lastconv.0.weight"] = (c, LASTCONV_OUT, 4, 4)
-        d[p + "lastconv.0.bias"] = (LASTCONV_OUT,)
+        d[p + "lastconv.0.weight"] = (c, last_out, 4, 4)
+        d[p + "lastconv.0.bias"] = (last_out,)
 
 
 def rife47_shapes():
@@ -75,8 +76,24 @@ def rife417_shapes():
     return d
 
 
+# rife_arch.py:451-457 (IFNet.__init__, arch "4.26"): 5 blocks, the later ones also take the 8 feature channels the
+# previous block returned; lastconv = ConvTranspose2d(c, 4*13, 4, 2, 1) + PixelShuffle(2) (:221-235); encoder = Head (:378-398)
+RIFE426_BLOCKS = ((7 + 8, 192), (8 + 4 + 8 + 8, 128), (8 + 4 + 8 + 8, 96), (8 + 4 + 8 + 8, 64), (8 + 4 + 8 + 8, 32))
+
+
+def rife426_shapes():
+    d = OrderedDict()
+    _block_shapes(d, RIFE426_BLOCKS, 4 * 13)
+    for i, (co, ci) in enumerate(((16, 3), (16, 16), (16, 16))):
+        d[f"encode.cnn{i}.weight"] = (co, ci, 3, 3)
+        d[f"encode.cnn{i}.bias"] = (co,)
+    d["encode.cnn3.weight"] = (16, 4, 4, 4)
+    d["encode.cnn3.bias"] = (4,)
+    return d
+
+
 def rife_shapes(arch_ver="4.7"):
-    return {"4.7": rife47_shapes, "4.17": rife417_shapes}[arch_ver]()
+    return {"4.7": rife47_shapes, "4.17": rife417_shapes, "4.26": rife426_shapes}[arch_ver]()
 
 
 def rife47_keys():

@@ -55,6 +55,12 @@ def rife417_synth_state_dict(seed=1234):
     return synth_state_dict(rife417_shapes(), seed)
 
 
+def rife426_synth_state_dict(seed=1234):
+    from .rife_spec import rife426_shapes
+
+    return synth_state_dict(rife426_shapes(), seed)
+
+
 def film_synth_state_dict(seed=1234, gain=1.2):
     """FILM: torch-default init shrinks the signal to a bias-dominated constant through ~20 LeakyReLU convs, which
     would make parity tests insensitive; weights are U(+-gain*sqrt(3/fan_in)) (roughly variance preserving), biases

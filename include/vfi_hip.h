@@ -177,12 +177,13 @@ typedef struct vfi_rife vfi_rife_t;
 
 /* Build the device-resident network from a reference checkpoint.
  * arch_ver_x10: 47 = architecture "4.7" (rife47.pth / rife49.pth, 124 tensors), 417 = "4.17" (rife417.pth, 128
- * tensors: same IFBlocks on 8 feature channels per frame, encoder Head_417, rife_arch.py:355-375,417-433).
+ * tensors: same IFBlocks on 8 feature channels per frame, encoder Head_417, rife_arch.py:355-375,417-433),
+ * 426 = "4.26" (rife426.pth, 158 tensors: 5 IFBlocks with carried block features, encoder Head, :378-398,451-457).
  * `tensors[i]` are host pointers to the state_dict tensors in the key order of rife_spec.rife_shapes(arch)
  * (== torch state_dict order of IFNet(arch)), each in the reference's own layout; `numels[i]` their element
  * counts (checked).  Replaces IFNet(arch_ver).load_state_dict(torch.load(path)) + .to(device),
  * vfi_models/rife/__init__.py:129-135. */
-vfi_rife_t* vfi_rife_create(int arch_ver_x10 /* 47 | 417 */, const float* const* tensors,
+vfi_rife_t* vfi_rife_create(int arch_ver_x10 /* 47 | 417 | 426 */, const float* const* tensors,
                             const int64_t* numels, int n_tensors);
 void vfi_rife_destroy(vfi_rife_t* net);
 

@@ -48,8 +48,9 @@ def warp(ten_input, ten_flow):
     return F.grid_sample(ten_input, g, mode="bilinear", padding_mode="border", align_corners=True)
 
 
-def ifblock(sd, prefix, x, flow, scale):
-    """rife_arch.py:237-276 for arch 4.7 (conv0 x2, 8 ResConv, deconv + PixelShuffle)."""
+def ifblock(sd, prefix, x, flow, scale, with_feat=False):
+    """rife_arch.py:237-276 for arch 4.7 / 4.17 (conv0 x2, 8 ResConv, deconv + PixelShuffle); with_feat: arch 4.26, whose
+    lastconv has 4*13 channels and which also returns tmp[:, 5:] (:267-273)."""
     x = F.interpolate(x, scale_factor=1.0 / scale, mode="bilinear", align_corners=False)
     if flow is not None:
         flow = F.interpolate(flow, scale_factor=1.0 / scale, mode="bilinear", align_corners=False) * 1.0 / scale
@@ -64,6 +65,8 @@ def ifblock(sd, prefix, x, flow, scale):
     tmp = F.conv_transpose2d(feat, sd[p + "lastconv.0.weight"], sd[p + "lastconv.0.bias"], 2, 1)
     tmp = F.pixel_shuffle(tmp, 2)
     tmp = F.interpolate(tmp, scale_factor=scale, mode="bilinear", align_corners=False)
+    if with_feat:
+        return tmp[:, :4] * scale, tmp[:, 4:5], tmp[:, 5:]
     return tmp[:, :4] * scale, tmp[:, 4:5]
 
 
@@ -86,6 +89,8 @@ def ifnet47_forward(sd, img0, img1, timestep, scale_list=(8, 4, 2, 1), return_au
     encoder and the channel counts only), ensemble=False (the only path the node reaches, App. C1).
 
     img0/img1: [B,3,H,W] f32;  timestep: [B,1,1,1] tensor.  Returns [B,3,H,W]."""
+    if arch == "4.26":
+        return ifnet426_forward(sd, img0, img1, timestep, scale_list, return_aux)
     enc = {"4.7": encode, "4.17": encode417}[arch]
     img0 = torch.clamp(img0, 0, 1)
     img1 = torch.clamp(img1, 0, 1)
@@ -129,6 +134,40 @@ def ifnet47_forward(sd, img0, img1, timestep, scale_list=(8, 4, 2, 1), return_au
     return (out, aux) if return_aux else out
 
 
+def ifnet426_forward(sd, img0, img1, timestep, scale_list=(16, 8, 4, 2, 1), return_aux=False):
+    """rife_arch.py:465-732, arch "4.26" (:451-457 five blocks, Head encoder :378-398; live path :501-503,512-526,
+    :555-583,698-705): every block also returns 8 feature channels that are appended to the next block's input."""
+    img0 = torch.clamp(img0, 0, 1)
+    img1 = torch.clamp(img1, 0, 1)
+    n, c, h, w = img0.shape
+    ph = ((h - 1) // 64 + 1) * 64
+    pw = ((w - 1) // 64 + 1) * 64
+    img0 = F.pad(img0, (0, pw - w, 0, ph - h))
+    img1 = F.pad(img1, (0, pw - w, 0, ph - h))
+    timestep = timestep.repeat(1, 1, img0.shape[2], img0.shape[3])
+    f0 = encode417(sd, img0[:, :3])   # Head has Head_417's structure (16 / 4 channels instead of 32 / 8)
+    f1 = encode417(sd, img1[:, :3])
+    warped_img0, warped_img1 = img0, img1
+    flow = mask = feat = None
+    aux = []
+    for i in range(5):
+        p = f"block{i}."
+        if flow is None:
+            flow, mask, feat = ifblock(sd, p, torch.cat((img0[:, :3], img1[:, :3], f0, f1, timestep), 1), None, scale_list[i], True)
+        else:
+            x = torch.cat((warped_img0[:, :3], warped_img1[:, :3], warp(f0, flow[:, :2]), warp(f1, flow[:, 2:4]), timestep, mask, feat), 1)
+            fd, m0, feat = ifblock(sd, p, x, flow, scale_list[i], True)
+            flow = flow + fd
+            mask = m0
+        warped_img0 = warp(img0, flow[:, :2])
+        warped_img1 = warp(img1, flow[:, 2:4])
+        if return_aux:
+            aux.append((flow.clone(), mask.clone(), feat.clone()))
+    mask = torch.sigmoid(mask)
+    out = (warped_img0 * mask + warped_img1 * (1 - mask))[:, :, :h, :w]
+    return (out, aux) if return_aux else out
+
+
 # ---------------------------------------------------------------------------------------------
 # node level (vfi_models/rife/__init__.py:146-239)
 # ---------------------------------------------------------------------------------------------
@@ -157,6 +196,8 @@ def rife_vfi(sd, frames, multiplier=2, scale_factor=1.0, batch_size=1, states=No
     n_pairs = len(x) - 1
     _, tasks = rife_tasks(len(x), multiplier, states)
     scale_list = [8 / scale_factor, 4 / scale_factor, 2 / scale_factor, 1 / scale_factor]
+    if arch == "4.26":   # rife/__init__.py:155-156
+        scale_list = [16 / scale_factor] + scale_list
     results = {i: [] for i in range(n_pairs)}
     pos = 0
     with torch.inference_mode():

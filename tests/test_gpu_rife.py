@@ -212,7 +212,7 @@ def test_node_rejects_unsupported(hip_lib, sd, tmp_path, monkeypatch):
     with pytest.raises(KeyError):
         R.RIFE_VFI().vfi("nope.pth", torch.zeros(2, 8, 8, 3))
     with pytest.raises(NotImplementedError):
-        R.RifeEngine(sd, "4.26")
+        R.RifeEngine(sd, "4.0")
 
 
 def test_config0_anime_pair_vs_reference_node(hip_lib, sd, golden_dir, tmp_path, monkeypatch):
@@ -335,6 +335,88 @@ def test_node417_against_reference_golden(hip_lib, sd417, golden_dir, tmp_path, 
     R._model_cache.clear()
     g = np.load(os.path.join(golden_dir, "rife417_node.npz"))
     (out,) = R.RIFE_VFI().vfi("rife417.pth", torch.from_numpy(g["frames"]), **kw)
+    R._model_cache.clear()
+    want = torch.from_numpy(g[name])
+    assert out.shape == want.shape and (out - want).abs().max().item() <= TOL, describe_diff(out, want, name)
+
+
+# ---- arch 4.26 (rife426.pth): Head encoder, 5 IFBlocks at scales [16,8,4,2,1], 8 block-feature channels carried on ----
+
+@pytest.fixture(scope="module")
+def sd426():
+    return synth.rife426_synth_state_dict(1234)
+
+
+@pytest.fixture(scope="module")
+def engine426(hip_lib, sd426):
+    from cfi_amd.rife import RifeEngine
+
+    e = RifeEngine(sd426, "4.26")
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("h,w,sf", [(64, 64, 1.0), (100, 150, 1.0), (270, 480, 1.0), (120, 200, 0.5), (120, 200, 2.0), (70, 100, 4.0)])
+def test_rife426_against_oracle(engine426, sd426, h, w, sf):
+    from cfi_amd.rife import run_tasks
+
+    frames = synth.smooth_frames(2, h, w, seed=4, shift=3.0)
+    tasks = [(0, 0.5), (0, 0.2)]
+    got = run_tasks(engine426, frames, tasks, batch_size=2, scale_factor=sf)
+    x = frames.permute(0, 3, 1, 2)
+    ts = torch.tensor([0.5, 0.2]).view(-1, 1, 1, 1)
+    with torch.inference_mode():
+        want = rife_oracle.ifnet47_forward(sd426, x[0:1].repeat(2, 1, 1, 1), x[1:2].repeat(2, 1, 1, 1), ts,
+                                           tuple(b / sf for b in (16.0, 8.0, 4.0, 2.0, 1.0)), arch="4.26")
+    want = want.clamp(0, 1).permute(0, 2, 3, 1)
+    assert (got - want).abs().max().item() <= TOL, describe_diff(got, want, f"rife 4.26 {h}x{w} sf={sf}")
+
+
+def test_rife426_flows_per_block(engine426, sd426):
+    """debug taps: flow after each of the 5 blocks (localises a failure)"""
+    from cfi_amd.rife import run_tasks
+
+    h, w, hp, wp = 100, 150, 128, 192
+    frames = synth.smooth_frames(2, h, w, seed=4, shift=3.0)
+    engine426.debug_keep(True)
+    try:
+        run_tasks(engine426, frames, [(0, 0.5)], batch_size=1)
+        x = frames.permute(0, 3, 1, 2)
+        with torch.inference_mode():
+            _, aux = rife_oracle.ifnet47_forward(sd426, x[0:1], x[1:2], torch.tensor([0.5]).view(1, 1, 1, 1), (16, 8, 4, 2, 1),
+                                                 return_aux=True, arch="4.26")
+        for i in range(5):
+            fl = engine426.debug_read(0, i, hp * wp * 4).view(1, hp, wp, 4).permute(0, 3, 1, 2)
+            wf = aux[i][0]
+            sl = (slice(None), slice(None), slice(0, h), slice(0, w)) if i == 4 else (slice(None),) * 4
+            assert (fl[sl] - wf[sl]).abs().max().item() <= 2e-4, describe_diff(fl[sl], wf[sl], f"flow after block {i}", chan_last=False)
+    finally:
+        engine426.debug_keep(False)
+
+
+def test_rife426_1080p(engine426, sd426):
+    from cfi_amd.rife import run_tasks
+
+    frames = synth.smooth_frames(2, 1080, 1920, seed=2, shift=4.0)
+    got = run_tasks(engine426, frames, [(0, 0.5)], batch_size=1)
+    x = frames.permute(0, 3, 1, 2)
+    with torch.inference_mode():
+        want = rife_oracle.ifnet47_forward(sd426, x[0:1], x[1:2], torch.tensor([0.5]).view(1, 1, 1, 1), (16, 8, 4, 2, 1), arch="4.26")
+    want = want.clamp(0, 1).permute(0, 2, 3, 1)
+    assert (got - want).abs().max().item() <= TOL, describe_diff(got, want, "rife 4.26 1080p")
+
+
+@pytest.mark.parametrize("name,kw", [("m2", dict(multiplier=2)), ("mlist_bs2", dict(multiplier=[3, 1], batch_size=2))])
+def test_node426_against_reference_golden(hip_lib, sd426, golden_dir, tmp_path, monkeypatch, name, kw):
+    """RIFE_VFI.vfi("rife426.pth", ...) vs the reference node's own output (tests/golden/rife426_node.npz)"""
+    import cfi_amd.rife as R
+
+    pth = tmp_path / "rife426.pth"
+    torch.save(sd426, pth)
+    monkeypatch.setattr(R, "load_file_from_github_release", lambda model_type, ckpt: str(pth))
+    R._model_cache.clear()
+    g = np.load(os.path.join(golden_dir, "rife426_node.npz"))
+    (out,) = R.RIFE_VFI().vfi("rife426.pth", torch.from_numpy(g["frames"]), **kw)
     R._model_cache.clear()
     want = torch.from_numpy(g[name])
     assert out.shape == want.shape and (out - want).abs().max().item() <= TOL, describe_diff(out, want, name)

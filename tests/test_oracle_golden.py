@@ -162,3 +162,25 @@ def test_node417_matches_reference_golden(golden_dir, name, kw):
     g = np.load(os.path.join(golden_dir, "rife417_node.npz"))
     out = rife_oracle.rife_vfi(synth.rife417_synth_state_dict(1234), torch.from_numpy(g["frames"]), arch="4.17", **kw)
     assert out.shape == g[name].shape and np.abs(out.numpy() - g[name]).max() <= TOL
+
+
+# ---- arch 4.26 (rife426.pth): goldens written by oracle/validate_rife426_vs_reference.py from the reference's IFNet("4.26")
+
+def test_ifnet426_matches_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "rife426_net_anime.npz"))
+    sd = synth.rife426_synth_state_dict(1234)
+    fr = torch.from_numpy(g["frames"])
+    ts = torch.from_numpy(g["timesteps"]).view(-1, 1, 1, 1)
+    b = ts.shape[0]
+    i0 = fr[0:1].permute(0, 3, 1, 2).repeat(b, 1, 1, 1)
+    i1 = fr[1:2].permute(0, 3, 1, 2).repeat(b, 1, 1, 1)
+    with torch.inference_mode():
+        out = rife_oracle.ifnet47_forward(sd, i0, i1, ts, (16, 8, 4, 2, 1), arch="4.26").permute(0, 2, 3, 1)
+    assert out.shape == g["out"].shape and np.abs(out.numpy() - g["out"]).max() <= TOL
+
+
+@pytest.mark.parametrize("name,kw", [("m2", dict(multiplier=2)), ("mlist_bs2", dict(multiplier=[3, 1], batch_size=2))])
+def test_node426_matches_reference_golden(golden_dir, name, kw):
+    g = np.load(os.path.join(golden_dir, "rife426_node.npz"))
+    out = rife_oracle.rife_vfi(synth.rife426_synth_state_dict(1234), torch.from_numpy(g["frames"]), arch="4.26", **kw)
+    assert out.shape == g[name].shape and np.abs(out.numpy() - g[name]).max() <= TOL
