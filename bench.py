@@ -208,8 +208,9 @@ def main():
         total_ms = sum(v[1] for v in rep.values())
         kernels = {k: {"calls": v[0], "ms": round(v[1], 3), "share": round(v[1] / total_ms, 4)} for k, v in rep.items()}
         res = {
-            "metric": "interpolated frames/sec/GPU @1080p RIFE4.7 2x" if world == 1 else
-                      "interpolated frames/sec @1080p RIFE4.7 2x (whole job)",
+            # BASELINE.json's metric; `value` is the whole-job aggregate over n_gpus (== per GPU at N=1), the per-GPU rate is
+            # config.per_gpu_frames_per_s
+            "metric": "interpolated frames/sec/GPU @1080p RIFE4.7 2x",
             "value": round(world * B * K / elapsed, 3),
             "unit": "frames/s",
             "n_gpus": world,

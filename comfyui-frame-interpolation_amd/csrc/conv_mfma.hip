@@ -19,6 +19,8 @@
 #include "vfi_common.h"
 
 #include <cstdlib>
+#include <map>
+#include <string>
 #include <cstring>
 
 namespace vfi {
@@ -307,6 +309,23 @@ int conv_launch(const ConvArgs& a, int stride, bool grouped, int variant, hipStr
     if (variant < 0 && grouped) {  // experiment hook: force a grouped (transposed-conv) tile variant
         static const char* env = getenv("VFI_GROUPED_VARIANT");
         if (env && *env) variant = atoi(env);
+    }
+    if (variant < 0 && trace_name) {  // experiment hook: VFI_VARIANT_OVERRIDE="conv0a_b3=42,resconv_c128=36" (by trace name)
+        static const std::map<std::string, int> ov = [] {
+            std::map<std::string, int> m;
+            const char* e = getenv("VFI_VARIANT_OVERRIDE");
+            std::string str = e ? e : "";
+            size_t pos = 0;
+            while (pos < str.size()) {
+                const size_t comma = str.find(',', pos), end = comma == std::string::npos ? str.size() : comma;
+                const size_t eq = str.find('=', pos);
+                if (eq != std::string::npos && eq < end) m[str.substr(pos, eq - pos)] = atoi(str.c_str() + eq + 1);
+                pos = end + 1;
+            }
+            return m;
+        }();
+        auto it = ov.find(trace_name);
+        if (it != ov.end()) variant = it->second;
     }
     if (variant < 0) variant = conv_pick_variant(a, stride, grouped);
     const ConvVariant* vp = conv_variant_lookup(variant);

@@ -227,7 +227,7 @@ def _oracle_mid(sd, fr, ts):
     return [nhwc(o)[0] for o in outs], aux
 
 
-@pytest.mark.parametrize("h,w", [(100, 150), (128, 128), (65, 200)])
+@pytest.mark.parametrize("h,w", [(100, 150), (128, 128), (65, 200), (64, 64), (20, 30)])
 def test_m2m_forward(engine, sd, h, w):
     fr = _frames(2, h, w)
     ts = [0.5, 0.25, 2 / 3]

@@ -420,3 +420,62 @@ def test_node426_against_reference_golden(hip_lib, sd426, golden_dir, tmp_path, 
     R._model_cache.clear()
     want = torch.from_numpy(g[name])
     assert out.shape == want.shape and (out - want).abs().max().item() <= TOL, describe_diff(out, want, name)
+
+
+# ---- edge cases of the node contract ---------------------------------------------------------------------------------
+
+def _node(sd, tmp_path, monkeypatch):
+    import cfi_amd.rife as R
+
+    pth = tmp_path / "rife47.pth"
+    torch.save(sd, pth)
+    monkeypatch.setattr(R, "load_file_from_github_release", lambda model_type, ckpt: str(pth))
+    R._model_cache.clear()
+    return R
+
+
+def test_node_edge_no_new_frames(hip_lib, sd, tmp_path, monkeypatch):
+    """single-frame clip, multiplier 1, and every pair skipped: nothing to synthesise, frames pass through bit-exact"""
+    R = _node(sd, tmp_path, monkeypatch)
+    fr = synth.smooth_frames(3, 40, 56, seed=1)
+    (o,) = R.RIFE_VFI().vfi("rife47.pth", fr[:1], multiplier=2)
+    assert torch.equal(o, fr[:1])
+    (o,) = R.RIFE_VFI().vfi("rife47.pth", fr, multiplier=1)
+    assert torch.equal(o, fr)
+    (o,) = R.RIFE_VFI().vfi("rife47.pth", fr, multiplier=3, optional_interpolation_states=InterpolationStateList([0, 1], True))
+    assert torch.equal(o, fr)
+    R._model_cache.clear()
+
+
+def test_node_edge_tiny_and_strided_input(hip_lib, sd, tmp_path, monkeypatch):
+    """5x7 frames (padded to 64x64 inside) and a non-contiguous RGBA input view; the input must not be modified"""
+    R = _node(sd, tmp_path, monkeypatch)
+    tiny = synth.noise_frames(2, 5, 7, seed=3)
+    (o,) = R.RIFE_VFI().vfi("rife47.pth", tiny, multiplier=2)
+    want = rife_oracle.rife_vfi(sd, tiny, multiplier=2)
+    assert o.shape == (3, 5, 7, 3) and (o - want).abs().max().item() <= TOL
+    big = synth.smooth_frames(6, 48, 80, seed=2, c=4)
+    view = big[::2, 4:44, 8:72]            # strided in N, H and W, 4 channels
+    before = big.clone()
+    (o,) = R.RIFE_VFI().vfi("rife47.pth", view, multiplier=2, batch_size=4)
+    want = rife_oracle.rife_vfi(sd, view, multiplier=2)
+    assert torch.equal(big, before)
+    assert o.shape == want.shape and (o - want).abs().max().item() <= TOL, describe_diff(o, want, "strided input")
+    assert torch.equal(o[0], view[0, ..., :3]) and torch.equal(o[-1], view[-1, ..., :3])
+    R._model_cache.clear()
+
+
+def test_engine_rejects_bad_calls(engine):
+    from cfi_amd import _lib
+
+    with pytest.raises(RuntimeError):
+        engine.configure(64, 64, 1, 4, 3.0)            # scale_factor outside the widget's values
+    with pytest.raises(RuntimeError):
+        engine.configure(64, 64, 64, 4, 1.0)           # batch above the library's task table
+    engine.configure(64, 64, 2, 4, 1.0)
+    out = torch.empty(3, 64, 64, 3, device="cuda")
+    with pytest.raises(RuntimeError):
+        engine.interpolate([0, 1, 2], [1, 2, 3], [0.5] * 3, out)   # batch above the configured maximum
+    with pytest.raises(RuntimeError):
+        engine.interpolate([0], [9], [0.5], out[:1])               # slot outside the frame cache
+    assert "slot" in _lib.last_error() or "batch" in _lib.last_error()
