@@ -37,8 +37,14 @@ def all_gather_frames(local, counts):
     if local.shape[0] != m:
         send = torch.zeros(shape, dtype=local.dtype, device=local.device)
         send[: local.shape[0]] = local
-    out = torch.empty((ws,) + shape, dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out.view(ws * m, *shape[1:]), send.contiguous())
+    if local.is_cuda and dist.get_backend() == "gloo":
+        # plumbing / test mode (several ranks on one GPU, no RCCL): stage through the host
+        host = torch.empty((ws,) + shape, dtype=local.dtype)
+        dist.all_gather_into_tensor(host.view(ws * m, *shape[1:]), send.contiguous().cpu())
+        out = host.to(local.device)
+    else:
+        out = torch.empty((ws,) + shape, dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out.view(ws * m, *shape[1:]), send.contiguous())
     return torch.cat([out[r, : counts[r]] for r in range(ws)], 0)
 
 
