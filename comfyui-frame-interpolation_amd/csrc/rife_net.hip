@@ -436,11 +436,13 @@ int vfi_rife_interpolate(vfi_rife_t* net, int B, const int* slot0, const int* sl
         }
         if (i < NB - 1) {
             const int sn = net->scales[i + 1];
-            // the fused transition kernel covers the 6-channel block output (flow + mask) of arch 4.7 / 4.17
-            fused_prev = !net->NX && u == 1 && net->up[i + 1] == 1 && s == 2 * sn && (sn == 4 || sn == 2 || sn == 1);
+            const bool on_grid = u == 1 && net->up[i + 1] == 1 && s == 2 * sn;
+            fused_prev = on_grid && (sn == 4 || sn == 2 || sn == 1 || (net->NX && sn == 8));
             if (fused_prev) {
-                if (stage_trans_launch(net->Ppool.p, net->pack_stride(), tasks, B, Tsrc, net->F.p, net->X.p, Hp, Wp,
-                                       s, sn, NF, i > 0, st))
+                if (net->NX ? stage_trans_x_launch(net->Ppool.p, net->pack_stride(), tasks, B, Tsrc, net->F.p, net->X.p, Hp, Wp, s, sn,
+                                                   i > 0, st)
+                            : stage_trans_launch(net->Ppool.p, net->pack_stride(), tasks, B, Tsrc, net->F.p, net->X.p, Hp, Wp,
+                                                 s, sn, NF, i > 0, st))
                     return -1;
             } else {
                 if (flow_up_launch(Tsrc, net->F.p, net->M.p, B, Hp, Wp, s, TP, i > 0, st)) return -1;

@@ -29,6 +29,9 @@ int flow_up_launch(const float* T, float* F, float* M, int B, int Hp, int Wp, in
 int feat_up_launch(const float* T, float* FEAT, int B, int Hp, int Wp, int s, hipStream_t st);
 int stage_trans_launch(const float* Ppool, size_t pack_stride, const RifeTasks& tasks, int B, const float* T, float* F,
                        float* X, int Hp, int Wp, int s_prev, int s_next, int NF, bool has_prev, hipStream_t st);
+// arch 4.26 (T with 4 planes, 8 carried feature channels, NF = 1); block scales 2*s_next -> s_next, s_next in {8,4,2,1}
+int stage_trans_x_launch(const float* Ppool, size_t pack_stride, const RifeTasks& tasks, int B, const float* T, float* F,
+                         float* X, int Hp, int Wp, int s_prev, int s_next, bool has_prev, hipStream_t st);
 int final_blend_launch(const float* Ppool, size_t pack_stride, const RifeTasks& tasks, int B, const float* T,
                        const float* F, float* out, float* Fdbg, int H, int W, int Hp, int Wp, int s, int tp, hipStream_t st);
 int planar4_up_launch(const float* X1, float* X, int B, int Hp, int Wp, int u, int CX, int flow_plane, hipStream_t st);

@@ -621,6 +621,160 @@ int stage_trans_launch(const float* Ppool, size_t pack_stride, const RifeTasks& 
 }
 
 // ---------------------------------------------------------------------------------------
+// fused block transition for arch 4.26: as stage_trans_kernel, plus the 8 feature channels the block returns
+// (T planes 1..3 = mask, g0..g7) which the next block takes un-warped, between mask and flow (rife_arch.py:555-583).
+// Block scales 2*SP -> SP with SP in {8, 4, 2, 1} (the first transition of 4.26 is 16 -> 8).
+// ---------------------------------------------------------------------------------------
+struct TXVal {
+    float4 f, p1, p2;   // flow delta | mask, g0, g1, g2 | g3..g6
+    float g7;
+};
+__device__ static inline TXVal tx_read(const float* __restrict__ Tb, int Hs, int Ws, int Yt, int Xt) {
+    const size_t p = (size_t)Yt * Ws + Xt, ps = (size_t)Hs * Ws;
+    TXVal v;
+    v.f = ((const float4*)Tb)[p];
+    v.p1 = ((const float4*)Tb)[ps + p];
+    v.p2 = ((const float4*)Tb)[2 * ps + p];
+    v.g7 = Tb[(3 * ps + p) * 4];
+    return v;
+}
+
+template <int SP, bool HAS_PREV>
+__global__ __launch_bounds__(256) void stage_trans_x_kernel(const float* __restrict__ Ppool, size_t pack_stride,
+                                                            RifeTasks tasks, const float* __restrict__ T,
+                                                            float* __restrict__ F, float* __restrict__ Xo, int Hp,
+                                                            int Wp, int tiles_x) {
+    constexpr int SI = 2 * SP;
+    constexpr int NP = SP == 1 ? 1 : 2;
+    constexpr int OFF = SP == 1 ? 0 : SP / 2 - 1;
+    const int Hs = Hp / SP, Ws = Wp / SP;
+    const int b = blockIdx.y;
+    const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x - tile_y * tiles_x;
+    const int xl = tile_x * 16 + (threadIdx.x & 15), yl = tile_y * 16 + (threadIdx.x >> 4);
+    if (xl >= Ws || yl >= Hs) return;
+    const int Hi = Hp / SI, Wi = Wp / SI;
+    const float* Tb = T + (size_t)b * Hi * Wi * 16;
+    const float rs = 1.0f / (float)SI;
+    const Bil by0 = bil_index(yl * SP, rs, Hi), bx0 = bil_index(xl * SP, rs, Wi);
+    const TXVal t00 = tx_read(Tb, Hi, Wi, by0.i0, bx0.i0), t01 = tx_read(Tb, Hi, Wi, by0.i0, bx0.i1);
+    const TXVal t10 = tx_read(Tb, Hi, Wi, by0.i1, bx0.i0), t11 = tx_read(Tb, Hi, Wi, by0.i1, bx0.i1);
+#define VFI_BL(A, B, C, D) \
+    __fadd_rn(__fmul_rn(wy0, __fadd_rn(__fmul_rn(wx0, A), __fmul_rn(wx1, B))), __fmul_rn(wy1, __fadd_rn(__fmul_rn(wx0, C), __fmul_rn(wx1, D))))
+    // ---- phase 1: flow (+)= up(T)*SI for every pixel of the cell; keep flow, mask and features of the centre pixels
+    float4 fc[NP * NP];
+    float mc[NP * NP], gc[NP * NP][8];
+#pragma unroll 1
+    for (int dy = 0; dy < SP; ++dy) {
+        const Bil wyb = bil_index(yl * SP + dy, rs, Hi);
+        const float wy0 = wyb.w0, wy1 = wyb.w1;
+#pragma unroll
+        for (int dx = 0; dx < SP; ++dx) {
+            const Bil wxb = bil_index(xl * SP + dx, rs, Wi);
+            const float wx0 = wxb.w0, wx1 = wxb.w1;
+            const size_t pb = (size_t)b * Hp * Wp + (size_t)(yl * SP + dy) * Wp + xl * SP + dx;
+            const float fs = (float)SI;
+            float4 f = make_float4(VFI_BL(t00.f.x, t01.f.x, t10.f.x, t11.f.x) * fs, VFI_BL(t00.f.y, t01.f.y, t10.f.y, t11.f.y) * fs,
+                                   VFI_BL(t00.f.z, t01.f.z, t10.f.z, t11.f.z) * fs, VFI_BL(t00.f.w, t01.f.w, t10.f.w, t11.f.w) * fs);
+            if (HAS_PREV) {
+                const float4 o = ((const float4*)F)[pb];
+                f = make_float4(o.x + f.x, o.y + f.y, o.z + f.z, o.w + f.w);
+            }
+            ((float4*)F)[pb] = f;
+            const int cy = dy - OFF, cx = dx - OFF;
+            if (cy >= 0 && cy < NP && cx >= 0 && cx < NP) {
+                const float m = VFI_BL(t00.p1.x, t01.p1.x, t10.p1.x, t11.p1.x);
+                const float g[8] = {VFI_BL(t00.p1.y, t01.p1.y, t10.p1.y, t11.p1.y), VFI_BL(t00.p1.z, t01.p1.z, t10.p1.z, t11.p1.z),
+                                    VFI_BL(t00.p1.w, t01.p1.w, t10.p1.w, t11.p1.w), VFI_BL(t00.p2.x, t01.p2.x, t10.p2.x, t11.p2.x),
+                                    VFI_BL(t00.p2.y, t01.p2.y, t10.p2.y, t11.p2.y), VFI_BL(t00.p2.z, t01.p2.z, t10.p2.z, t11.p2.z),
+                                    VFI_BL(t00.p2.w, t01.p2.w, t10.p2.w, t11.p2.w), VFI_BL(t00.g7, t01.g7, t10.g7, t11.g7)};
+#pragma unroll
+                for (int q = 0; q < NP * NP; ++q)   // static indices only (cy, cx depend on the rolled dy)
+                    if (q == cy * NP + cx) {
+                        fc[q] = f;
+                        mc[q] = m;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) gc[q][j] = g[j];
+                    }
+            }
+        }
+    }
+#undef VFI_BL
+    // ---- phase 2: warp both frame packs at the centre pixels, down-resize (weights 1/2), write X
+    const float* P0 = Ppool + (size_t)tasks.slot0[b] * pack_stride;
+    const float* P1 = Ppool + (size_t)tasks.slot1[b] * pack_stride;
+    const size_t hi_off = (size_t)Hp * Wp * 4;
+    const float tstep = tasks.t[b];
+    const WarpGeo g = make_warp_geo(Wp, Hp);
+    constexpr int NC = 28, NR = 32;   // img 6, features 8, timestep, mask, carried 8, flow 4 (+4 zero)
+    float r[NR], row[NC], o[NC];
+#pragma unroll
+    for (int c = 0; c < NR; ++c) r[c] = 0.f;
+#pragma unroll 1
+    for (int k = 0; k < NP * NP; ++k) {
+        const int dy = k / NP, dx = k % NP;
+        float4 f = fc[0];
+        float m = mc[0];
+        float gg[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gg[j] = gc[0][j];
+#pragma unroll
+        for (int q = 1; q < NP * NP; ++q) {
+            if (k == q) {
+                f = fc[q];
+                m = mc[q];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) gg[j] = gc[q][j];
+            }
+        }
+        const int Y = yl * SP + OFF + dy, X = xl * SP + OFF + dx;
+        const Tap4 t0 = warp_taps(g, X, Y, f.x, f.y);
+        const Tap4 t1 = warp_taps(g, X, Y, f.z, f.w);
+        float4 a_lo, b_lo, a_hi[1], b_hi[1];
+        sample_pack<1>(P0, hi_off, t0, a_lo, a_hi);
+        sample_pack<1>(P1, hi_off, t1, b_lo, b_hi);
+        cat_inputs<1>(o, a_lo, b_lo, a_hi, b_hi, tstep);
+        o[15] = m;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[16 + j] = gg[j];
+        o[24] = f.x; o[25] = f.y; o[26] = f.z; o[27] = f.w;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) row[c] = dx == 0 ? o[c] : __fadd_rn(0.5f * row[c], 0.5f * o[c]);
+        if (dx == NP - 1) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) r[c] = dy == 0 ? row[c] : __fadd_rn(0.5f * r[c], 0.5f * row[c]);
+        }
+    }
+    const float inv_s = 1.0f / (float)SP;
+#pragma unroll
+    for (int c = NC - 4; c < NC; ++c) r[c] = r[c] * inv_s;
+    float4* op = (float4*)Xo + (size_t)b * (NR / 4) * Hs * Ws + (size_t)yl * Ws + xl;
+#pragma unroll
+    for (int q = 0; q < NR / 4; ++q) op[(size_t)q * Hs * Ws] = make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
+}
+
+int stage_trans_x_launch(const float* Ppool, size_t pack_stride, const RifeTasks& tasks, int B, const float* T, float* F,
+                         float* X, int Hp, int Wp, int s_prev, int s_next, bool has_prev, hipStream_t st) {
+    VFI_REQUIRE(s_prev == 2 * s_next && (s_next == 8 || s_next == 4 || s_next == 2 || s_next == 1),
+                "stage_trans_x: scales %d -> %d not on the fused path", s_prev, s_next);
+    const int Hs = Hp / s_next, Ws = Wp / s_next;
+    const int tiles_x = cdiv(Ws, 16), tiles_y = cdiv(Hs, 16);
+    dim3 grid(tiles_x * tiles_y, B);
+    TraceScope ts("stage_trans", st);
+#define VFI_ST(SPV, HP) \
+    hipLaunchKernelGGL((stage_trans_x_kernel<SPV, HP>), grid, dim3(256), 0, st, Ppool, pack_stride, tasks, T, F, X, Hp, Wp, tiles_x)
+#define VFI_ST2(SPV) \
+    do { if (has_prev) VFI_ST(SPV, true); else VFI_ST(SPV, false); } while (0)
+    if (s_next == 8) VFI_ST2(8);
+    else if (s_next == 4) VFI_ST2(4);
+    else if (s_next == 2) VFI_ST2(2);
+    else VFI_ST2(1);
+#undef VFI_ST2
+#undef VFI_ST
+    VFI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
 // last stage fused with the output: flow += tmp*s, mask = tmp[4], warp both images,
 // sigmoid blend, crop to HxW, node-level clamp(0,1)            rife_arch.py:703-704,721-723,732
 //                                                               rife/__init__.py:207

@@ -43,4 +43,15 @@ if __name__ == "__main__":
         flop, _ = eng.work_per_task()
         print(f"RIFE {arch}: {dt * 1e3:.2f} ms per step of {B} -> {B / dt:.1f} interpolated 1080p frames/s, "
               f"{flop * B / dt / 1e12:.1f} TFLOP/s over the whole network ({flop / 1e9:.1f} GFLOP/frame)", flush=True)
+        if "--split" in sys.argv:
+            from cfi_amd import _lib
+            lib = _lib.load()
+            lib.vfi_trace_reset(); lib.vfi_trace_enable(1)
+            step()
+            torch.cuda.synchronize()
+            lib.vfi_trace_enable(0)
+            rep = _lib.trace_report()
+            tot = sum(v[1] for v in rep.values())
+            print("   " + ", ".join(f"{k} {v[1]:.2f}" for k, v in sorted(rep.items(), key=lambda kv: -kv[1][1])) + f"  (sum {tot:.2f} ms)")
+            lib.vfi_trace_reset()
         eng.close()
