@@ -54,10 +54,18 @@ __device__ static inline void splat_weights(float fx, float fy, int& x0, int& y0
     w[3] = __fmul_rn(__fsub_rn(fx, (float)x0), __fsub_rn(fy, (float)y0));   // south-east
 }
 
+// LDS accumulator layout is planar, acc[c][pixel] (64 consecutive targets = 64 different banks per ds_add_f32); NCT > 0
+// fixes the channel count at compile time (M2M: 4, one float4 load per source).  Measured against the interleaved
+// [pixel][c] layout: no change (179 vs 180 us per [1,1088,1920,4] splat, profiles/r01b_splat_bench_v3.txt) — the kernel is
+// bound by the ds_add_f32 rate itself: 37.8 M atomic lanes in 179 us = 0.34 lanes per clock per CU, independent of the
+// flow magnitude (sigma 0 ... 8 px), of bank conflicts and of the window size.
+template <int NCT>
 __global__ __launch_bounds__(256) void softsplat_tile_kernel(const float* __restrict__ in, const float* __restrict__ flow,
                                                              float* __restrict__ out, const unsigned* __restrict__ absmax_bits,
-                                                             int H, int W, int C, int c0, int nc, int tiles_x, int tiles_y) {
-    __shared__ float acc[SPLAT_T * SPLAT_T * SPLAT_CMAX];
+                                                             int H, int W, int C, int c0, int nc_rt, int tiles_x, int tiles_y) {
+    constexpr int PLANE = SPLAT_T * SPLAT_T;
+    const int nc = NCT > 0 ? NCT : nc_rt;
+    __shared__ float acc[PLANE * (NCT > 0 ? NCT : SPLAT_CMAX)];
     const int tid = threadIdx.x;
     const int n = blockIdx.x / (tiles_x * tiles_y);
     const int trem = blockIdx.x - n * tiles_x * tiles_y;
@@ -103,14 +111,28 @@ __global__ __launch_bounds__(256) void softsplat_tile_kernel(const float* __rest
             const int lx = x0 - X0, ly = y0 - Y0;                         // tile-local north-west target
             if (lx < -1 || lx >= SPLAT_T || ly < -1 || ly >= SPLAT_T) continue;
             const float* ip = in + sp * C + c0;
+            float iv[NCT > 0 ? NCT : 1];
+            if (NCT == 4 && (C & 3) == 0 && (c0 & 3) == 0) {
+                const float4 t4 = *(const float4*)ip;
+                iv[0] = t4.x; iv[1 % (NCT > 0 ? NCT : 1)] = t4.y; iv[2 % (NCT > 0 ? NCT : 1)] = t4.z; iv[3 % (NCT > 0 ? NCT : 1)] = t4.w;
+            } else if (NCT > 0) {
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) iv[c] = ip[c];
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int tx_ = lx + (k & 1), ty_ = ly + (k >> 1);
                 // inside this tile and inside the image (the reference's per-target bounds check)
                 if (tx_ < 0 || tx_ >= SPLAT_T || ty_ < 0 || ty_ >= SPLAT_T || X0 + tx_ >= W || Y0 + ty_ >= H) continue;
-                float* a = &acc[(ty_ * SPLAT_T + tx_) * nc];
-                for (int c = 0; c < nc; ++c)
-                    __hip_atomic_fetch_add(a + c, __fmul_rn(ip[c], w[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                float* a = &acc[ty_ * SPLAT_T + tx_];
+                if (NCT > 0) {
+#pragma unroll
+                    for (int c = 0; c < NCT; ++c)
+                        __hip_atomic_fetch_add(a + c * PLANE, __fmul_rn(iv[c], w[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else {
+                    for (int c = 0; c < nc; ++c)
+                        __hip_atomic_fetch_add(a + c * PLANE, __fmul_rn(ip[c], w[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
         }
     }
@@ -118,7 +140,7 @@ __global__ __launch_bounds__(256) void softsplat_tile_kernel(const float* __rest
     for (int i = tid; i < SPLAT_T * SPLAT_T * nc; i += 256) {
         const int pix = i / nc, c = i - pix * nc;
         const int y = Y0 + pix / SPLAT_T, x = X0 + pix % SPLAT_T;
-        if (y < H && x < W) out[(nbase + (size_t)y * W + x) * C + c0 + c] = acc[i];
+        if (y < H && x < W) out[(nbase + (size_t)y * W + x) * C + c0 + c] = acc[c * PLANE + pix];
     }
 }
 
@@ -160,8 +182,12 @@ int softsplat_sum_launch(const float* in, const float* flow, float* out, int N, 
     for (int c0 = 0; c0 < C; c0 += SPLAT_CMAX) {
         const int nc = C - c0 < SPLAT_CMAX ? C - c0 : SPLAT_CMAX;
         TraceScope ts("softsplat_sum", s);
-        hipLaunchKernelGGL(softsplat_tile_kernel, dim3(N * tiles_x * tiles_y), dim3(256), 0, s, in, flow, out, d_absmax, H, W,
-                           C, c0, nc, tiles_x, tiles_y);
+        if (nc == 4)
+            hipLaunchKernelGGL(softsplat_tile_kernel<4>, dim3(N * tiles_x * tiles_y), dim3(256), 0, s, in, flow, out, d_absmax, H,
+                               W, C, c0, nc, tiles_x, tiles_y);
+        else
+            hipLaunchKernelGGL(softsplat_tile_kernel<0>, dim3(N * tiles_x * tiles_y), dim3(256), 0, s, in, flow, out, d_absmax, H,
+                               W, C, c0, nc, tiles_x, tiles_y);
     }
     {
         TraceScope ts("splat_far", s);

@@ -1,5 +1,6 @@
 #!/bin/bash
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_gpu_rife.py -x -q -m gpu -k "426" 2>&1 | tail -12 | tee gpurun_out/gpu_tests.log
-timeout 200 python tools/rife_arch_bench.py --split 2>&1 | grep -A1 "^RIFE 4.26" | tee gpurun_out/rife_arch_bench2.log
+timeout 300 python -m pytest tests/test_gpu_m2m_ops.py -x -q -m gpu 2>&1 | tail -3
+timeout 200 python tools/splat_bench.py 2>&1 | grep "softsplat" | tee gpurun_out/splat_bench_v3.log
+timeout 200 python tools/m2m_bench.py 2>&1 | grep -E "prepare|softsplat|splat_absmax" | tee -a gpurun_out/splat_bench_v3.log

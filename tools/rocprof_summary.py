@@ -37,7 +37,12 @@ def pmc(db, sub=None):
 
 if __name__ == "__main__":
     mode, db = sys.argv[1], sys.argv[2]
-    db = glob.glob(db)[0]
+    import os
+    cands = glob.glob(db) if not os.path.isdir(db) else []
+    if not cands:  # a directory (or a pattern that missed): look for the rocpd database below it
+        root = db if os.path.isdir(db) else os.path.dirname(db.split('*')[0]) or '.'
+        cands = sorted(glob.glob(os.path.join(root, '**', '*_results.db'), recursive=True))
+    db = cands[0]
     if mode == "stats":
         stats(db)
     else:
