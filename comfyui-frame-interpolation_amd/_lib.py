@@ -82,6 +82,11 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run `python __graft_entry__.py build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the VFI hot path.")
+    # torch ships its own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7 — the same SONAME as the ROCm
+    # install this library was linked against).  Whichever is mapped first serves both; if ours came first, torch would
+    # run on a runtime it was not built with and the second initialisation finds no device.  So: torch first, always.
+    import torch  # noqa: F401
+
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch

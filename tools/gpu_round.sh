@@ -1,6 +1,4 @@
 #!/bin/bash
 export TMPDIR=/tmp
-mkdir -p gpurun_out
-timeout 300 python -m pytest tests/test_gpu_m2m_ops.py -x -q -m gpu 2>&1 | tail -3
-timeout 200 python tools/splat_bench.py 2>&1 | grep "softsplat" | tee gpurun_out/splat_bench_v3.log
-timeout 200 python tools/m2m_bench.py 2>&1 | grep -E "prepare|softsplat|splat_absmax" | tee -a gpurun_out/splat_bench_v3.log
+timeout 200 python -c "import __graft_entry__ as g; g.build(); g.smoke()" 2>&1 | tail -2
+timeout 200 python __graft_entry__.py smoke 2>&1 | tail -1
