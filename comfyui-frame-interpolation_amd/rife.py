@@ -13,6 +13,7 @@ Differences that do not change results:
     float32 warns and computes in float32 (the parity contract is fp32, |d| <= 1e-3).
 """
 import ctypes as C
+import os
 import pathlib
 import typing
 import warnings
@@ -29,6 +30,15 @@ from .schedule import InterpolationStateList, rife_output_plan, rife_task_list, 
 MODEL_TYPE = "rife"
 DTYPE_OPTIONS = ["float32", "float16", "bfloat16"]
 MAX_LIB_BATCH = 16  # kMaxTasks in csrc/rife_ops.h
+# Tasks are independent and every task's arithmetic is the same whatever it is batched with (only the conv tile variant,
+# i.e. the fp32 summation order, may depend on the launch size: differences ~1e-6), so the node's `batch_size` widget (default 1, rife/__init__.py:68-71) only trades memory for speed.  288 GB of HBM make
+# that trade moot: the node runs at least this many tasks per launch (8 below 4K, 4 from 4K up; 0 = honour the widget).
+MIN_NODE_BATCH = int(os.environ.get("VFI_RIFE_MIN_BATCH", "8"))
+
+
+def effective_batch(batch_size, H, W):
+    floor_ = MIN_NODE_BATCH if H * W <= 2304 * 4096 // 2 else min(MIN_NODE_BATCH, 4)
+    return max(1, min(MAX_LIB_BATCH, max(int(batch_size), floor_)))
 
 
 class RifeEngine:
@@ -302,6 +312,7 @@ class RIFE_VFI:
         # ahead of the copies that fill it
         passthrough = prefault_async(out)
         passthrough += copy_rows_async(out, src_rows, frames, src_idx)
+        batch_size = effective_batch(batch_size, frames.shape[1], frames.shape[2])
         rank, ws = world()
         if ws > 1:
             lo, hi = shard_tasks(tasks, rank, ws)

@@ -1,6 +1,6 @@
 """-m gpu: the N>1 path of the three node classes, for real — 2 ranks (gloo rendezvous, both on the one GPU of the box)
-shard the pairs / tasks, interpolate with the HIP engines and all-gather the new frames; every rank must return exactly
-what a single process returns (sharding must not change any pixel: tasks are independent)."""
+shard the pairs / tasks, interpolate with the HIP engines and all-gather the new frames; every rank must return what a
+single process returns (tasks are independent; only fp32 summation order may differ, 2e-5)."""
 import os
 import socket
 import sys
@@ -80,6 +80,7 @@ def test_two_ranks_equal_single_process(hip_lib, tmp_path):
         for k, want in single.items():
             g = got[rank][k]
             assert g.shape == want.shape, (rank, k, g.shape, want.shape)
-            # identical kernels on identical inputs; the M2M splat accumulates with LDS atomics (order not fixed) -> 1e-5 there
-            tol = 2e-5 if k.startswith("m2m") else 0.0
+            # same arithmetic per task; the conv tile variant (fp32 summation order) can depend on how many tasks share a
+            # launch, and the M2M splat accumulates with LDS atomics (order not fixed)
+            tol = 2e-5
             assert (g - want).abs().max().item() <= tol, (rank, k, (g - want).abs().max().item())
