@@ -331,3 +331,23 @@ def test_m2m_node_vs_reference_golden(sd, golden_dir, tmp_path, monkeypatch, nam
     assert torch.equal(frames, before), "input must not be mutated"
     assert out.shape == want.shape and out.device.type == "cpu" and out.dtype == torch.float32
     assert (out - want).abs().max().item() <= TOL, describe_diff(out, want, "node vs reference golden")
+
+
+def test_m2m_larger_flows(lib):
+    """PWC flow heads scaled x4: refined flows of ~15 px at full resolution, a splat window of ~17 px around every tile."""
+    from cfi_amd.m2m import M2MEngine
+
+    sd = synth.m2m_synth_state_dict(99)
+    big = {k: (v * 4.0 if ".netMain.netMain.10." in k else v) for k, v in sd.items()}
+    eng = M2MEngine(big)
+    try:
+        fr = _frames(2, 160, 224, seed=8)
+        want, aux = _oracle_mid(big, fr, [0.5, 0.3])
+        fmax = aux["ten_fwd"].abs().max().item()
+        assert fmax > 8.0, f"test premise: larger flows (got {fmax:.1f} px)"
+        eng.prepare(fr[0].cuda().contiguous(), fr[1].cuda().contiguous())
+        for t, wv in zip([0.5, 0.3], want):
+            got = eng.render(t).cpu()
+            assert (got - wv).abs().max().item() <= TOL, describe_diff(got, wv, f"m2m larger flows ({fmax:.0f} px) t={t}")
+    finally:
+        eng.close()

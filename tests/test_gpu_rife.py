@@ -479,3 +479,23 @@ def test_engine_rejects_bad_calls(engine):
     with pytest.raises(RuntimeError):
         engine.interpolate([0], [9], [0.5], out[:1])               # slot outside the frame cache
     assert "slot" in _lib.last_error() or "batch" in _lib.last_error()
+
+
+def test_large_flows(hip_lib):
+    """Real checkpoints move pixels by tens of px; the synthetic default moves them by ~3.  Scale every lastconv x8
+    (flows and mask logits of tens of units, warps far outside the frame at the borders) and check parity still holds."""
+    from cfi_amd.rife import RifeEngine, run_tasks
+
+    sd = synth.rife47_synth_state_dict(77)
+    big = {k: (v * 8.0 if "lastconv" in k else v) for k, v in sd.items()}
+    eng = RifeEngine(big, "4.7")
+    try:
+        frames = synth.smooth_frames(2, 200, 328, seed=12, shift=6.0)
+        tasks = [(0, 0.5), (0, 0.125)]
+        got = run_tasks(eng, frames, tasks, batch_size=2)
+        want, aux = _oracle_mid(big, frames, tasks)
+        fmax = max(a[0].abs().max().item() for a in aux)
+        assert fmax > 15.0, f"test premise: large flows (got {fmax:.1f} px)"
+        assert (got - want).abs().max().item() <= TOL, describe_diff(got, want, f"large flows ({fmax:.0f} px)")
+    finally:
+        eng.close()
