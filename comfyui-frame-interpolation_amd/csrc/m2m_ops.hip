@@ -98,38 +98,60 @@ __global__ __launch_bounds__(256) void softsplat_tile_kernel(const float* __rest
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (!ok[u]) continue;
             const int sx = sxs[u], sy = sys[u];
             const float2 f = fl[u];
             const size_t sp = nbase + (size_t)sy * W + sx;
             const float fx = (float)sx + f.x, fy = (float)sy + f.y;
-            if (!isfinite(fx) || !isfinite(fy)) continue;                 // softsplat.py:157-158
-            if (fmaxf(fabsf(f.x), fabsf(f.y)) > cap) continue;            // far pixels: second pass
-            int x0, y0;
-            float w[4];
-            splat_weights(fx, fy, x0, y0, w);
+            // softsplat.py:157-158 (non-finite targets are skipped); far pixels go to the second pass
+            bool live = ok[u] && isfinite(fx) && isfinite(fy) && !(fmaxf(fabsf(f.x), fabsf(f.y)) > cap);
+            int x0 = 0, y0 = 0;
+            float w[4] = {0.f, 0.f, 0.f, 0.f};
+            if (live) splat_weights(fx, fy, x0, y0, w);
             const int lx = x0 - X0, ly = y0 - Y0;                         // tile-local north-west target
-            if (lx < -1 || lx >= SPLAT_T || ly < -1 || ly >= SPLAT_T) continue;
+            live = live && !(lx < -1 || lx >= SPLAT_T || ly < -1 || ly >= SPLAT_T);
             const float* ip = in + sp * C + c0;
-            float iv[NCT > 0 ? NCT : 1];
-            if (NCT == 4 && (C & 3) == 0 && (c0 & 3) == 0) {
-                const float4 t4 = *(const float4*)ip;
-                iv[0] = t4.x; iv[1 % (NCT > 0 ? NCT : 1)] = t4.y; iv[2 % (NCT > 0 ? NCT : 1)] = t4.z; iv[3 % (NCT > 0 ? NCT : 1)] = t4.w;
-            } else if (NCT > 0) {
+            if (NCT == 4) {
+                // ---- 4 channels, with neighbour hand-off.  The 64 lanes scan 64 consecutive source pixels; where the
+                // flow is smooth, lane l's eastern targets are lane l+1's western targets.  Then lane l hands its NE / SE
+                // contributions to lane l+1 (DPP row shift, 16-lane rows), which adds them to its own NW / SW before the
+                // LDS atomic: 8 instead of 16 ds_add_f32 per source — the instruction this kernel is bound by.
+                float4 iv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (live) iv = (C & 3) == 0 && (c0 & 3) == 0 ? *(const float4*)ip : make_float4(ip[0], ip[1], ip[2], ip[3]);
+                const int key = live ? ((ly + 1) << 8) + (lx + 1) : -4096;           // target cell id (row, col)
+                const int keyL = __builtin_amdgcn_update_dpp(-8192, key, 0x111, 0xf, 0xf, false);   // from lane-1 (row_shr:1)
+                const int keyR = __builtin_amdgcn_update_dpp(-8192, key, 0x101, 0xf, 0xf, false);   // from lane+1 (row_shl:1)
+                const bool take = live && keyL + 1 == key;       // left neighbour's east column == my west column
+                const bool give = live && key + 1 == keyR;       // the right neighbour takes my east column
+                float e[8] = {iv.x * w[1], iv.y * w[1], iv.z * w[1], iv.w * w[1], iv.x * w[3], iv.y * w[3], iv.z * w[3], iv.w * w[3]};
+                float fromL[8];
 #pragma unroll
-                for (int c = 0; c < NCT; ++c) iv[c] = ip[c];
-            }
+                for (int j = 0; j < 8; ++j)
+                    fromL[j] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(e[j]), 0x111, 0xf, 0xf, false));
+                float wv[8] = {iv.x * w[0], iv.y * w[0], iv.z * w[0], iv.w * w[0], iv.x * w[2], iv.y * w[2], iv.z * w[2], iv.w * w[2]};
+                if (take) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int tx_ = lx + (k & 1), ty_ = ly + (k >> 1);
-                // inside this tile and inside the image (the reference's per-target bounds check)
-                if (tx_ < 0 || tx_ >= SPLAT_T || ty_ < 0 || ty_ >= SPLAT_T || X0 + tx_ >= W || Y0 + ty_ >= H) continue;
-                float* a = &acc[ty_ * SPLAT_T + tx_];
-                if (NCT > 0) {
+                    for (int j = 0; j < 8; ++j) wv[j] += fromL[j];
+                }
+                if (live) {
 #pragma unroll
-                    for (int c = 0; c < NCT; ++c)
-                        __hip_atomic_fetch_add(a + c * PLANE, __fmul_rn(iv[c], w[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                } else {
+                    for (int k = 0; k < 4; ++k) {
+                        if ((k & 1) && give) continue;            // east column handed to the right neighbour
+                        const int tx_ = lx + (k & 1), ty_ = ly + (k >> 1);
+                        if (tx_ < 0 || tx_ >= SPLAT_T || ty_ < 0 || ty_ >= SPLAT_T || X0 + tx_ >= W || Y0 + ty_ >= H) continue;
+                        float* a = &acc[ty_ * SPLAT_T + tx_];
+                        const float* v = (k & 1) ? &e[(k >> 1) * 4] : &wv[(k >> 1) * 4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            __hip_atomic_fetch_add(a + c * PLANE, v[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            } else if (live) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int tx_ = lx + (k & 1), ty_ = ly + (k >> 1);
+                    // inside this tile and inside the image (the reference's per-target bounds check)
+                    if (tx_ < 0 || tx_ >= SPLAT_T || ty_ < 0 || ty_ >= SPLAT_T || X0 + tx_ >= W || Y0 + ty_ >= H) continue;
+                    float* a = &acc[ty_ * SPLAT_T + tx_];
                     for (int c = 0; c < nc; ++c)
                         __hip_atomic_fetch_add(a + c * PLANE, __fmul_rn(ip[c], w[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
