@@ -62,3 +62,35 @@ def load_file_from_github_release(model_type, ckpt_name):
             errors.append(f"Error when downloading from: {url}\n\n{traceback.format_exc()}")
     raise Exception(f"Tried all urls to download {ckpt_name} but no success. Below is the error log:\n\n"
                     + "\n\n".join(errors))
+
+
+# ---- engine cache -------------------------------------------------------------------------------------------------
+# The reference caches its RIFE module across node executions (rife/__init__.py:29-31) but rebuilds FILM and M2M on
+# every call.  Building an engine means re-packing and uploading every weight (~0.15 s for FILM's 138 MB), so the HIP
+# nodes keep the device-resident weights of the last checkpoint per model type; activations are released after each
+# call.  Keyed by path + size + mtime: a replaced file is reloaded.  VFI_MODEL_CACHE=0 restores load-per-call.
+_engine_cache = {}
+
+
+def cached_engine(model_type, path, build):
+    """build(): -> engine with .close() and .release_workspace().  Returns (engine, cached: bool)."""
+    import os
+
+    if os.environ.get("VFI_MODEL_CACHE", "1") == "0":
+        return build(), False
+    st = os.stat(path)
+    key = (os.path.abspath(path), st.st_size, st.st_mtime_ns)
+    hit = _engine_cache.get(model_type)
+    if hit is not None and hit[0] == key:
+        return hit[1], True
+    if hit is not None:
+        hit[1].close()
+    eng = build()
+    _engine_cache[model_type] = (key, eng)
+    return eng, True
+
+
+def clear_engine_cache():
+    for _, eng in _engine_cache.values():
+        eng.close()
+    _engine_cache.clear()

@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .ckpt import load_file_from_github_release
+from .ckpt import cached_engine, load_file_from_github_release
 from .dist import all_gather_frames, world
 from .film_spec import FLOW_FILTERS, check_state_dict, feat_channels
 from .schedule import InterpolationStateList, shard_tasks
@@ -134,6 +134,12 @@ class FilmEngine:
         self.al = [self._z(*hw[l], self.cal[l] + (64 << min(l, 3) if l < 4 else 0)) for l in range(FUS)]
         self.scratch = {}
         self.shape = (H, W)
+
+    def release_workspace(self):
+        """Drop the activations (15 GB at 1080p); the packed weights stay on the device."""
+        self.img = self.tw = self.pair = self.flow = self.vres = self.vup = self.al = None
+        self.scratch = {}
+        self.shape = None
 
     def _tmp(self, name, h, w, c):
         key = (name, h, w, c)
@@ -289,7 +295,8 @@ class FILM_VFI:
     def vfi(self, ckpt_name: typing.AnyStr, frames: torch.Tensor, clear_cache_after_n_frames=10,
             multiplier: typing.SupportsInt = 2, optional_interpolation_states: InterpolationStateList = None, **kwargs):
         model_path = load_file_from_github_release(MODEL_TYPE, ckpt_name)
-        engine = FilmEngine(_load_state_dict(model_path))   # the reference also re-loads per call (film/__init__.py:74)
+        # (the reference re-loads the TorchScript file on every call, film/__init__.py:74; see ckpt.cached_engine)
+        engine, cached = cached_engine(MODEL_TYPE, model_path, lambda: FilmEngine(_load_state_dict(model_path)))
         try:
             frames = frames[..., :3]
             n = len(frames)
@@ -310,28 +317,41 @@ class FILM_VFI:
             counts = [sum(per_pair[slice(*shard_tasks(pairs, r, ws))]) for r in range(ws)]
             # host side (hostpipe.py): new frames and pass-through frames land in their rows of the output tensor in the
             # background while the next pair computes
-            from .hostpipe import OutputWriter
+            from .hostpipe import OutputWriter, Uploader
             wr = OutputWriter(sum(per_pair) + 1, H, W, dev)
             row0 = [0]
             for m in per_pair:
                 row0.append(row0[-1] + m)          # first output row of each kept pair
             local = torch.empty((counts[rank], H, W, 3), dtype=torch.float32, device=dev) if ws > 1 else None
-            keep, pos = [], 0
-            for j in range(lo, hi):
-                i = pairs[j]
-                res = {0: frames[i].to(dev, torch.float32).contiguous(),
-                       multipliers[i]: frames[i + 1].to(dev, torch.float32).contiguous()}
-                for (l, r, new) in film_schedule(multipliers[i] - 1):
-                    res[new] = engine.forward(res[l], res[r], clamp=True)
-                for n_k, k in enumerate(sorted(res)[:-1]):
-                    if ws > 1:
-                        local[pos] = res[k]      # res[0] is the uploaded original: bit-exact round trip
-                    elif k == 0:
-                        wr.put_host(row0[j] + n_k, frames[i])
-                    else:
-                        wr.put_dev(row0[j] + n_k, res[k])
-                        keep.append(res[k])      # alive until the copy-back has read it
-                    pos += 1
+            mine = pairs[lo:hi]
+            order = sorted({f for i in mine for f in (i, i + 1)})       # every needed frame is uploaded once, ahead of use
+            item_of = {f: k for k, f in enumerate(order)}
+            up = Uploader(frames, order, dev, torch.cuda.current_stream(dev), depth=min(4, len(order)) or 1)
+            keep, pos, held, released = [], 0, {}, 0
+            try:
+                for j in range(lo, hi):
+                    i = pairs[j]
+                    for f in (i, i + 1):
+                        if f not in held:
+                            held[f] = up.get(item_of[f])
+                    res = {0: held[i], multipliers[i]: held[i + 1]}
+                    for (l, r, new) in film_schedule(multipliers[i] - 1):
+                        res[new] = engine.forward(res[l], res[r], clamp=True)
+                    for n_k, k in enumerate(sorted(res)[:-1]):
+                        if ws > 1:
+                            local[pos] = res[k]      # res[0] is the uploaded original: bit-exact round trip
+                        elif k == 0:
+                            wr.put_host(row0[j] + n_k, frames[i])
+                        else:
+                            wr.put_dev(row0[j] + n_k, res[k])
+                            keep.append(res[k])      # alive until the copy-back has read it
+                        pos += 1
+                    while released < item_of[i + 1]:     # frames before i+1 are not needed again (pairs ascend)
+                        up.release(released)
+                        held.pop(order[released], None)
+                        released += 1
+            finally:
+                up.close()
             if ws > 1:
                 allf = all_gather_frames(local, counts)
                 for k in range(allf.shape[0]):
@@ -339,4 +359,8 @@ class FILM_VFI:
             wr.put_host(sum(per_pair), frames[-1])
             return (wr.finish(),)
         finally:
-            engine.close()
+            if cached:
+                torch.cuda.synchronize(engine.device)
+                engine.release_workspace()
+            else:
+                engine.close()

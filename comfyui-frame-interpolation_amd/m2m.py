@@ -26,7 +26,7 @@ import typing
 import torch
 
 from . import _lib
-from .ckpt import load_file_from_github_release
+from .ckpt import cached_engine, load_file_from_github_release
 from .dist import all_gather_frames, world
 from .m2m_spec import check_state_dict
 from .schedule import InterpolationStateList, generic_output_plan, shard_tasks
@@ -179,6 +179,14 @@ class M2MEngine:
         self.sout = z(8, Hp, Wp, 4)
         self.scratch = {}
         self.shape = (H, W)
+
+    def release_workspace(self):
+        """Drop the activations; the packed weights stay on the device."""
+        for name in ("d0", "imh", "decb", "flow", "enc", "fl", "s3", "xf", "r", "tf", "e", "sin", "sfl", "sout", "_keep"):
+            setattr(self, name, None)
+        self.scratch = {}
+        self.shape = None
+        self.prepared = False
 
     def _tmp(self, name, h, w, c):
         key = (name, h, w, c)
@@ -400,9 +408,14 @@ class M2M_VFI:
             multiplier: typing.SupportsInt = 2, optional_interpolation_states: InterpolationStateList = None, **kwargs):
         assert len(frames) >= 2, f"VFI model M2M requires at least 2 frames to work with, only found {frames.shape[0]}."
         model_path = load_file_from_github_release(MODEL_TYPE, ckpt_name)
-        engine = M2MEngine(_load_state_dict(model_path))
+        # (the reference rebuilds M2M_PWC on every call, m2m/__init__.py:43-46; see ckpt.cached_engine)
+        engine, cached = cached_engine(MODEL_TYPE, model_path, lambda: M2MEngine(_load_state_dict(model_path)))
         try:
             plan, tasks = generic_output_plan(len(frames), multiplier, optional_interpolation_states)
             return (run_plan(engine, frames, plan, tasks),)
         finally:
-            engine.close()
+            if cached:
+                torch.cuda.synchronize(engine.device)
+                engine.release_workspace()
+            else:
+                engine.close()

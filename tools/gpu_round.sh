@@ -1,6 +1,5 @@
 #!/bin/bash
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 300 python -m pytest tests/test_gpu_m2m_ops.py tests/test_gpu_m2m.py -x -q -m gpu 2>&1 | tail -3
-timeout 200 python tools/splat_bench.py 2>&1 | grep "softsplat" | tee gpurun_out/splat_bench_v4.log
-timeout 200 python tools/m2m_bench.py 2>&1 | grep -E "prepare|softsplat" | tee -a gpurun_out/splat_bench_v4.log
+timeout 600 python -m pytest tests/test_gpu_film.py tests/test_gpu_m2m.py tests/test_gpu_dist_nodes.py -x -q -m gpu 2>&1 | tail -3
+timeout 300 python tools/node_e2e_models.py 2>&1 | grep "node e2e" | tee gpurun_out/node_e2e_models.log

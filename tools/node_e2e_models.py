@@ -35,4 +35,4 @@ if __name__ == "__main__":
                     del res
                     new = out.shape[0] - n
                     print(f"{name} node e2e: {n} frames 1080p x{m} -> {out.shape[0]} frames: {dt:.3f} s, {new / dt:.1f} interpolated frames/s "
-                          f"(incl. checkpoint load + weight upload per call, like the reference)", flush=True)
+                          f"(engine cached across calls; VFI_MODEL_CACHE=0 reloads per call like the reference)", flush=True)
