@@ -62,6 +62,12 @@ PROTOTYPES = {
                                        C.c_int, C.c_void_p]),
     "vfi_m2m_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                   C.c_int, C.c_void_p]),
+    "vfi_rife40_prep": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "vfi_warp_rife": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                C.c_void_p]),
+    "vfi_absmax": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
+    "vfi_rife40_output": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vfi_rife_create": (C.c_void_p, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int]),
     "vfi_rife_destroy": (None, [C.c_void_p]),
     "vfi_rife_configure": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]),

@@ -239,6 +239,32 @@ def run_tasks(engine, frames_cpu, tasks, batch_size, scale_factor=1.0, out_devic
 
 
 class RIFE_VFI:
+    @staticmethod
+    def _vfi40(engine, frames, multiplier, fast_mode, ensemble, scale_factor, batch_size, states):
+        """arch 4.0: op-by-op engine (rife40.py).  The widget's batch_size is honoured exactly and tasks are not sharded over
+        ranks: the scale list is doubled in place by a test over the whole batch (rife_arch.py:598-607) and stays doubled for
+        the rest of the call, so batch composition and order are part of the result."""
+        from .hostpipe import OutputWriter
+        from .rife40 import run_tasks40
+
+        frames = frames[..., :3]
+        n = len(frames)
+        _, tasks = rife_task_list(n, multiplier, states)
+        plan = rife_output_plan(n, tasks)
+        wr = OutputWriter(len(plan), frames.shape[1], frames.shape[2], engine.device)
+        rows = [0] * len(tasks)
+        for i, (kind, idx) in enumerate(plan):
+            if kind == "new":
+                rows[idx] = i
+            else:
+                wr.put_host(i, frames[idx])
+        scale_list = [8 / scale_factor, 4 / scale_factor, 2 / scale_factor, 1 / scale_factor]   # rife/__init__.py:157-160
+        keep = run_tasks40(engine, frames, tasks, batch_size, scale_list, fast_mode, ensemble, wr, rows)
+        out = wr.finish()
+        del keep
+        print(f"Comfy-VFI done! {len(plan)} frames generated")
+        return out
+
     @classmethod
     def INPUT_TYPES(s):
         return {
@@ -291,9 +317,16 @@ class RIFE_VFI:
         if cache_key not in _model_cache:
             model_path = load_file_from_github_release(MODEL_TYPE, ckpt_name)
             sd = torch.load(model_path, map_location="cpu", weights_only=False)
-            _model_cache[cache_key] = RifeEngine(sd, arch_ver)
+            if arch_ver == "4.0":
+                from .rife40 import Rife40Engine
+                _model_cache[cache_key] = Rife40Engine(sd)
+            else:
+                _model_cache[cache_key] = RifeEngine(sd, arch_ver)
             print(f"Comfy-VFI: Loaded and cached model {ckpt_name} (HIP, float32)")
         engine = _model_cache[cache_key]
+        if arch_ver == "4.0":
+            return (self._vfi40(engine, frames, multiplier, fast_mode, ensemble, scale_factor, batch_size,
+                                optional_interpolation_states),)
 
         frames = frames[..., :3]  # preprocess_frames: drop alpha; layout stays NHWC on this path
         n = len(frames)

@@ -22,7 +22,7 @@ CKPT_NAME_VER_DICT = {
     "sudo_rife4_269.662_testV1_scale1.pth": "4.0",
 }
 # architectures the HIP path implements so far
-SUPPORTED_ARCH = ("4.7", "4.17", "4.26")
+SUPPORTED_ARCH = ("4.7", "4.17", "4.26")   # one fused C-ABI object (vfi_rife_*); "4.0" runs op by op (rife40.py)
 # architecture -> code handed to vfi_rife_create
 ARCH_CODE = {"4.7": 47, "4.17": 417, "4.26": 426}
 
@@ -92,7 +92,45 @@ def rife426_shapes():
     return d
 
 
+# rife_arch.py:404-408,460-462 (IFNet.__init__, arch "4.0"): PReLU convs, plain 8-conv trunk, lastconv = ConvTranspose2d(c,5),
+# Contextnet (:278-313) and Unet (:316-342)
+RIFE40_BLOCKS = ((7, 192), (8 + 4, 128), (8 + 4, 96), (8 + 4, 64))
+
+
+def rife40_shapes():
+    d = OrderedDict()
+
+    def cp(p, cout, cin):
+        d[p + ".0.weight"] = (cout, cin, 3, 3)
+        d[p + ".0.bias"] = (cout,)
+        d[p + ".1.weight"] = (cout,)
+
+    for b, (cin, c) in enumerate(RIFE40_BLOCKS):
+        p = f"block{b}."
+        cp(p + "conv0.0", c // 2, cin)
+        cp(p + "conv0.1", c, c // 2)
+        for i in range(N_RESCONV):
+            cp(p + f"convblock.{i}", c, c)
+        d[p + "lastconv.weight"] = (c, 5, 4, 4)
+        d[p + "lastconv.bias"] = (5,)
+    for i, (ci, co) in enumerate(((3, 16), (16, 32), (32, 64), (64, 128))):
+        cp(f"contextnet.conv{i + 1}.conv1", co, ci)
+        cp(f"contextnet.conv{i + 1}.conv2", co, co)
+    for i, (ci, co) in enumerate(((17, 32), (64, 64), (128, 128), (256, 256))):
+        cp(f"unet.down{i}.conv1", co, ci)
+        cp(f"unet.down{i}.conv2", co, co)
+    for i, (ci, co) in enumerate(((512, 128), (256, 64), (128, 32), (64, 16))):
+        d[f"unet.up{i}.0.weight"] = (ci, co, 4, 4)
+        d[f"unet.up{i}.0.bias"] = (co,)
+        d[f"unet.up{i}.1.weight"] = (co,)
+    d["unet.conv.weight"] = (3, 16, 3, 3)
+    d["unet.conv.bias"] = (3,)
+    return d
+
+
 def rife_shapes(arch_ver="4.7"):
+    if arch_ver == "4.0":
+        return rife40_shapes()
     return {"4.7": rife47_shapes, "4.17": rife417_shapes, "4.26": rife426_shapes}[arch_ver]()
 
 

@@ -61,6 +61,21 @@ def rife426_synth_state_dict(seed=1234):
     return synth_state_dict(rife426_shapes(), seed)
 
 
+def rife40_synth_state_dict(seed=1234):
+    """arch 4.0: conv weights / biases as torch's default init, PReLU slopes U(0.1, 0.4)"""
+    from .rife_spec import rife40_shapes
+
+    shapes = rife40_shapes()
+    sd = synth_state_dict({k: v for k, v in shapes.items() if len(v) != 1 or k.endswith("bias")}, seed)
+    out = {}
+    for k, shp in shapes.items():
+        if k in sd:
+            out[k] = sd[k]
+        else:   # PReLU slope vector
+            out[k] = (0.1 + 0.3 * torch.rand(shp, generator=_gen(seed, k))).to(torch.float32)
+    return out
+
+
 def film_synth_state_dict(seed=1234, gain=1.2):
     """FILM: torch-default init shrinks the signal to a bias-dominated constant through ~20 LeakyReLU convs, which
     would make parity tests insensitive; weights are U(+-gain*sqrt(3/fan_in)) (roughly variance preserving), biases

@@ -171,6 +171,24 @@ int vfi_m2m_splat_inputs(const float* d0_dev, int d0_cs, const float* tf_dev, co
 int vfi_m2m_combine(const float* splat_dev, const float* d0_dev, int d0_cs, const float* stats_dev, float t, float* out_dev,
                     int Hp, int Wp, int H, int W, void* stream);
 
+/* ---- RIFE arch 4.0 building blocks (sudo_rife4 checkpoint; rife40.py drives them with the layer objects above) -- */
+
+/* Block-0 input of one task: out [Hp,Wp,8] = (clamp(frame0.rgb), clamp(frame1.rgb), timestep, 0), images zero in the
+ * padding, timestep everywhere (torch.clamp + F.pad + timestep.repeat, rife_arch.py:476-499).  frames [H,W,C>=3]. */
+int vfi_rife40_prep(const float* frame0_dev, const float* frame1_dev, int C, int H, int W, float timestep, float* out_dev,
+                    int Hp, int Wp, void* stream);
+/* warp() (rife_arch.py:31-70: bilinear, border, align_corners=True, reference expression order) over NHWC channel
+ * windows; flow = [dx, dy] at flow_dev[pixel * flow_cs]. */
+int vfi_warp_rife(const float* in_dev, int in_cs, const float* flow_dev, int flow_cs, float* out_dev, int out_cs, int N,
+                  int H, int W, int C, void* stream);
+/* *out_dev = max |x| over a C-channel window of `pixels` pixels — the `f0[:, :2].abs().max() > 32` test that doubles
+ * the block scales (rife_arch.py:598-607). */
+int vfi_absmax(const float* x_dev, int cs, int C, int64_t pixels, float* out_dev, void* stream);
+/* merged = w0 * sigmoid(mask) + w1 * (1 - sigmoid(mask)); with res (the Unet output): clamp(merged + (res*2 - 1), 0, 1);
+ * crop to H x W and the node's clamp(0,1) (rife_arch.py:712-732, rife/__init__.py:207).  w01 [B,Hp,Wp,>=6] = (w0 | w1). */
+int vfi_rife40_output(const float* w01_dev, int w_cs, const float* mask_dev, int m_cs, const float* res_dev, int r_cs,
+                      float* out_dev, int B, int Hp, int Wp, int H, int W, void* stream);
+
 /* ---- RIFE 4.7 / 4.9 model --------------------------------------------------------------- */
 
 typedef struct vfi_rife vfi_rife_t;

@@ -169,6 +169,108 @@ def ifnet426_forward(sd, img0, img1, timestep, scale_list=(16, 8, 4, 2, 1), retu
 
 
 # ---------------------------------------------------------------------------------------------
+# arch "4.0" (sudo_rife4_269.662_testV1_scale1.pth): PReLU convs, no encoder, flow/mask ACCUMULATED over the blocks,
+# optional Contextnet + Unet refinement.  Here the node's two booleans finally matter, under crossed names: the node passes
+# (fast_mode, ensemble) positionally into forward(..., training, fastmode) (rife/__init__.py:200-206, rife_arch.py:465-475).
+# ---------------------------------------------------------------------------------------------
+def _cp(sd, p, x, stride=1):
+    """conv() for arch 4.0: Conv2d(3, stride, 1) + PReLU(out_planes), rife_arch.py:82-94"""
+    return F.prelu(F.conv2d(x, sd[p + ".0.weight"], sd[p + ".0.bias"], stride, 1), sd[p + ".1.weight"])
+
+
+def ifblock40(sd, p, x, flow, scale):
+    """IFBlock.forward for arch 4.0, rife_arch.py:237-261: conv0 x2 (stride 2), convblock(feat) + feat, ConvTranspose2d(c,5),
+    up-resize by 2*scale"""
+    x = F.interpolate(x, scale_factor=1.0 / scale, mode="bilinear", align_corners=False)
+    if flow is not None:
+        flow = F.interpolate(flow, scale_factor=1.0 / scale, mode="bilinear", align_corners=False) * 1.0 / scale
+        x = torch.cat((x, flow), 1)
+    feat = _cp(sd, p + "conv0.1", _cp(sd, p + "conv0.0", x, 2), 2)
+    y = feat
+    for i in range(8):
+        y = _cp(sd, p + f"convblock.{i}", y)
+    feat = y + feat
+    tmp = F.conv_transpose2d(feat, sd[p + "lastconv.weight"], sd[p + "lastconv.bias"], 2, 1)
+    tmp = F.interpolate(tmp, scale_factor=scale * 2, mode="bilinear", align_corners=False)
+    return tmp[:, :4] * scale * 2, tmp[:, 4:5]
+
+
+def _conv2_40(sd, p, x):
+    return _cp(sd, p + ".conv2", _cp(sd, p + ".conv1", x, 2))
+
+
+def contextnet40(sd, x, flow):
+    """Contextnet.forward, rife_arch.py:288-313"""
+    out = []
+    for i in range(1, 5):
+        x = _conv2_40(sd, f"contextnet.conv{i}", x)
+        flow = F.interpolate(flow, scale_factor=0.5, mode="bilinear", align_corners=False) * 0.5
+        out.append(warp(x, flow))
+    return out
+
+
+def unet40(sd, img0, img1, w0, w1, mask, flow, c0, c1):
+    """Unet.forward, rife_arch.py:330-342"""
+    def dec(p, x):
+        return F.prelu(F.conv_transpose2d(x, sd[p + ".0.weight"], sd[p + ".0.bias"], 2, 1), sd[p + ".1.weight"])
+
+    s0 = _conv2_40(sd, "unet.down0", torch.cat((img0, img1, w0, w1, mask, flow), 1))
+    s1 = _conv2_40(sd, "unet.down1", torch.cat((s0, c0[0], c1[0]), 1))
+    s2 = _conv2_40(sd, "unet.down2", torch.cat((s1, c0[1], c1[1]), 1))
+    s3 = _conv2_40(sd, "unet.down3", torch.cat((s2, c0[2], c1[2]), 1))
+    x = dec("unet.up0", torch.cat((s3, c0[3], c1[3]), 1))
+    x = dec("unet.up1", torch.cat((x, s2), 1))
+    x = dec("unet.up2", torch.cat((x, s1), 1))
+    x = dec("unet.up3", torch.cat((x, s0), 1))
+    return torch.sigmoid(F.conv2d(x, sd["unet.conv.weight"], sd["unet.conv.bias"], 1, 1))
+
+
+def ifnet40_forward(sd, img0, img1, timestep, scale_list, training=True, fastmode=True, return_aux=False):
+    """rife_arch.py:465-732, arch "4.0", ensemble=False.  ``scale_list`` is a LIST and is doubled IN PLACE when block 1
+    reports flows above 32 px in both directions and ``training`` is False (:598-607) — the node builds the list once per
+    call and passes the same object to every batch (rife/__init__.py:157-160,200-206), so the doubling sticks."""
+    img0 = torch.clamp(img0, 0, 1)
+    img1 = torch.clamp(img1, 0, 1)
+    n, c, h, w = img0.shape
+    ph = ((h - 1) // 64 + 1) * 64
+    pw = ((w - 1) // 64 + 1) * 64
+    img0 = F.pad(img0, (0, pw - w, 0, ph - h))
+    img1 = F.pad(img1, (0, pw - w, 0, ph - h))
+    timestep = timestep.repeat(1, 1, img0.shape[2], img0.shape[3])
+    warped_img0, warped_img1 = img0, img1
+    flow = mask = None
+    aux = []
+    for i in range(4):
+        p = f"block{i}."
+        if flow is None:
+            flow, mask = ifblock40(sd, p, torch.cat((img0[:, :3], img1[:, :3], timestep), 1), None, scale_list[i])
+        else:
+            f0, m0 = ifblock40(sd, p, torch.cat((warped_img0[:, :3], warped_img1[:, :3], timestep, mask), 1), flow, scale_list[i])
+            if i == 1 and f0[:, :2].abs().max() > 32 and f0[:, 2:4].abs().max() > 32 and not training:
+                for k in range(4):
+                    scale_list[k] *= 2
+                flow, mask = ifblock40(sd, "block0.", torch.cat((img0[:, :3], img1[:, :3], timestep), 1), None, scale_list[0])
+                warped_img0 = warp(img0, flow[:, :2])
+                warped_img1 = warp(img1, flow[:, 2:4])
+                f0, m0 = ifblock40(sd, p, torch.cat((warped_img0[:, :3], warped_img1[:, :3], timestep, mask), 1), flow, scale_list[i])
+            flow = flow + f0
+            mask = mask + m0
+        warped_img0 = warp(img0, flow[:, :2])
+        warped_img1 = warp(img1, flow[:, 2:4])
+        if return_aux:
+            aux.append((flow.clone(), mask.clone()))
+    sm = torch.sigmoid(mask)
+    merged = warped_img0 * sm + warped_img1 * (1 - sm)
+    if not fastmode:
+        c0 = contextnet40(sd, img0, flow[:, :2])
+        c1 = contextnet40(sd, img1, flow[:, 2:4])
+        tmp = unet40(sd, img0, img1, warped_img0, warped_img1, mask, flow, c0, c1)
+        merged = torch.clamp(merged + (tmp[:, :3] * 2 - 1), 0, 1)
+    out = merged[:, :, :h, :w]
+    return (out, aux) if return_aux else out
+
+
+# ---------------------------------------------------------------------------------------------
 # node level (vfi_models/rife/__init__.py:146-239)
 # ---------------------------------------------------------------------------------------------
 
@@ -190,7 +292,7 @@ def rife_tasks(n_frames, multiplier, states=None):
     return multipliers, tasks
 
 
-def rife_vfi(sd, frames, multiplier=2, scale_factor=1.0, batch_size=1, states=None, arch="4.7"):
+def rife_vfi(sd, frames, multiplier=2, scale_factor=1.0, batch_size=1, states=None, arch="4.7", fast_mode=False, ensemble=False):
     """Whole-node oracle: frames [N,H,W,C] f32 CPU -> [N_out,H,W,3] f32 CPU."""
     x = frames[..., :3].permute(0, 3, 1, 2)  # preprocess_frames, vfi_utils.py:139-140
     n_pairs = len(x) - 1
@@ -206,7 +308,10 @@ def rife_vfi(sd, frames, multiplier=2, scale_factor=1.0, batch_size=1, states=No
             f0 = torch.cat([x[p : p + 1] for p, _ in bt], 0).to(torch.float32)
             f1 = torch.cat([x[p + 1 : p + 2] for p, _ in bt], 0).to(torch.float32)
             ts = torch.tensor([t for _, t in bt], dtype=torch.float32).view(-1, 1, 1, 1)
-            mid = ifnet47_forward(sd, f0, f1, ts, scale_list, arch=arch).clamp(0, 1)
+            if arch == "4.0":   # the two booleans land on forward()'s `training` / `fastmode` (rife/__init__.py:200-206)
+                mid = ifnet40_forward(sd, f0, f1, ts, scale_list, fast_mode, ensemble).clamp(0, 1)
+            else:
+                mid = ifnet47_forward(sd, f0, f1, ts, scale_list, arch=arch).clamp(0, 1)
             for i, (p, _) in enumerate(bt):
                 results[p].append(mid[i : i + 1])
             pos += len(bt)

@@ -499,3 +499,78 @@ def test_large_flows(hip_lib):
         assert (got - want).abs().max().item() <= TOL, describe_diff(got, want, f"large flows ({fmax:.0f} px)")
     finally:
         eng.close()
+
+
+# ---- arch 4.0 (sudo_rife4 checkpoint): op-by-op engine (rife40.py), the node's fast_mode / ensemble widgets matter here ----
+
+CKPT40 = "sudo_rife4_269.662_testV1_scale1.pth"
+
+
+@pytest.fixture(scope="module")
+def sd40():
+    return synth.rife40_synth_state_dict(1234)
+
+
+def _run40(sd, frames, ts, scale_list, training, fastmode):
+    from cfi_amd.rife40 import Rife40Engine
+
+    eng = Rife40Engine(sd)
+    try:
+        h, w = frames.shape[1:3]
+        eng.configure(h, w, len(ts))
+        f0, f1 = frames[0].cuda().contiguous(), frames[1].cuda().contiguous()
+        out = torch.empty(len(ts), h, w, 3, device="cuda")
+        eng.forward([f0] * len(ts), [f1] * len(ts), ts, scale_list, training, fastmode, out)
+        return out.cpu()
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("h,w,training,fastmode,sf", [(64, 64, True, True, 1.0), (100, 150, False, False, 1.0), (270, 480, True, False, 1.0),
+                                                      (120, 200, False, True, 0.5), (100, 150, False, False, 2.0)])
+def test_rife40_against_oracle(hip_lib, sd40, h, w, training, fastmode, sf):
+    frames = synth.smooth_frames(2, h, w, seed=4, shift=3.0)
+    ts = [0.5, 0.2]
+    got = _run40(sd40, frames, ts, [8 / sf, 4 / sf, 2 / sf, 1 / sf], training, fastmode)
+    x = frames.permute(0, 3, 1, 2)
+    with torch.inference_mode():
+        want = rife_oracle.ifnet40_forward(sd40, x[0:1].repeat(2, 1, 1, 1), x[1:2].repeat(2, 1, 1, 1), torch.tensor(ts).view(-1, 1, 1, 1),
+                                           [8 / sf, 4 / sf, 2 / sf, 1 / sf], training, fastmode)
+    want = want.clamp(0, 1).permute(0, 2, 3, 1)
+    assert (got - want).abs().max().item() <= TOL, describe_diff(got, want, f"rife 4.0 {h}x{w} training={training} fastmode={fastmode} sf={sf}")
+
+
+def test_rife40_scale_doubling(hip_lib, sd40):
+    """block-1 flows above 32 px in both directions with training=False: the block scales are doubled in place and blocks 0/1
+    re-run (rife_arch.py:598-607); with training=True the same weights must NOT double."""
+    big = {k: (v * 6.0 if "lastconv" in k and k[:6] in ("block0", "block1") else v) for k, v in sd40.items()}
+    frames = synth.smooth_frames(2, 128, 192, seed=3, shift=2.5)
+    x = frames.permute(0, 3, 1, 2)
+    for training in (False, True):
+        sl_g, sl_o = [8.0, 4.0, 2.0, 1.0], [8.0, 4.0, 2.0, 1.0]
+        got = _run40(big, frames, [0.5], sl_g, training, False)
+        with torch.inference_mode():
+            want = rife_oracle.ifnet40_forward(big, x[0:1], x[1:2], torch.tensor([0.5]).view(1, 1, 1, 1), sl_o, training, False)
+        want = want.clamp(0, 1).permute(0, 2, 3, 1)
+        assert sl_g == sl_o == ([16.0, 8.0, 4.0, 2.0] if not training else [8.0, 4.0, 2.0, 1.0]), (training, sl_g, sl_o)
+        assert (got - want).abs().max().item() <= TOL, describe_diff(got, want, f"rife 4.0 doubling training={training}")
+
+
+@pytest.mark.parametrize("name,kw", [("default", dict(multiplier=2, fast_mode=True, ensemble=True)),
+                                     ("refine_bs2", dict(multiplier=[3, 1], batch_size=2, fast_mode=False, ensemble=False))])
+def test_node40_against_reference_golden(hip_lib, sd40, golden_dir, tmp_path, monkeypatch, name, kw):
+    import cfi_amd.rife as R
+
+    pth = tmp_path / CKPT40
+    torch.save(sd40, pth)
+    monkeypatch.setattr(R, "load_file_from_github_release", lambda model_type, ckpt: str(pth))
+    R._model_cache.clear()
+    g = np.load(os.path.join(golden_dir, "rife40_node.npz"))
+    frames = torch.from_numpy(g["frames"])
+    (out,) = R.RIFE_VFI().vfi(CKPT40, frames, **kw)
+    for e in R._model_cache.values():
+        e.close()
+    R._model_cache.clear()
+    want = torch.from_numpy(g[name])
+    assert out.shape == want.shape and (out - want).abs().max().item() <= TOL, describe_diff(out, want, name)
+    assert torch.equal(out[0], frames[0, ..., :3]) and torch.equal(out[-1], frames[-1, ..., :3])

@@ -184,3 +184,27 @@ def test_node426_matches_reference_golden(golden_dir, name, kw):
     g = np.load(os.path.join(golden_dir, "rife426_node.npz"))
     out = rife_oracle.rife_vfi(synth.rife426_synth_state_dict(1234), torch.from_numpy(g["frames"]), arch="4.26", **kw)
     assert out.shape == g[name].shape and np.abs(out.numpy() - g[name]).max() <= TOL
+
+
+# ---- arch 4.0 (sudo_rife4 checkpoint): goldens written by oracle/validate_rife40_vs_reference.py ----------------------------
+
+@pytest.mark.parametrize("key,training,fastmode", [("out_fast", True, True), ("out_full", False, False)])
+def test_ifnet40_matches_reference_golden(golden_dir, key, training, fastmode):
+    g = np.load(os.path.join(golden_dir, "rife40_net_anime.npz"))
+    sd = synth.rife40_synth_state_dict(1234)
+    fr = torch.from_numpy(g["frames"])
+    ts = torch.from_numpy(g["timesteps"]).view(-1, 1, 1, 1)
+    b = ts.shape[0]
+    i0 = fr[0:1].permute(0, 3, 1, 2).repeat(b, 1, 1, 1)
+    i1 = fr[1:2].permute(0, 3, 1, 2).repeat(b, 1, 1, 1)
+    with torch.inference_mode():
+        out = rife_oracle.ifnet40_forward(sd, i0, i1, ts, [8.0, 4.0, 2.0, 1.0], training, fastmode).permute(0, 2, 3, 1)
+    assert out.shape == g[key].shape and np.abs(out.numpy() - g[key]).max() <= TOL
+
+
+@pytest.mark.parametrize("name,kw", [("default", dict(multiplier=2, fast_mode=True, ensemble=True)),
+                                     ("refine_bs2", dict(multiplier=[3, 1], batch_size=2, fast_mode=False, ensemble=False))])
+def test_node40_matches_reference_golden(golden_dir, name, kw):
+    g = np.load(os.path.join(golden_dir, "rife40_node.npz"))
+    out = rife_oracle.rife_vfi(synth.rife40_synth_state_dict(1234), torch.from_numpy(g["frames"]), arch="4.0", **kw)
+    assert out.shape == g[name].shape and np.abs(out.numpy() - g[name]).max() <= TOL
