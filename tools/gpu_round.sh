@@ -1,4 +1,11 @@
 #!/bin/bash
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_gpu_rife.py -x -q -m gpu -k "40" 2>&1 | tail -25 | tee gpurun_out/gpu_tests.log
+for b in 2 4; do
+timeout 200 python bench.py --height 2160 --width 3840 --batch $b --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('4K batch', d['config']['pairs_per_step_per_gpu'], 'value', d['value'], 'fps; ms/step', d['ms_per_step'], 'roofline', d['roofline']['achieved'], 'TF/s', 'whole-net', d['conv_tflops_whole_net'])
+" | tee -a gpurun_out/bench_4k.log
+done
