@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("VFI_BENCH_BATCH", "8")), help="frame pairs per step per GPU")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("VFI_BENCH_BATCH", "16")), help="frame pairs per step per GPU")
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--no-cpu-baseline", action="store_true")
