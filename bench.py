@@ -202,7 +202,10 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom)
+                tj = json.load(open(tpath))
+                traffic = tj.get(dom)
+                if traffic is not None:   # measured per launch at the batch recorded in the file; linear in the batch
+                    traffic = int(traffic * B / float(tj.get("_detail", {}).get("batch", B)))
             except Exception:
                 traffic = None
         total_ms = sum(v[1] for v in rep.values())
