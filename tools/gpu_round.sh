@@ -1,8 +1,5 @@
 #!/bin/bash
 export TMPDIR=/tmp
-timeout 200 python bench.py --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys
-for l in sys.stdin:
-    if l.startswith('{'):
-        d=json.loads(l); k=d['kernels']; print('value', d['value'], 'stage_trans', k['stage_trans']['ms']/k['stage_trans']['calls'], 'conv0a_b3', k['conv0a_b3']['ms']/k['conv0a_b3']['calls'])
-"
+mkdir -p gpurun_out
+timeout 200 python tools/rife40_bench.py 2>&1 | grep -A1 "^RIFE 4.0" | tee gpurun_out/rife40_bench.log
+REPS=2 timeout 200 python tools/node_e2e.py 17 4 2>&1 | grep "node e2e" | tee gpurun_out/node_e2e_misc.log
