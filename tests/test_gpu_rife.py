@@ -574,3 +574,30 @@ def test_node40_against_reference_golden(hip_lib, sd40, golden_dir, tmp_path, mo
     want = torch.from_numpy(g[name])
     assert out.shape == want.shape and (out - want).abs().max().item() <= TOL, describe_diff(out, want, name)
     assert torch.equal(out[0], frames[0, ..., :3]) and torch.equal(out[-1], frames[-1, ..., :3])
+
+
+def test_resconv_beta_edge_cases(hip_lib):
+    """ResConv's `conv(x) * beta + x` is normally folded into the centre tap (w += 1/beta); a layer with any |beta| < 1e-2
+    must take the explicit-residual path instead.  Negative and tiny betas, whole network against the oracle."""
+    from cfi_amd.rife import RifeEngine, run_tasks
+
+    sd = dict(synth.rife47_synth_state_dict(5))
+    g = torch.Generator().manual_seed(9)
+    for k in list(sd):
+        if k.endswith("beta"):
+            b = sd[k].clone()
+            if "convblock.0" in k or "convblock.5" in k:
+                b.view(-1)[::7] = 0.0                       # exact zeros: the block's output there is just lrelu(x)
+                b.view(-1)[3::11] = 1e-4
+            elif "convblock.2" in k:
+                b = -b                                      # negative scale (still foldable)
+            sd[k] = b
+    eng = RifeEngine(sd, "4.7")
+    try:
+        frames = synth.smooth_frames(2, 96, 160, seed=13, shift=3.0)
+        tasks = [(0, 0.5)]
+        got = run_tasks(eng, frames, tasks, batch_size=1)
+        want, _ = _oracle_mid(sd, frames, tasks)
+        assert (got - want).abs().max().item() <= TOL, describe_diff(got, want, "beta edge cases")
+    finally:
+        eng.close()
