@@ -236,7 +236,8 @@ def prefault_async(t, chunk=16 << 20, workers=None):
         return []
     pool = _pool("fault", workers)
     base, n = t.data_ptr(), t.numel() * t.element_size()
-    _madvise(base, n, _MADV_HUGEPAGE)   # best effort (THP may be disabled)
+    if os.environ.get("VFI_HOST_THP", "1") == "1":
+        _madvise(base, n, _MADV_HUGEPAGE)   # best effort (THP may be disabled)
     return [pool.submit(_populate, base + off, min(chunk, n - off)) for off in range(0, n, chunk)]
 
 
