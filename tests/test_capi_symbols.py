@@ -36,3 +36,34 @@ def test_checkpoint_spec_counts():
             k *= d
         n += k
     assert n == 5325012
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No CPU fallback: without libvfi_hip.so the product path raises (it never routes through torch ops or the oracle)."""
+    import pytest
+
+    from cfi_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libvfi_hip.so"))
+    with pytest.raises(RuntimeError, match="not built|not found"):
+        _lib.load()
+
+
+def test_engines_need_a_gpu():
+    """On a box without a GPU the engines refuse to start instead of computing on the CPU."""
+    import pytest
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from cfi_amd import synth
+    from cfi_amd.film import FilmEngine
+    from cfi_amd.m2m import M2MEngine
+    from cfi_amd.rife import RifeEngine
+    from cfi_amd.rife40 import Rife40Engine
+
+    for ctor, sd in ((lambda s: RifeEngine(s, "4.7"), synth.rife47_synth_state_dict), (FilmEngine, synth.film_synth_state_dict),
+                     (M2MEngine, synth.m2m_synth_state_dict), (Rife40Engine, synth.rife40_synth_state_dict)):
+        with pytest.raises(RuntimeError, match="no GPU"):
+            ctor(sd(1))

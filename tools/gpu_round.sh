@@ -1,8 +1,8 @@
 #!/bin/bash
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-: > gpurun_out/thp.log
-for thp in 1 0 1 0; do
-echo "VFI_HOST_THP=$thp" | tee -a gpurun_out/thp.log
-VFI_HOST_THP=$thp REPS=3 timeout 200 python tools/node_e2e.py 65 8 2>&1 | grep "node e2e" | cut -c1-110 | tee -a gpurun_out/thp.log
-done
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 | tee gpurun_out/gpu_tests.log
+timeout 200 python -c "import __graft_entry__ as g; g.build(); g.smoke()" 2>&1 | tail -1
+timeout 400 python bench.py > gpurun_out/bench.log 2>&1; tail -1 gpurun_out/bench.log | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print({k:d[k] for k in ('metric','value','n_gpus','steps','warmup','ms_per_step','dtype')}); print(d['roofline']); print(d['cpu_baseline']['value'], d['cpu_baseline']['cores'])"
