@@ -1,8 +1,8 @@
 #!/bin/bash
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 | tee gpurun_out/gpu_tests.log
-timeout 200 python -c "import __graft_entry__ as g; g.build(); g.smoke()" 2>&1 | tail -1
-timeout 400 python bench.py > gpurun_out/bench.log 2>&1; tail -1 gpurun_out/bench.log | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print({k:d[k] for k in ('metric','value','n_gpus','steps','warmup','ms_per_step','dtype')}); print(d['roofline']); print(d['cpu_baseline']['value'], d['cpu_baseline']['cores'])"
+rm -rf gpurun_out/prof_lds
+timeout 240 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_BUSY_CYCLES -d gpurun_out/prof_lds -o lds -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --batch 8 > gpurun_out/prof_lds.log 2>&1
+python tools/rocprof_summary.py pmc gpurun_out/prof_lds > gpurun_out/r01c_pmc_LDS_planar.txt 2>&1
+head -9 gpurun_out/r01c_pmc_LDS_planar.txt
+rm -rf gpurun_out/prof_lds
