@@ -176,6 +176,62 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     }
 
     // ---- epilogue: lane holds output channel co for 16 pixels of each sub-tile
+    // Fast paths chosen once per workgroup (uniform): the generic loop below re-tests act / res / beta / out_mode for every
+    // one of the 16*MT*NT values of a lane (hundreds of scalar branches per tile).
+    const bool plain = !EXT && a.res == nullptr && a.act != 2 && (a.act == 0 || (a.slope >= 0.f && a.slope <= 1.f));
+    if (plain && !GROUPED && a.out_mode == 0) {   // NHWC store, activation none / LeakyReLU(slope in [0,1]) = max(v, v*slope)
+        const float slope = a.act == 1 ? a.slope : 1.0f;
+        const int rowp = a.Wout * a.out_cs;
+        const bool interior = Y0 + (SUBS / SUBX) * 4 <= a.Hout && X0 + SUBX * 8 <= a.Wout;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int co = co0 + nt * 32 + l31;
+            if (co >= a.Cout) continue;
+            const float bs = a.bias[co], bt = a.beta ? a.beta[co] : 1.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int s = wm * MT + mt;
+                const int sx = s % SUBX, sy = s / SUBX;
+                const int oy0 = Y0 + sy * 4, ox0 = X0 + sx * 8 + 4 * half;
+                float* ob = a.out + ((size_t)(n * a.Hout + oy0) * a.Wout + ox0) * a.out_cs + co;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = (acc[mt][nt][r] + bs) * bt;
+                    v = fmaxf(v, v * slope);
+                    if (interior || (oy0 + (r >> 2) < a.Hout && ox0 + (r & 3) < a.Wout)) ob[(r >> 2) * rowp + (r & 3) * a.out_cs] = v;
+                }
+            }
+        }
+        return;
+    }
+    if (plain && GROUPED && a.out_mode == 1 && a.act == 0 && a.beta == nullptr) {
+        // transposed conv + PixelShuffle(2): value (parity group g, channel co) of input pixel (oy, ox) goes to plane c/4,
+        // component c%4 (c = co/4) of pixel (4*oy + 2*gy + (co>>1)&1, 4*ox + 2*gx + co&1) of the planar4 output
+        const int Ws = 4 * a.Wout, Hs = 4 * a.Hout;
+        const int planes = a.out_planes ? a.out_planes : 2;
+        const bool interior = Y0 + (SUBS / SUBX) * 4 <= a.Hout && X0 + SUBX * 8 <= a.Wout;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int co = co0 + nt * 32 + l31;
+            if (co >= a.Cout) continue;
+            const float bs = a.bias[g * a.Cout_p + co];
+            const int c = co >> 2;
+            float* lane_base = a.out + ((size_t)(n * planes + (c >> 2)) * Hs * Ws + (size_t)(2 * (g >> 1) + ((co >> 1) & 1)) * Ws +
+                                        2 * (g & 1) + (co & 1)) * 4 + (c & 3);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int s = wm * MT + mt;
+                const int sx = s % SUBX, sy = s / SUBX;
+                const int oy0 = Y0 + sy * 4, ox0 = X0 + sx * 8 + 4 * half;
+                float* ob = lane_base + ((size_t)(4 * oy0) * Ws + 4 * ox0) * 4;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (interior || (oy0 + (r >> 2) < a.Hout && ox0 + (r & 3) < a.Wout))
+                        ob[((r >> 2) * 4 * Ws + (r & 3) * 4) * 4] = acc[mt][nt][r] + bs;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = co0 + nt * 32 + l31;

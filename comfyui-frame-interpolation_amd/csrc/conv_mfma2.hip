@@ -215,26 +215,72 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
             frag(0, av[0], bv[0]);
 #pragma unroll
             for (int st = 0; st < NS; ++st) {
-                if (st + 1 < NS) frag(st + 1, av[(st + 1) & 1], bv[(st + 1) & 1]);
+                // Issue order matters twice.  (1) Consecutive MFMAs must rotate through ALL MT*NT accumulators: left alone, hipcc
+                // groups them by A operand (acc0, acc1, acc0, acc1, ...), halving the distance between dependent MFMAs.
+                // (2) The fragment reads of step s+1 are issued after the first accumulator round of step s: early enough to
+                // hide their latency under the remaining 3/4 of the step, late enough that the s_waitcnt lgkmcnt(0) hipcc puts
+                // in front of the step's first MFMA (it does not count the in-order LDS returns) only sees reads that had a
+                // whole step to complete.  (Pure-MFMA microbenchmark: 154 TFLOP/s; this loop before pinning: 122.)
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; ++j) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st & 1][mt][j], bv[st & 1][nt][j],
                                                                                acc[mt][nt], 0, 0, 0);
-                // pin the order "LDS reads of step s+1, then the MFMAs of step s" (hipcc otherwise sinks the reads
-                // next to their first use and exposes the LDS latency once per step)
-                if (st + 1 < NS) __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT * NT, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (j == 0 && st + 1 < NS) {
+                        frag(st + 1, av[(st + 1) & 1], bv[(st + 1) & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
             }
             __syncthreads();  // chunk consumed by every wave; the next chunk has landed
             buf ^= 1;
         }
 
         // ---- epilogue (stores are fire-and-forget; the next tile's MFMAs start right behind them)
-        {
+        // Fast path, decided once per tile with uniform branches: plain NHWC store of an interior tile, activation none /
+        // LeakyReLU with a slope in [0,1] (then lrelu(v) == max(v, v*slope)), residual folded.  The generic path below
+        // re-tests act / res / beta / bounds for each of the 64 values of a lane — ~4000 instructions and ~700 scalar branches
+        // per tile, during which this wave feeds no MFMAs.
+        const bool fast = !EXT && !GROUPED && a.res == nullptr && a.out_mode == 0 && a.act != 2 &&
+                          (a.act == 0 || (a.slope >= 0.f && a.slope <= 1.f));
+        if (fast) {
+            const float slope = a.act == 1 ? a.slope : 1.0f;
+            const int rowp = a.Wout * a.out_cs;
+            const bool interior = Y0 + THO <= a.Hout && X0 + TWO <= a.Wout;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int co = co0 + nt * 32 + l31;
+                if (co < a.Cout) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const int s = wm * MT + mt;
+                        const int sx = s % SUBX, sy = s / SUBX;
+                        const int oy0 = Y0 + sy * 4, ox0 = X0 + sx * 8 + 4 * half;
+                        float* ob = a.out + ((size_t)(n * a.Hout + oy0) * a.Wout + ox0) * a.out_cs + co;
+                        if (interior) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                float v = (acc[mt][nt][r] + bs[nt]) * bt[nt];
+                                v = fmaxf(v, v * slope);
+                                ob[(r >> 2) * rowp + (r & 3) * a.out_cs] = v;
+                            }
+                        } else {   // image border: same arithmetic, stores predicated per row / column
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                float v = (acc[mt][nt][r] + bs[nt]) * bt[nt];
+                                v = fmaxf(v, v * slope);
+                                if (oy0 + (r >> 2) < a.Hout && ox0 + (r & 3) < a.Wout) ob[(r >> 2) * rowp + (r & 3) * a.out_cs] = v;
+                            }
+                        }
+                    }
+                }
+            }
+        } else {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int co = co0 + nt * 32 + l31;

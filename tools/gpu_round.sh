@@ -1,8 +1,9 @@
 #!/bin/bash
 export TMPDIR=/tmp
-mkdir -p gpurun_out
-rm -rf gpurun_out/prof_lds
-timeout 240 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_BUSY_CYCLES -d gpurun_out/prof_lds -o lds -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --batch 8 > gpurun_out/prof_lds.log 2>&1
-python tools/rocprof_summary.py pmc gpurun_out/prof_lds > gpurun_out/r01c_pmc_LDS_planar.txt 2>&1
-head -9 gpurun_out/r01c_pmc_LDS_planar.txt
-rm -rf gpurun_out/prof_lds
+timeout 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_rife.py tests/test_gpu_film.py -x -q -m gpu -k "not 4k and not config2" 2>&1 | tail -3
+timeout 200 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --batch 8 2>/dev/null | python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); k=d['kernels']; print('value', d['value'], 'roofline', d['roofline']['achieved'], ' '.join(f\"{n}={v['ms']/v['calls']*1e3:.0f}us\" for n,v in k.items() if n.startswith(('resconv','conv0','lastconv'))))
+"
