@@ -178,33 +178,47 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     // ---- epilogue: lane holds output channel co for 16 pixels of each sub-tile
     // Fast paths chosen once per workgroup (uniform): the generic loop below re-tests act / res / beta / out_mode for every
     // one of the 16*MT*NT values of a lane (hundreds of scalar branches per tile).
-    const bool plain = !EXT && a.res == nullptr && a.act != 2 && (a.act == 0 || (a.slope >= 0.f && a.slope <= 1.f));
-    if (plain && !GROUPED && a.out_mode == 0) {   // NHWC store, activation none / LeakyReLU(slope in [0,1]) = max(v, v*slope)
-        const float slope = a.act == 1 ? a.slope : 1.0f;
-        const int rowp = a.Wout * a.out_cs;
+    const bool plain = a.res == nullptr && (a.act == 0 || a.act == 1 || (EXT && a.act == 3)) && !(EXT && a.post_scale != 0.f);
+    const bool nhwc = a.out_mode == 0 && !GROUPED;
+    const bool inter = EXT && GROUPED && a.out_mode == 2;       // transposed conv, parity groups interleaved into NHWC
+    if (plain && (nhwc || inter)) {
+        const int m = inter ? 2 : 1;
+        const int xstr = m * a.out_cs, ystr = m * m * a.Wout * a.out_cs;
         const bool interior = Y0 + (SUBS / SUBX) * 4 <= a.Hout && X0 + SUBX * 8 <= a.Wout;
+        const bool unif01 = a.act == 0 || (a.act == 1 && a.slope >= 0.f && a.slope <= 1.f);
+        const float uslope = a.act == 1 ? a.slope : 1.0f;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int co = co0 + nt * 32 + l31;
             if (co >= a.Cout) continue;
-            const float bs = a.bias[co], bt = a.beta ? a.beta[co] : 1.f;
+            const float bs = a.bias[g * a.Cout_p + co], bt = a.beta ? a.beta[co] : 1.f;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int s = wm * MT + mt;
                 const int sx = s % SUBX, sy = s / SUBX;
                 const int oy0 = Y0 + sy * 4, ox0 = X0 + sx * 8 + 4 * half;
-                float* ob = a.out + ((size_t)(n * a.Hout + oy0) * a.Wout + ox0) * a.out_cs + co;
+                float* ob = a.out + ((size_t)(n * m * a.Hout + m * oy0 + (inter ? (g >> 1) : 0)) * (m * a.Wout) + m * ox0 +
+                                     (inter ? (g & 1) : 0)) * a.out_cs + co;
+                if (unif01 && interior) {   // the common case: uniform slope in [0,1] -> lrelu(v) == max(v, v*slope)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = (acc[mt][nt][r] + bs) * bt;
-                    v = fmaxf(v, v * slope);
-                    if (interior || (oy0 + (r >> 2) < a.Hout && ox0 + (r & 3) < a.Wout)) ob[(r >> 2) * rowp + (r & 3) * a.out_cs] = v;
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = (acc[mt][nt][r] + bs) * bt;
+                        ob[(r >> 2) * ystr + (r & 3) * xstr] = fmaxf(v, v * uslope);
+                    }
+                } else {
+                    const float sl = a.act == 0 ? 1.0f : (a.act == 1 ? a.slope : a.prelu[co]);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = (acc[mt][nt][r] + bs) * bt;
+                        v = v > 0.f ? v : v * sl;
+                        if (interior || (oy0 + (r >> 2) < a.Hout && ox0 + (r & 3) < a.Wout)) ob[(r >> 2) * ystr + (r & 3) * xstr] = v;
+                    }
                 }
             }
         }
         return;
     }
-    if (plain && GROUPED && a.out_mode == 1 && a.act == 0 && a.beta == nullptr) {
+    if (!EXT && plain && GROUPED && a.out_mode == 1 && a.act == 0 && a.beta == nullptr) {
         // transposed conv + PixelShuffle(2): value (parity group g, channel co) of input pixel (oy, ox) goes to plane c/4,
         // component c%4 (c = co/4) of pixel (4*oy + 2*gy + (co>>1)&1, 4*ox + 2*gx + co&1) of the planar4 output
         const int Ws = 4 * a.Wout, Hs = 4 * a.Hout;

@@ -246,12 +246,17 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
         // LeakyReLU with a slope in [0,1] (then lrelu(v) == max(v, v*slope)), residual folded.  The generic path below
         // re-tests act / res / beta / bounds for each of the 64 values of a lane — ~4000 instructions and ~700 scalar branches
         // per tile, during which this wave feeds no MFMAs.
-        const bool fast = !EXT && !GROUPED && a.res == nullptr && a.out_mode == 0 && a.act != 2 &&
-                          (a.act == 0 || (a.slope >= 0.f && a.slope <= 1.f));
+        const bool nhwc = a.out_mode == 0 && !GROUPED;
+        const bool inter = EXT && GROUPED && a.out_mode == 2;       // transposed conv, parity groups interleaved into NHWC
+        const bool fast = a.res == nullptr && (nhwc || inter) && (a.act == 0 || a.act == 1 || (EXT && a.act == 3)) &&
+                          !(EXT && a.post_scale != 0.f);
         if (fast) {
-            const float slope = a.act == 1 ? a.slope : 1.0f;
-            const int rowp = a.Wout * a.out_cs;
+            // element (r) of a sub-tile -> output pixel: NHWC (oy, ox); interleaved (2*oy + gy, 2*ox + gx) of a [2H, 2W] image
+            const int m = inter ? 2 : 1;
+            const int xstr = m * a.out_cs, ystr = m * m * a.Wout * a.out_cs;
             const bool interior = Y0 + THO <= a.Hout && X0 + TWO <= a.Wout;
+            const bool unif01 = a.act == 0 || (a.act == 1 && a.slope >= 0.f && a.slope <= 1.f);
+            const float uslope = a.act == 1 ? a.slope : 1.0f;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int co = co0 + nt * 32 + l31;
@@ -261,20 +266,21 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
                         const int s = wm * MT + mt;
                         const int sx = s % SUBX, sy = s / SUBX;
                         const int oy0 = Y0 + sy * 4, ox0 = X0 + sx * 8 + 4 * half;
-                        float* ob = a.out + ((size_t)(n * a.Hout + oy0) * a.Wout + ox0) * a.out_cs + co;
-                        if (interior) {
+                        float* ob = a.out + ((size_t)(n * m * a.Hout + m * oy0 + (inter ? (g >> 1) : 0)) * (m * a.Wout) + m * ox0 +
+                                             (inter ? (g & 1) : 0)) * a.out_cs + co;
+                        if (unif01 && interior) {   // the common case: uniform slope in [0,1] -> lrelu(v) == max(v, v*slope)
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
-                                float v = (acc[mt][nt][r] + bs[nt]) * bt[nt];
-                                v = fmaxf(v, v * slope);
-                                ob[(r >> 2) * rowp + (r & 3) * a.out_cs] = v;
+                                const float v = (acc[mt][nt][r] + bs[nt]) * bt[nt];
+                                ob[(r >> 2) * ystr + (r & 3) * xstr] = fmaxf(v, v * uslope);
                             }
-                        } else {   // image border: same arithmetic, stores predicated per row / column
+                        } else {                    // image border and / or per-channel (or out-of-range) slopes
+                            const float sl = a.act == 0 ? 1.0f : (a.act == 1 ? a.slope : a.prelu[co]);
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
                                 float v = (acc[mt][nt][r] + bs[nt]) * bt[nt];
-                                v = fmaxf(v, v * slope);
-                                if (oy0 + (r >> 2) < a.Hout && ox0 + (r & 3) < a.Wout) ob[(r >> 2) * rowp + (r & 3) * a.out_cs] = v;
+                                v = v > 0.f ? v : v * sl;
+                                if (interior || (oy0 + (r >> 2) < a.Hout && ox0 + (r & 3) < a.Wout)) ob[(r >> 2) * ystr + (r & 3) * xstr] = v;
                             }
                         }
                     }
