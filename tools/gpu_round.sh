@@ -1,11 +1,9 @@
 #!/bin/bash
 export TMPDIR=/tmp
-for i in 1 2; do
-timeout 200 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --batch 8 2>/dev/null | python -c "
-import json,sys
-for l in sys.stdin:
-    if l.startswith('{'):
-        d=json.loads(l); k=d['kernels']; print('value', d['value'], 'roofline', d['roofline']['achieved'])
-"
-done
-timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_rife.py tests/test_gpu_film.py tests/test_gpu_m2m.py -x -q -m gpu -k "not 4k and not config2 and not 1080p" 2>&1 | tail -2
+mkdir -p gpurun_out
+bash tools/profile_round.sh r01d > gpurun_out/profile_round.log 2>&1
+grep -A3 "^kernel" gpurun_out/r01d_kernel_stats.txt | head -5
+head -3 gpurun_out/r01d_pmc_FETCH_SIZE.txt; head -3 gpurun_out/r01d_pmc_WRITE_SIZE.txt; head -4 "gpurun_out/r01d_pmc_SQ_VALU_MFMA_BUSY_CYCLES+SQ_BUSY_CYCLES+.txt"
+timeout 200 python tools/m2m_bench.py 2>&1 | grep -E "prepare" | tail -1
+timeout 200 python tools/film_bench.py 2>&1 | grep -E "ms per interpolated" | tail -1
+timeout 200 python tools/rife_arch_bench.py 2>&1 | grep "^RIFE"
