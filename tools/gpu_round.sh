@@ -1,9 +1,10 @@
 #!/bin/bash
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-bash tools/profile_round.sh r01d > gpurun_out/profile_round.log 2>&1
-grep -A3 "^kernel" gpurun_out/r01d_kernel_stats.txt | head -5
-head -3 gpurun_out/r01d_pmc_FETCH_SIZE.txt; head -3 gpurun_out/r01d_pmc_WRITE_SIZE.txt; head -4 "gpurun_out/r01d_pmc_SQ_VALU_MFMA_BUSY_CYCLES+SQ_BUSY_CYCLES+.txt"
-timeout 200 python tools/m2m_bench.py 2>&1 | grep -E "prepare" | tail -1
-timeout 200 python tools/film_bench.py 2>&1 | grep -E "ms per interpolated" | tail -1
-timeout 200 python tools/rife_arch_bench.py 2>&1 | grep "^RIFE"
+: > gpurun_out/r01d_pmc_waves.txt
+for grp in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_SMEM"; do
+rm -rf gpurun_out/prof_w
+timeout 200 rocprofv3 --kernel-trace --pmc $grp -d gpurun_out/prof_w -o w -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --batch 8 > gpurun_out/prof_w.log 2>&1
+python tools/rocprof_summary.py pmc gpurun_out/prof_w "conv_mfma2_kernel<1, 9, 2, 2" 2>&1 | tee -a gpurun_out/r01d_pmc_waves.txt | head -6
+done
+rm -rf gpurun_out/prof_w
