@@ -360,7 +360,10 @@ int conv_pick_variant(const ConvArgs& a, int stride, bool grouped) {
         return kConv2Base + (a.ntaps == 4 ? 19 : 18);
     }
     const long cus = n_cus_cached();
-    if (grouped) return a.Cin_p % 16 == 0 ? 13 : kConv2Base + 11;
+    if (grouped) {  // big pixel-shuffled block outputs (RIFE lastconv of blocks 2/3): LDS-DMA variant dg_m4 (8 % faster there)
+        if (a.out_mode == 1 && px >= 250000) return kConv2Base + 11;
+        return a.Cin_p % 16 == 0 ? 13 : kConv2Base + 11;
+    }
     const bool n3 = a.Cout_p % 96 == 0;
     const bool n2 = a.Cout_p % 64 == 0;
     (void)cus;

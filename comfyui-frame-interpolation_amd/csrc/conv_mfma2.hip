@@ -286,6 +286,31 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
                     }
                 }
             }
+        } else if (!EXT && GROUPED && a.out_mode == 1 && a.act == 0 && a.beta == nullptr && a.res == nullptr) {
+            // transposed conv + PixelShuffle(2) into the planar4 block output (see conv_mfma.hip)
+            const int Ws = 4 * a.Wout, Hs = 4 * a.Hout;
+            const int planes = a.out_planes ? a.out_planes : 2;
+            const bool interior = Y0 + THO <= a.Hout && X0 + TWO <= a.Wout;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int co = co0 + nt * 32 + l31;
+                if (co < a.Cout) {
+                    const int c = co >> 2;
+                    float* lane_base = a.out + ((size_t)(n * planes + (c >> 2)) * Hs * Ws + (size_t)(2 * (g >> 1) + ((co >> 1) & 1)) * Ws +
+                                                2 * (g & 1) + (co & 1)) * 4 + (c & 3);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const int s = wm * MT + mt;
+                        const int sx = s % SUBX, sy = s / SUBX;
+                        const int oy0 = Y0 + sy * 4, ox0 = X0 + sx * 8 + 4 * half;
+                        float* ob = lane_base + ((size_t)(4 * oy0) * Ws + 4 * ox0) * 4;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (interior || (oy0 + (r >> 2) < a.Hout && ox0 + (r & 3) < a.Wout))
+                                ob[((r >> 2) * 4 * Ws + (r & 3) * 4) * 4] = acc[mt][nt][r] + bs[nt];
+                    }
+                }
+            }
         } else {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
