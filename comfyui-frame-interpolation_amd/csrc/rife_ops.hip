@@ -16,6 +16,7 @@
 // :645,698-699; final blend :721-723,732; encode :414-416.
 #include "rife_ops.h"
 #include "rife_warp.h"
+#include <cstdlib>
 
 namespace vfi {
 
@@ -540,6 +541,181 @@ __global__ __launch_bounds__(256) void stage_trans_kernel(const float* __restric
     for (int q = 0; q < NR / 4; ++q) op[(size_t)q * Hs * Ws] = make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
 }
 
+// ---------------------------------------------------------------------------------------
+// The same transition with one thread per warped pixel (SP = 2, 4, 8).  The cell-per-thread kernel above touches F with
+// a lane stride of SP pixels (SP store instructions per row, each filling 1/SP of the lines it touches) and walks its
+// 4 centre pixels one after the other; at SP = 2 every pixel is a centre pixel and that kernel ran at ~2.2 TB/s.
+// Here the 4 lanes of a quad are the 2x2 centre pixels of one cell:
+//   * F is updated with row-contiguous accesses (SP >= 4: a separate pass over the (16 SP)x(4 SP)-pixel tile, the centre
+//     pixels' flow/mask/features handed to their quad lanes through 5-13 KB of LDS; SP = 2: the quad lanes themselves);
+//   * the 2x2 T pixels that a cell up-samples from are loaded one corner per lane and exchanged with quad DPP moves;
+//   * the down-resize (weights 1/2, torch's row-then-column order) is two quad swaps per channel;
+//   * each lane of the quad stores a different planar4 plane of X.
+// Arithmetic is expression-for-expression the cell kernel's; results agree to rounding noise (hipcc chooses the FMA
+// contractions of the bilinear expressions per kernel: max 1.5e-5 on the output, tests/test_gpu_rife.py).
+// ---------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ static inline float quad_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// One pixel of the block output T as 5+NX floats: flow delta 4, mask, then (arch 4.26, NX = 8) the carried features.
+// NX = 0: planar4 [2][Hs][Ws][4] (plane 1 = mask,-,-,-); NX = 8: [4][Hs][Ws][4] (mask,g0..g2 | g3..g6 | g7,-,-,-).
+// FULL = false reads the flow plane only.
+template <int NX, bool FULL>
+__device__ static inline void tq_read(const float* __restrict__ Tb, int Hs, int Ws, int Yt, int Xt, float* v) {
+    const size_t p = (size_t)Yt * Ws + Xt, ps = (size_t)Hs * Ws;
+    const float4 f = ((const float4*)Tb)[p];
+    v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+    if constexpr (FULL) {
+        if constexpr (NX == 0) {
+            v[4] = Tb[(ps + p) * 4];
+        } else {
+            const float4 p1 = ((const float4*)Tb)[ps + p], p2 = ((const float4*)Tb)[2 * ps + p];
+            v[4] = p1.x; v[5] = p1.y; v[6] = p1.z; v[7] = p1.w;
+            v[8] = p2.x; v[9] = p2.y; v[10] = p2.z; v[11] = p2.w;
+            v[4 + NX] = Tb[(3 * ps + p) * 4];
+        }
+    }
+}
+// up-sampled T at pixel (X,Y); the quad's 4 lanes must share the 2x2 source pixels (same cell row/column run):
+// lane ql fetches corner (ql>>1, ql&1), quad broadcasts (quad_perm [j,j,j,j]) deliver the other three.
+template <int NX, bool FULL>
+__device__ static inline void t_upsample_quad(const float* __restrict__ Tb, int Hi, int Wi, float rs, int Y, int X, int ql,
+                                              float* out) {
+    constexpr int N = FULL ? 5 + NX : 4;
+    const Bil by = bil_index(Y, rs, Hi), bx = bil_index(X, rs, Wi);
+    float mine[5 + NX];
+    tq_read<NX, FULL>(Tb, Hi, Wi, (ql >> 1) ? by.i1 : by.i0, (ql & 1) ? bx.i1 : bx.i0, mine);
+    const float wy0 = by.w0, wy1 = by.w1, wx0 = bx.w0, wx1 = bx.w1;
+    // torch upsample_bilinear2d: wy0*(wx0*a + wx1*b) + wy1*(wx0*c + wx1*d), as t_bilerp
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const float a = quad_f<0x00>(mine[j]), bb = quad_f<0x55>(mine[j]), c = quad_f<0xAA>(mine[j]), d = quad_f<0xFF>(mine[j]);
+        out[j] = __fadd_rn(__fmul_rn(wy0, __fadd_rn(__fmul_rn(wx0, a), __fmul_rn(wx1, bb))),
+                           __fmul_rn(wy1, __fadd_rn(__fmul_rn(wx0, c), __fmul_rn(wx1, d))));
+    }
+}
+
+template <int SP, bool HAS_PREV, int NF, int NX>
+__global__ __launch_bounds__(256) void stage_trans_quad_kernel(const float* __restrict__ Ppool, size_t pack_stride,
+                                                               RifeTasks tasks, const float* __restrict__ T,
+                                                               float* __restrict__ F, float* __restrict__ Xo, int Hp,
+                                                               int Wp, int tiles_x) {
+    static_assert(SP == 2 || SP == 4 || SP == 8, "quad transition: block scales 4->2, 8->4, 16->8");
+    static_assert(NX == 0 || (NX == 8 && NF == 1), "carried block features: arch 4.26 only");
+    constexpr int SI = 2 * SP;          // scale of the block that produced T
+    constexpr int OFF = SP / 2 - 1;     // first centre pixel of a cell
+    constexpr int NV = 5 + NX;          // flow 4, mask, carried features
+    const int Hs = Hp / SP, Ws = Wp / SP, Hi = Hp / SI, Wi = Wp / SI;
+    const int b = blockIdx.y;
+    const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x - tile_y * tiles_x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ql = lane & 3;
+    const float* Tb = T + (size_t)b * Hi * Wi * (NX ? 16 : 8);
+    const float rs = 1.0f / (float)SI, fs = (float)SI;
+    // block tile = 16 x 4 cells; a wave is one row of 16 cells, a quad one cell
+    const int xl = tile_x * 16 + (lane >> 2), yl = tile_y * 4 + wave;
+    const int X = xl * SP + OFF + (ql & 1), Y = yl * SP + OFF + (ql >> 1);
+    const bool cell_ok = xl < Ws && yl < Hs;
+    float v[NV];   // this centre pixel: updated flow, mask, carried features
+    if constexpr (SP == 2) {
+        if (!cell_ok) return;   // whole quads leave together
+        t_upsample_quad<NX, true>(Tb, Hi, Wi, rs, Y, X, ql, v);
+        const size_t pb = (size_t)b * Hp * Wp + (size_t)Y * Wp + X;
+        float4 f = make_float4(v[0] * fs, v[1] * fs, v[2] * fs, v[3] * fs);
+        if (HAS_PREV) {
+            const float4 o = ((const float4*)F)[pb];
+            f = make_float4(o.x + f.x, o.y + f.y, o.z + f.z, o.w + f.w);
+        }
+        ((float4*)F)[pb] = f;
+        v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+    } else {
+        // ---- phase 1: flow (+)= up(T)*SI over the (16*SP)x(4*SP)-pixel tile, 64 contiguous pixels per wave and pass;
+        // a quad is 4 pixels of one cell row, so it shares its 2x2 T pixels
+        __shared__ float centre[NV][256];
+#pragma unroll
+        for (int p = 0; p < SP; ++p) {
+            constexpr int NH = SP / 4;
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                const int col = h * 64 + lane;
+                const int Yp = yl * SP + p, Xp = tile_x * 16 * SP + col;
+                if (Xp < Wp && Yp < Hp) {
+                    const bool crow = p == OFF || p == OFF + 1;   // a row with centre pixels: mask / features too
+                    float u[NV];
+                    if (crow) t_upsample_quad<NX, true>(Tb, Hi, Wi, rs, Yp, Xp, ql, u);
+                    else t_upsample_quad<NX, false>(Tb, Hi, Wi, rs, Yp, Xp, ql, u);
+                    const size_t pb = (size_t)b * Hp * Wp + (size_t)Yp * Wp + Xp;
+                    float4 fp = make_float4(u[0] * fs, u[1] * fs, u[2] * fs, u[3] * fs);
+                    if (HAS_PREV) {
+                        const float4 o = ((const float4*)F)[pb];
+                        fp = make_float4(o.x + fp.x, o.y + fp.y, o.z + fp.z, o.w + fp.w);
+                    }
+                    ((float4*)F)[pb] = fp;
+                    const int ix = col & (SP - 1);
+                    if (crow && (ix == OFF || ix == OFF + 1)) {   // a centre pixel: hand over to its quad lane
+                        const int dst = wave * 64 + (col / SP) * 4 + (ix - OFF) + ((p - OFF) << 1);
+                        centre[0][dst] = fp.x; centre[1][dst] = fp.y; centre[2][dst] = fp.z; centre[3][dst] = fp.w;
+#pragma unroll
+                        for (int j = 4; j < NV; ++j) centre[j][dst] = u[j];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (!cell_ok) return;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) v[j] = centre[j][threadIdx.x];
+    }
+    // ---- phase 2: warp both frame packs at this centre pixel, down-resize across the quad, write X
+    const float* P0 = Ppool + (size_t)tasks.slot0[b] * pack_stride;
+    const float* P1 = Ppool + (size_t)tasks.slot1[b] * pack_stride;
+    const size_t hi_off = (size_t)Hp * Wp * 4;
+    const WarpGeo g = make_warp_geo(Wp, Hp);
+    constexpr int NC = 12 + 8 * NF + NX;     // images, features, timestep, mask, carried features, flow
+    constexpr int NR = (NC + 7) / 8 * 8;     // X channels (zero padded)
+    float r[NR];
+    {
+        const Tap4 t0 = warp_taps(g, X, Y, v[0], v[1]);
+        const Tap4 t1 = warp_taps(g, X, Y, v[2], v[3]);
+        float4 a_lo, b_lo, a_hi[NF], b_hi[NF];
+        sample_pack<NF>(P0, hi_off, t0, a_lo, a_hi);
+        sample_pack<NF>(P1, hi_off, t1, b_lo, b_hi);
+        cat_inputs<NF>(r, a_lo, b_lo, a_hi, b_hi, tasks.t[b]);
+#pragma unroll
+        for (int j = 4; j < NV; ++j) r[3 + 8 * NF + j] = v[j];   // mask at 7+8NF, carried features after it
+        r[NC - 4] = v[0]; r[NC - 3] = v[1]; r[NC - 2] = v[2]; r[NC - 1] = v[3];
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {   // 0.5*left + 0.5*right, then 0.5*top + 0.5*bottom (all four lanes get the result)
+        const float row = __fadd_rn(0.5f * r[c], 0.5f * quad_f<0xB1>(r[c]));
+        r[c] = __fadd_rn(0.5f * row, 0.5f * quad_f<0x4E>(row));
+    }
+#pragma unroll
+    for (int c = NC; c < NR; ++c) r[c] = 0.f;
+    const float inv_s = 1.0f / (float)SP;
+#pragma unroll
+    for (int c = NC - 4; c < NC; ++c) r[c] = r[c] * inv_s;  // interpolate(flow) * 1.0 / scale
+    float4* op = (float4*)Xo + (size_t)b * (NR / 4) * Hs * Ws + (size_t)yl * Ws + xl;
+#pragma unroll
+    for (int base = 0; base < NR / 4; base += 4) {   // lane ql of the quad stores plane base+ql
+        float4 val = make_float4(r[4 * base], r[4 * base + 1], r[4 * base + 2], r[4 * base + 3]);
+#pragma unroll
+        for (int j = 1; j < 4; ++j)
+            if (base + j < NR / 4 && ql == j)
+                val = make_float4(r[4 * (base + j)], r[4 * (base + j) + 1], r[4 * (base + j) + 2], r[4 * (base + j) + 3]);
+        if (base + ql < NR / 4) op[(size_t)(base + ql) * Hs * Ws] = val;
+    }
+}
+
+// VFI_STAGE_QUAD: bit mask of the next-block scales (2, 4, 8) that take the quad kernel; default all
+static int stage_quad_mask() {
+    static const int mask = [] {
+        const char* e = getenv("VFI_STAGE_QUAD");
+        return e && *e ? atoi(e) : 14;
+    }();
+    return mask;
+}
+
 int stage_trans_launch(const float* Ppool, size_t pack_stride, const RifeTasks& tasks, int B, const float* T, float* F,
                        float* X, int Hp, int Wp, int s_prev, int s_next, int NF, bool has_prev, hipStream_t st) {
     VFI_REQUIRE(s_prev == 2 * s_next && (s_next == 4 || s_next == 2 || s_next == 1) && (NF == 1 || NF == 2),
@@ -548,6 +724,23 @@ int stage_trans_launch(const float* Ppool, size_t pack_stride, const RifeTasks& 
     const int tiles_x = cdiv(Ws, 16), tiles_y = cdiv(Hs, 16);
     dim3 grid(tiles_x * tiles_y, B);
     TraceScope ts("stage_trans", st);
+    if ((s_next == 2 || s_next == 4) && (stage_quad_mask() & s_next)) {
+        const int qtx = cdiv(Ws, 16);
+        dim3 qgrid(qtx * cdiv(Hs, 4), B);
+#define VFI_SQ(SPV, HP, NFV) \
+    hipLaunchKernelGGL((stage_trans_quad_kernel<SPV, HP, NFV, 0>), qgrid, dim3(256), 0, st, Ppool, pack_stride, tasks, T, F, X, Hp, Wp, qtx)
+#define VFI_SQ2(SPV, HP) \
+    do { if (NF == 1) VFI_SQ(SPV, HP, 1); else VFI_SQ(SPV, HP, 2); } while (0)
+        if (s_next == 4) {
+            if (has_prev) VFI_SQ2(4, true); else VFI_SQ2(4, false);
+        } else {
+            if (has_prev) VFI_SQ2(2, true); else VFI_SQ2(2, false);
+        }
+#undef VFI_SQ2
+#undef VFI_SQ
+        VFI_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
 #define VFI_ST(SPV, HP, NFV) \
     hipLaunchKernelGGL((stage_trans_kernel<SPV, HP, NFV>), grid, dim3(256), 0, st, Ppool, pack_stride, tasks, T, F, X, Hp, Wp, tiles_x)
 #define VFI_ST2(SPV, HP) \
@@ -705,6 +898,21 @@ int stage_trans_x_launch(const float* Ppool, size_t pack_stride, const RifeTasks
     const int tiles_x = cdiv(Ws, 16), tiles_y = cdiv(Hs, 16);
     dim3 grid(tiles_x * tiles_y, B);
     TraceScope ts("stage_trans", st);
+    if (s_next >= 2 && (stage_quad_mask() & s_next)) {
+        const int qtx = cdiv(Ws, 16);
+        dim3 qgrid(qtx * cdiv(Hs, 4), B);
+#define VFI_SQ(SPV, HP) \
+    hipLaunchKernelGGL((stage_trans_quad_kernel<SPV, HP, 1, 8>), qgrid, dim3(256), 0, st, Ppool, pack_stride, tasks, T, F, X, Hp, Wp, qtx)
+#define VFI_SQ2(SPV) \
+    do { if (has_prev) VFI_SQ(SPV, true); else VFI_SQ(SPV, false); } while (0)
+        if (s_next == 8) VFI_SQ2(8);
+        else if (s_next == 4) VFI_SQ2(4);
+        else VFI_SQ2(2);
+#undef VFI_SQ2
+#undef VFI_SQ
+        VFI_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
 #define VFI_ST(SPV, HP) \
     hipLaunchKernelGGL((stage_trans_x_kernel<SPV, HP>), grid, dim3(256), 0, st, Ppool, pack_stride, tasks, T, F, X, Hp, Wp, tiles_x)
 #define VFI_ST2(SPV) \

@@ -601,3 +601,43 @@ def test_resconv_beta_edge_cases(hip_lib):
         assert (got - want).abs().max().item() <= TOL, describe_diff(got, want, "beta edge cases")
     finally:
         eng.close()
+
+
+# ---- block transitions: quad-per-cell kernel (default) vs the cell-per-thread kernel -------------------------------
+_QUAD_SNIPPET = r"""
+import sys, torch
+sys.path.insert(0, {root!r})
+from pkgload import load_package
+load_package()
+from cfi_amd import synth
+from cfi_amd.rife import RifeEngine, run_tasks
+torch.cuda.set_device(0)
+outs = []
+for arch, mk in (("4.7", synth.rife47_synth_state_dict), ("4.17", synth.rife417_synth_state_dict)):
+    e = RifeEngine(mk(77), arch)
+    for h, w in ((70, 90), (200, 328)):
+        frames = synth.smooth_frames(3, h, w, seed=h, shift=3.0)
+        outs.append(run_tasks(e, frames, [(0, 0.5), (1, 0.3), (0, 0.8)], batch_size=3).cpu())
+    e.close()
+torch.save(outs, {out!r})
+"""
+
+
+def test_quad_transition_matches_cell_kernel(hip_lib, tmp_path):
+    """stage_trans_quad_kernel restates stage_trans_kernel expression for expression: VFI_STAGE_QUAD=0 (cell kernel
+    for every transition) and the default (quad kernel for the 8->4 and 4->2 transitions) must agree to rounding
+    noise, including frames whose padded size leaves partial 16x4-cell tiles.  Not to the bit: HIP's __fmul_rn /
+    __fadd_rn are plain operators, so hipcc picks the FMA contractions of the bilinear expressions per kernel
+    (measured: max 1.5e-5 on the output, run-to-run identical for either kernel)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mask in ("0", "6"):
+        out = str(tmp_path / f"quad{mask}.pt")
+        env = dict(os.environ, VFI_STAGE_QUAD=mask)
+        subprocess.run([sys.executable, "-c", _QUAD_SNIPPET.format(root=root, out=out)], check=True, env=env, timeout=300)
+        res[mask] = torch.load(out)
+    for a, b in zip(res["0"], res["6"]):
+        assert (a - b).abs().max().item() <= 5e-5, describe_diff(a, b, "quad vs cell transition")

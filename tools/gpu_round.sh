@@ -1,6 +1,7 @@
 #!/bin/bash
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 330 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-timeout 60 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-timeout 120 python bench.py 2>/dev/null | tail -1 | tee gpurun_out/final_bench.json
+timeout 300 python -m pytest tests/test_gpu_rife.py -x -q -m gpu -k "426 or 417 or quad" 2>&1 | tail -4
+(timeout 120 python tools/rife_arch_bench.py --split 2>&1 | grep -v amdgpu.ids
+echo "--- VFI_STAGE_QUAD=0 (cell kernels)"
+VFI_STAGE_QUAD=0 timeout 120 python tools/rife_arch_bench.py --split --arch=4.26 --arch=4.17 2>&1 | grep -v amdgpu.ids) | tee gpurun_out/arch_bench_quad.txt

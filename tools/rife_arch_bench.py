@@ -20,7 +20,10 @@ if __name__ == "__main__":
     fr = synth.smooth_frames(3, H, W, seed=1, shift=4.0)
     dev = [fr[i % 3].cuda().contiguous() for i in range(B + 1)]
     out = torch.empty((B, H, W, 3), device="cuda")
+    only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--arch=")]
     for arch, sdf in (("4.7", synth.rife47_synth_state_dict), ("4.17", synth.rife417_synth_state_dict), ("4.26", synth.rife426_synth_state_dict)):
+        if only and arch not in only:
+            continue
         eng = RifeEngine(sdf(1234), arch)
         eng.configure(H, W, B, 2 * B + 2, 1.0)
         for i in range(B + 1):
