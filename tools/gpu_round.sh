@@ -1,7 +1,12 @@
 #!/bin/bash
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 300 python -m pytest tests/test_gpu_rife.py -x -q -m gpu -k "426 or 417 or quad" 2>&1 | tail -4
-(timeout 120 python tools/rife_arch_bench.py --split 2>&1 | grep -v amdgpu.ids
-echo "--- VFI_STAGE_QUAD=0 (cell kernels)"
-VFI_STAGE_QUAD=0 timeout 120 python tools/rife_arch_bench.py --split --arch=4.26 --arch=4.17 2>&1 | grep -v amdgpu.ids) | tee gpurun_out/arch_bench_quad.txt
+CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf gpurun_out/prof_pmc_$c
+  timeout 100 rocprofv3 --kernel-trace --pmc $c -d gpurun_out/prof_pmc_$c -o pmc_$c -- $CMD > gpurun_out/prof_pmc_$c.log 2>&1
+  echo "$c rc=$?"
+  python tools/rocprof_summary.py pmc gpurun_out/prof_pmc_$c > gpurun_out/r01e_pmc_$c.txt 2>&1
+  head -14 gpurun_out/r01e_pmc_$c.txt | cut -c1-150
+  rm -rf gpurun_out/prof_pmc_$c
+done
