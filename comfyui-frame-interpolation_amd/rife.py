@@ -9,8 +9,9 @@ Differences that do not change results:
   * ``encode`` is evaluated once per input frame and cached on the device, not once per task;
   * ``fast_mode`` / ``ensemble`` are accepted and ignored — for arch 4.7 the reference's own call
     binds them to parameters that are inert (positional mis-binding, rife/__init__.py:200-207);
-  * ``torch_compile`` is ignored (kernels are ahead-of-time compiled), ``dtype`` other than
-    float32 warns and computes in float32 (the parity contract is fp32, |d| <= 1e-3).
+  * ``torch_compile`` is ignored (kernels are ahead-of-time compiled); ``dtype`` float16 / bfloat16
+    rounds the clip to that dtype on the way in and returns the IMAGE tensor in it, like the reference,
+    but computes in float32 (the parity contract is fp32, |d| <= 1e-3).
 """
 import ctypes as C
 import os
@@ -29,6 +30,7 @@ from .schedule import InterpolationStateList, rife_output_plan, rife_task_list, 
 
 MODEL_TYPE = "rife"
 DTYPE_OPTIONS = ["float32", "float16", "bfloat16"]
+DTYPE_MAP = {"float32": torch.float32, "float16": torch.float16, "bfloat16": torch.bfloat16}   # rife/__init__.py:23-27
 MAX_LIB_BATCH = 16  # kMaxTasks in csrc/rife_ops.h
 # Tasks are independent and every task's arithmetic is the same whatever it is batched with (only the conv tile variant,
 # i.e. the fp32 summation order, may depend on the launch size: differences ~1e-6), so the node's `batch_size` widget (default 1, rife/__init__.py:68-71) only trades memory for speed.  288 GB of HBM make
@@ -308,11 +310,20 @@ class RIFE_VFI:
         optional_interpolation_states: InterpolationStateList = None,
         **kwargs,
     ):
-        arch_ver = CKPT_NAME_VER_DICT[ckpt_name]
         if dtype not in DTYPE_OPTIONS:
             raise KeyError(dtype)
         if dtype != "float32":
-            warnings.warn(f"RIFE VFI (HIP): dtype={dtype} requested; this path computes in float32.")
+            # The reference casts model, inputs and the returned IMAGE tensor to the widget's dtype
+            # (rife/__init__.py:120-134,195-198,210,227-230).  Here the hot path always computes in fp32: the clip is
+            # rounded to the requested dtype on the way in (so pass-through frames are bit-identical to the
+            # reference's) and the result is returned in that dtype; new frames are the fp32 result, rounded once.
+            torch_dtype = DTYPE_MAP[dtype]
+            warnings.warn(f"RIFE VFI (HIP): dtype={dtype}: I/O in {dtype}, compute in float32.")
+            (out,) = self.vfi(ckpt_name, frames.to(torch_dtype).to(torch.float32), clear_cache_after_n_frames, multiplier,
+                              fast_mode, ensemble, scale_factor, "float32", torch_compile, batch_size,
+                              optional_interpolation_states, **kwargs)
+            return (out.to(torch_dtype),)
+        arch_ver = CKPT_NAME_VER_DICT[ckpt_name]
         cache_key = (ckpt_name,)
         if cache_key not in _model_cache:
             model_path = load_file_from_github_release(MODEL_TYPE, ckpt_name)

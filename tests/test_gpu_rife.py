@@ -215,6 +215,27 @@ def test_node_rejects_unsupported(hip_lib, sd, tmp_path, monkeypatch):
         R.RifeEngine(sd, "4.0")
 
 
+@pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
+def test_node_dtype_widget(hip_lib, sd, tmp_path, monkeypatch, dtype):
+    """dtype widget (rife/__init__.py:120-134,195-198,210,227-230): the reference returns the IMAGE tensor in the
+    requested dtype.  Here: clip rounded to that dtype on the way in, fp32 compute, result returned in that dtype."""
+    import cfi_amd.rife as R
+
+    pth = tmp_path / "rife47.pth"
+    torch.save(sd, pth)
+    monkeypatch.setattr(R, "load_file_from_github_release", lambda model_type, ckpt: str(pth))
+    td = getattr(torch, dtype)
+    frames = synth.smooth_frames(3, 70, 90, seed=5, shift=2.0)
+    with pytest.warns(UserWarning):
+        (out,) = R.RIFE_VFI().vfi("rife47.pth", frames, multiplier=2, dtype=dtype)
+    (ref,) = R.RIFE_VFI().vfi("rife47.pth", frames.to(td).to(torch.float32), multiplier=2)
+    assert out.dtype == td and out.device.type == "cpu" and out.shape == ref.shape == (5, 70, 90, 3)
+    assert torch.equal(out, ref.to(td))
+    assert torch.equal(out[0], frames[0].to(td)) and torch.equal(out[4], frames[2].to(td))   # pass-through frames
+    with pytest.raises(KeyError):
+        R.RIFE_VFI().vfi("rife47.pth", frames, dtype="float64")
+
+
 def test_config0_anime_pair_vs_reference_node(hip_lib, sd, golden_dir, tmp_path, monkeypatch):
     """BASELINE.json configs[0]: the node on the full demo pair anime0+anime1 (540x960), 2x, against the frame the
     reference node synthesised on torch-CPU (tests/golden/rife47_node_anime540.npz, oracle/make_golden.py)."""
