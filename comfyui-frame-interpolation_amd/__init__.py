@@ -1,4 +1,4 @@
-"""MI355X-native drop-in for the RIFE / FILM / M2M nodes of ComfyUI-Frame-Interpolation.
+"""MI355X-native drop-in for the RIFE / FILM / M2M / IFRNet nodes of ComfyUI-Frame-Interpolation.
 
 ComfyUI imports this directory as a custom-node package and reads
 ``NODE_CLASS_MAPPINGS`` (reference: /root/reference/__init__.py:24-48).  The node
@@ -10,6 +10,7 @@ _LAZY = {
     "RIFE_VFI": ("rife", "RIFE_VFI"),
     "FILM_VFI": ("film", "FILM_VFI"),
     "M2M_VFI": ("m2m", "M2M_VFI"),
+    "IFRNet_VFI": ("ifrnet", "IFRNet_VFI"),
     "MakeInterpolationStateList": ("schedule", "MakeInterpolationStateList"),
     "InterpolationStateList": ("schedule", "InterpolationStateList"),
 }
@@ -28,6 +29,7 @@ def __getattr__(name):
 
 def _node_class_mappings():
     from .film import FILM_VFI
+    from .ifrnet import IFRNet_VFI
     from .m2m import M2M_VFI
     from .rife import RIFE_VFI
     from .schedule import MakeInterpolationStateList
@@ -36,6 +38,7 @@ def _node_class_mappings():
         "RIFE VFI": RIFE_VFI,
         "FILM VFI": FILM_VFI,
         "M2M VFI": M2M_VFI,
+        "IFRNet VFI": IFRNet_VFI,
         "Make Interpolation State List": MakeInterpolationStateList,
     }
 
@@ -44,4 +47,5 @@ NODE_DISPLAY_NAME_MAPPINGS = {
     "RIFE VFI": "RIFE VFI (MI355X HIP; rife47 / rife49)",
     "FILM VFI": "FILM VFI (MI355X HIP)",
     "M2M VFI": "M2M VFI (MI355X HIP)",
+    "IFRNet VFI": "IFRNet VFI (MI355X HIP)",
 }

@@ -68,6 +68,16 @@ PROTOTYPES = {
     "vfi_absmax": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
     "vfi_rife40_output": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vfi_ifrnet_prep": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "vfi_ifrnet_center": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
+    "vfi_conv7x7s2_prelu": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_void_p]),
+    "vfi_sigmoid": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
+    "vfi_fill_items": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, c_float_p, C.c_void_p]),
+    "vfi_resize_bilinear_ratio": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "vfi_ifrnet_output": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vfi_rife_create": (C.c_void_p, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int]),
     "vfi_rife_destroy": (None, [C.c_void_p]),
     "vfi_rife_configure": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]),

@@ -373,7 +373,7 @@ int conv_pick_variant(const ConvArgs& a, int stride, bool grouped) {
         return 10;                       // s2_m1n1
     }
     if (n2) return a.Cout_p == 64 ? kConv2Base + 0 : kConv2Base + 2;  // d1_m2n2 / d1_m1n2
-    if (n3) return px >= 100000 ? kConv2Base + 3 : 4;                  // d1_m1n3 / s1_m1n1
+    if (n3) return px >= 100000 || a.Cin_p % 16 ? kConv2Base + 3 : 4;  // d1_m1n3 / s1_m1n1 (K chunk 16)
     return a.Cin_p % 16 == 0 && px < 20000 ? 4 : kConv2Base + 13;      // 32-channel N tile: s1_m1n1 / d1_m2n1
 }
 

@@ -318,14 +318,14 @@ def _load_state_dict(path):
     return sd.state_dict() if hasattr(sd, "state_dict") else sd
 
 
-def run_plan(engine, frames, plan, tasks):
+def run_plan(engine, frames, plan, tasks, name="M2M VFI"):
     """Shared by the node and the tests.  frames: [N,H,W,C] host tensor; plan/tasks from generic_output_plan.
 
     Pairs are independent: the (pair, timesteps) tasks are block-partitioned over ranks and the new frames
     all-gathered.  Host side (hostpipe.py): every needed frame is uploaded once through pinned staging ahead of the
     compute stream; new frames and pass-through frames land in their final rows of the output tensor in the background."""
     if not plan:  # list multiplier of zeros: the reference fails in torch.cat of an empty list (vfi_utils.py:386)
-        raise RuntimeError("M2M VFI: every frame pair was dropped (multiplier 0 everywhere) - nothing to output")
+        raise RuntimeError(f"{name}: every frame pair was dropped (multiplier 0 everywhere) - nothing to output")
     dev = engine.device
     frames = frames[..., :3]
     H, W = frames.shape[1:3]

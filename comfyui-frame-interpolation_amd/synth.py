@@ -119,6 +119,27 @@ def m2m_synth_state_dict(seed=1234, gain=1.0):
     return sd
 
 
+def ifrnet_synth_state_dict(kind="L", seed=1234, gain=1.0):
+    """IFRNet_L / IFRNet_S: conv weights U(+-gain*sqrt(3/fan_in)) (roughly variance preserving through the PReLU
+    trunk, so the decoders emit flows of a few pixels), biases U(+-0.05), PReLU slopes U(0.1, 0.4)."""
+    from .ifrnet_spec import ifrnet_shapes
+
+    sd = {}
+    for k, shp in ifrnet_shapes(kind).items():
+        g = _gen(seed, kind + k)
+        if len(shp) == 4:
+            fan_in = 1
+            for d in shp[1:]:
+                fan_in *= d
+            t = (torch.rand(shp, generator=g) * 2 - 1) * (gain * math.sqrt(3.0 / fan_in))
+        elif k.endswith("bias"):
+            t = (torch.rand(shp, generator=g) * 2 - 1) * 0.05
+        else:  # PReLU slopes
+            t = 0.1 + 0.3 * torch.rand(shp, generator=g)
+        sd[k] = t.to(torch.float32).contiguous()
+    return sd
+
+
 def smooth_frames(n, h, w, seed=0, shift=3.0, c=3):
     """[n,h,w,c] f32 in [0,1]: low-pass noise drifting ``shift`` px/frame (ComfyUI IMAGE layout)."""
     g = torch.Generator(device="cpu")

@@ -189,6 +189,35 @@ int vfi_absmax(const float* x_dev, int cs, int C, int64_t pixels, float* out_dev
 int vfi_rife40_output(const float* w01_dev, int w_cs, const float* mask_dev, int m_cs, const float* res_dev, int r_cs,
                       float* out_dev, int B, int Hp, int Wp, int H, int W, void* stream);
 
+/* ---- IFRNet building blocks (IFRNet_L / IFRNet_S checkpoints; ifrnet.py drives them with the layer objects above) -- */
+
+/* img{0,1} [Hp,Wp,4] = (frame{0,1}.rgb, 0), zero in the padding: F.pad of both frames, no clamp
+ * (vfi_models/ifrnet/IFRNet_L_arch.py:230-235).  frames [H,W,C>=3]. */
+int vfi_ifrnet_prep(const float* frame0_dev, const float* frame1_dev, int C, int H, int W, float* img0_dev, float* img1_dev,
+                    int Hp, int Wp, void* stream);
+/* mean_[n] = mean over both padded images of pair n (IFRNet_L_arch.py:242-247), from the per-image channel means
+ * chan_means [2N,4] (vfi_pool_mean mode 0 over img [2N,Hp,Wp,4]; images 0..N-1 = img0, N..2N-1 = img1);
+ * writes mean_out[n] and subtracts it from the colour channels of both images in place (:248-249). */
+int vfi_ifrnet_center(float* img_dev, const float* chan_means_dev, float* mean_out_dev, int N, int64_t pixels, void* stream);
+/* convrelu(3, 64, 7, 2, 3): Conv2d 7x7 stride 2 pad 3 + PReLU(64), the head of IFRNet_L's encoder (:128-130).
+ * w_dev [7][7][3][Cout] (device), out [N,(Hin-1)/2+1,(Win-1)/2+1,out_cs]. */
+int vfi_conv7x7s2_prelu(const float* in_dev, int in_cs, const float* w_dev, const float* bias_dev, const float* slope_dev, int Cout,
+                        float* out_dev, int out_cs, int N, int Hin, int Win, void* stream);
+/* torch.sigmoid in place over a C-channel window (:278) */
+int vfi_sigmoid(float* x_dev, int cs, int C, int64_t pixels, void* stream);
+/* out[n, p, 0..C) = values_host[n] for N <= 64 items of pixels_per_item pixels: embt.repeat(1, 1, h, w) (:160-163) */
+int vfi_fill_items(float* out_dev, int cs, int C, int N, int64_t pixels_per_item, const float* values_host, void* stream);
+/* F.interpolate(x, scale_factor=s, mode="bilinear", align_corners=False) * post_mul with the source step the CALLER
+ * derived from s (torch uses (float)(1/s), not Hin/Hout, when a scale_factor is given) and the output size floor(in*s)
+ * (:38-41,250-251,281-288). */
+int vfi_resize_bilinear_ratio(const float* in_dev, int in_cs, float* out_dev, int out_cs, int N, int Hin, int Win, int Hout, int Wout,
+                              int C, float ratio_h, float ratio_w, float post_mul, void* stream);
+/* imgt = clamp(mask * warp(img0, flow0) + (1 - mask) * warp(img1, flow1) + mean_ + res, 0, 1)[:H, :W] (:290-294).
+ * fin [N,Hf,Wf,8] = (flow0 xy, flow1 xy, mask, res rgb) at the size of the reference's last resize (the warp grid has
+ * that size, the images Hp x Wp); img{0,1} [N,Hp,Wp,4] mean-removed; out [N,H,W,3]. */
+int vfi_ifrnet_output(const float* img0_dev, const float* img1_dev, const float* fin_dev, const float* mean_dev, float* out_dev, int N,
+                      int Hp, int Wp, int Hf, int Wf, int H, int W, void* stream);
+
 /* ---- RIFE 4.7 / 4.9 model --------------------------------------------------------------- */
 
 typedef struct vfi_rife vfi_rife_t;

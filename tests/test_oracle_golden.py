@@ -208,3 +208,47 @@ def test_node40_matches_reference_golden(golden_dir, name, kw):
     g = np.load(os.path.join(golden_dir, "rife40_node.npz"))
     out = rife_oracle.rife_vfi(synth.rife40_synth_state_dict(1234), torch.from_numpy(g["frames"]), arch="4.0", **kw)
     assert out.shape == g[name].shape and np.abs(out.numpy() - g[name]).max() <= TOL
+
+
+# ---- IFRNet: goldens written by oracle/validate_ifrnet_vs_reference.py from the reference's IFRNet_VFI node ----------
+IFRNET_NODE_CASES = {
+    "x2": dict(multiplier=2),
+    "x2_t05": dict(multiplier=2, scale_factor=0.5),
+    "x4_skip1": dict(multiplier=4, states=InterpolationStateList([1], True)),
+}
+
+
+@pytest.mark.parametrize("kind", ["L", "S"])
+@pytest.mark.parametrize("name", list(IFRNET_NODE_CASES))
+def test_ifrnet_node_matches_reference_golden(golden_dir, kind, name):
+    """oracle/ifrnet_oracle.py (incl. the node's timestep/scale_factor mis-binding: multiplier 4 runs the network at
+    working resolutions 0.25, 0.5 and 0.75) vs outputs of the reference node"""
+    from oracle import ifrnet_oracle
+
+    g = np.load(os.path.join(golden_dir, "ifrnet_node.npz"))
+    out = ifrnet_oracle.ifrnet_vfi(synth.ifrnet_synth_state_dict(kind, 1234), torch.from_numpy(g[f"{kind}_frames"]),
+                                   **IFRNET_NODE_CASES[name])
+    want = g[f"{kind}_{name}"]
+    assert out.shape == want.shape
+    assert np.abs(out.numpy() - want).max() <= 5 * TOL
+
+
+def test_ifrnet_spec_and_geometry():
+    from cfi_amd import ifrnet_spec
+
+    for kind, n_tensors in (("L", 104), ("S", 104)):
+        sh = ifrnet_spec.ifrnet_shapes(kind)
+        assert len(sh) == n_tensors
+        ifrnet_spec.check_state_dict(synth.ifrnet_synth_state_dict(kind, 1), kind)
+    assert ifrnet_spec.decoder_io("L") == [(4, 385, 384, 148), (3, 436, 432, 100), (2, 292, 288, 68), (1, 196, 192, 8)]
+    assert ifrnet_spec.decoder_io("S") == [(4, 145, 144, 58), (3, 166, 162, 40), (2, 112, 108, 28), (1, 76, 72, 8)]
+    assert [ifrnet_spec.kind_of(n) for n in ifrnet_spec.CKPT_NAMES] == ["S", "L", "S", "L"]
+    from cfi_amd.ifrnet import IFRNetEngine
+
+    assert IFRNetEngine.geometry(72, 100, 0.75) == (128, 128, 96, 96, 128, 128)
+    assert IFRNetEngine.geometry(64, 64, 1.0 / 3.0) == (64, 64, 21, 21, 63, 63)      # the reference fails in torch.cat here
+    assert IFRNetEngine.geometry(1080, 1920, 0.5) == (1088, 1920, 544, 960, 1088, 1920)
+    bad = synth.ifrnet_synth_state_dict("S", 1)
+    bad.pop("decoder1.convblock.2.bias")
+    with pytest.raises(KeyError):
+        ifrnet_spec.check_state_dict(bad, "S")

@@ -1,3 +1,5 @@
 #!/bin/bash
 export TMPDIR=/tmp
-timeout 120 python -m pytest tests/test_gpu_rife.py -x -q -m gpu -k "dtype_widget or rejects or node_against_reference_golden" 2>&1 | tail -4
+mkdir -p gpurun_out
+timeout 150 python -m pytest tests/test_gpu_ifrnet.py -q -m gpu 2>&1 | tail -150 > gpurun_out/ifrnet_tests.log
+tail -5 gpurun_out/ifrnet_tests.log
