@@ -146,6 +146,22 @@ def test_engine_against_oracle(net, h, w, n, sf, t):
     assert (got - want).abs().max().item() <= TOL, describe_diff(got, want, f"IFRNet_{kind} {h}x{w} sf={sf} t={t}")
 
 
+def test_engine_1080p_node_default(net):
+    """The node's default call at 1080p (multiplier 2 -> working resolution 0.5, time embedding = scale_factor widget 1.0)
+    against the oracle at full size (measured: 5e-5 max, profiles/r01e_ifrnet_bench_1080p.txt)."""
+    kind, sd, e = net
+    fr = synth.smooth_frames(2, 1080, 1920, seed=2, shift=4.0)
+    x = fr.permute(0, 3, 1, 2)
+    with torch.inference_mode():
+        want = ifrnet_oracle.ifrnet_forward(sd, x[0:1], x[1:2], 0.5, 1.0).permute(0, 2, 3, 1).contiguous()
+    dev = fr.cuda()
+    out = torch.empty(1, 1080, 1920, 3, device="cuda")
+    e.forward([dev[0]], [dev[1]], 0.5, 1.0, out)
+    got = out.cpu()
+    e.release_workspace()
+    assert (got - want).abs().max().item() <= TOL, describe_diff(got, want, f"IFRNet_{kind} 1080p")
+
+
 def test_engine_rejects_what_the_reference_rejects(net):
     kind, sd, e = net
     fr = synth.smooth_frames(2, 64, 64, seed=1).cuda()

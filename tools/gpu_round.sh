@@ -1,5 +1,3 @@
 #!/bin/bash
 export TMPDIR=/tmp
-mkdir -p gpurun_out
-timeout 150 python -m pytest tests/test_gpu_ifrnet.py -q -m gpu 2>&1 | tail -150 > gpurun_out/ifrnet_tests.log
-tail -5 gpurun_out/ifrnet_tests.log
+timeout 100 python -m pytest tests/test_gpu_ifrnet.py tests/test_gpu_m2m.py -x -q -m gpu -k "1080p_node_default or node or plan" 2>&1 | tail -4
