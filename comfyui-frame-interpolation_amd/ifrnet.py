@@ -22,7 +22,6 @@ Timesteps whose resized frame is not a multiple of 16 fail in the reference's ``
 """
 import ctypes as C
 import math
-import pathlib
 import typing
 
 import torch
