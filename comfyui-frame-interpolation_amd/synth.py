@@ -140,6 +140,34 @@ def ifrnet_synth_state_dict(kind="L", seed=1234, gain=1.0):
     return sd
 
 
+def gmfss_synth_state_dicts(seed=1234):
+    """GMFSS Fortuna (union): the five state_dicts.  Conv / linear weights U(+-sqrt(3/fan_in)), biases U(+-0.05), PReLU
+    slopes U(0.1, 0.4), LayerNorm weights 1 +- 0.1, ResConv betas 1 +- 0.25 (as rife47)."""
+    from .gmfss_spec import gmfss_union_shapes
+
+    out = {}
+    for part, shapes in gmfss_union_shapes().items():
+        sd = {}
+        for k, shp in shapes.items():
+            g = _gen(seed, part + "/" + k)
+            if k.endswith("beta"):
+                t = 1.0 + 0.25 * (torch.rand(shp, generator=g) * 2 - 1)
+            elif len(shp) >= 2:
+                fan_in = 1
+                for d in shp[1:]:
+                    fan_in *= d
+                t = (torch.rand(shp, generator=g) * 2 - 1) * math.sqrt(3.0 / fan_in)
+            elif "norm" in k and k.endswith("weight"):
+                t = 1.0 + 0.1 * (torch.rand(shp, generator=g) * 2 - 1)
+            elif k.endswith("bias"):
+                t = (torch.rand(shp, generator=g) * 2 - 1) * 0.05
+            else:  # PReLU slope
+                t = 0.1 + 0.3 * torch.rand(shp, generator=g)
+            sd[k] = t.to(torch.float32).contiguous()
+        out[part] = sd
+    return out
+
+
 def smooth_frames(n, h, w, seed=0, shift=3.0, c=3):
     """[n,h,w,c] f32 in [0,1]: low-pass noise drifting ``shift`` px/frame (ComfyUI IMAGE layout)."""
     g = torch.Generator(device="cpu")

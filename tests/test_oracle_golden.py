@@ -252,3 +252,27 @@ def test_ifrnet_spec_and_geometry():
     bad.pop("decoder1.convblock.2.bias")
     with pytest.raises(KeyError):
         ifrnet_spec.check_state_dict(bad, "S")
+
+
+# ---- GMFSS Fortuna (union), SURVEY 8f rank 3 groundwork: golden written by oracle/validate_gmfss_vs_reference.py from
+# the reference's CommonModelInference (summation splat through the C restatement, as for M2M) -------------------------
+def test_gmfss_union_matches_reference_golden(golden_dir):
+    from oracle import gmfss_oracle
+
+    g = np.load(os.path.join(golden_dir, "gmfss_union.npz"))
+    x = torch.from_numpy(g["frames"]).permute(0, 3, 1, 2).contiguous()
+    with torch.inference_mode():
+        out = gmfss_oracle.gmfss_forward(synth.gmfss_synth_state_dicts(1234), x[0:1], x[1:2], float(g["t"])).permute(0, 2, 3, 1)
+    assert out.shape == g["out"].shape
+    # the matching softmax over ~200 random-feature candidates amplifies last-bit differences of other CPUs' matmul
+    # kernels; on the build container the agreement is bit-exact (oracle/VALIDATION_GMFSS.log)
+    assert np.abs(out.numpy() - g["out"]).mean() <= 1e-4
+
+
+def test_gmfss_spec_tables():
+    from cfi_amd import gmfss_spec
+
+    sh = gmfss_spec.gmfss_union_shapes()
+    assert [len(sh[p]) for p in gmfss_spec.PARTS] == [120, 124, 14, 18, 133]
+    sds = synth.gmfss_synth_state_dicts(3)
+    assert all(tuple(sds[p][k].shape) == tuple(v) for p in gmfss_spec.PARTS for k, v in sh[p].items())
