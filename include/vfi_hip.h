@@ -218,6 +218,67 @@ int vfi_resize_bilinear_ratio(const float* in_dev, int in_cs, float* out_dev, in
 int vfi_ifrnet_output(const float* img0_dev, const float* img1_dev, const float* fin_dev, const float* mean_dev, float* out_dev, int N,
                       int Hp, int Wp, int Hf, int Wf, int H, int W, void* stream);
 
+/* ---- GMFSS Fortuna (union) building blocks (vfi_models/gmfss_fortuna/GMFSS_Fortuna_union_arch.py; gmfss.py drives them
+ * together with the layer objects above).  First-correct versions: one thread per output element. ------------------------ */
+
+/* F.pad of an RGB frame into channels 0..2 of an NHWC tensor, zeros in the padding (gmfss_fortuna/__init__.py:43-48) */
+int vfi_pad_rgb(const float* frame_dev, int C, int H, int W, float* out_dev, int out_cs, int Hp, int Wp, void* stream);
+/* (x - mean[c]) / std[c], C <= 8: normalize_img (:1123-1131) */
+int vfi_normalize_channels(const float* in_dev, int in_cs, float* out_dev, int out_cs, int C, int64_t pixels, const float* mean_host,
+                           const float* std_host, void* stream);
+/* nn.PReLU() (one shared slope) over a channel window: the pre-activations of MetricNet / FeatureNet / GridNet (:1420-1561) */
+int vfi_prelu_scalar(const float* in_dev, int in_cs, float* out_dev, int out_cs, int C, int64_t pixels, float slope, void* stream);
+/* nn.InstanceNorm2d (no affine, eps 1e-5): stats [N][C][2] = (mean, 1/sqrt(var+eps)); workspace >= N*64*C*2 doubles (:165-215) */
+int vfi_instnorm_stats(const float* x_dev, int cs, int C, int N, int64_t HW, float* stats_dev, double* workspace_dev,
+                       int64_t workspace_bytes, void* stream);
+/* out = act2(act1((x - mean) * rstd) + add): norm(+relu) and the residual sum + relu of ResidualBlock_class (:207-215) */
+int vfi_instnorm_apply(const float* x_dev, int cs, const float* stats_dev, int C, int N, int64_t HW, int relu1, const float* add_dev,
+                       int add_cs, int relu2, float* out_dev, int out_cs, void* stream);
+/* nn.LayerNorm(C) over the channel axis (eps 1e-5), TransformerLayer.norm1 / norm2 (:479-523) */
+int vfi_layernorm(const float* x_dev, int cs, int C, int64_t tokens, const float* gamma_dev, const float* beta_dev, float* out_dev,
+                  int out_cs, void* stream);
+/* nn.GELU() (erf form) in place over a channel window (:467-471) */
+int vfi_gelu(float* x_dev, int cs, int C, int64_t pixels, void* stream);
+/* torch.roll by (-shift_h, -shift_w) + split_feature into splits x splits windows: [B,h,w,C] -> [B*K*K, (h/K)*(w/K), C];
+ * inverse != 0: merge_splits + roll back (:367-436,1059-1120) */
+int vfi_window_partition(const float* in_dev, int in_cs, float* out_dev, int out_cs, int B, int h, int w, int C, int splits, int shift_h,
+                         int shift_w, int inverse, void* stream);
+/* out[b][m][n] = alpha * sum_k A[b][m][k] * B[b][n][k]: q k^T / sqrt(c) of the attention and matching steps (:319,417,810) */
+int vfi_bmm_nt(const float* a_dev, int a_cs, const float* b_dev, int b_cs, float* out_dev, int nb, int M, int N, int K, float alpha,
+               void* stream);
+/* out[b][m][c] = sum_n P[b][m][n] * V[b][n][c]: attn v, prob grid, prob flow (:321,425,833,741) */
+int vfi_bmm_nn(const float* p_dev, const float* v_dev, int v_cs, float* out_dev, int out_cs, int nb, int M, int N, int C, void* stream);
+/* softmax over the rows of x [nb][rows][cols] in place; mask [period][rows][cols] (nullable) is added first, batch b taking
+ * mask[b % period] (scores += attn_mask.repeat(b, 1, 1), :422-425) */
+int vfi_softmax_rows(float* x_dev, int nb, int rows, int cols, const float* mask_dev, int mask_period, void* stream);
+/* flow_warp / bilinear_sample: grid_sample(zeros, align_corners=True) at pixel + flow (:955-991) */
+int vfi_flow_sample(const float* in_dev, int in_cs, const float* flow_dev, int flow_cs, float* out_dev, int out_cs, int N, int H, int W,
+                    int C, void* stream);
+/* flow[:, 0:2] += local_correlation_softmax(f0, f1, radius) (:846-913,1335) */
+int vfi_local_match(const float* f0_dev, int f0_cs, const float* f1_dev, int f1_cs, float* flow_dev, int flow_cs, int N, int H, int W,
+                    int C, int radius, void* stream);
+/* FeatureFlowAttention.forward_local_window_attn: q / k already projected, (2r+1)^2 window, zero padding (:745-803) */
+int vfi_local_propagate(const float* q_dev, int q_cs, const float* k_dev, int k_cs, const float* flow_dev, int flow_cs, float* out_dev,
+                        int out_cs, int N, int H, int W, int C, int radius, void* stream);
+/* convex up-sampling of the flow by `factor` from the up-sampler's 9*factor^2 mask logits (:1237-1258) */
+int vfi_convex_upsample(const float* mask_dev, int mask_cs, const float* flow_dev, int flow_cs, float* out_dev, int out_cs, int N, int H,
+                        int W, int factor, void* stream);
+/* MetricNet's 14 input channels: images, -l1 photometric errors after backwarp, normalised flows, fwd/bwd occlusion (:1375-1454) */
+int vfi_gmfss_metric_inputs(const float* img0_dev, const float* img1_dev, int img_cs, const float* flow01_dev, const float* flow10_dev,
+                            int flow_cs, float* out_dev, int out_cs, int H, int W, void* stream);
+/* tanh(x) * scale in place over a channel window (:1465) */
+int vfi_tanh_scale(float* x_dev, int cs, int C, int64_t pixels, float scale, void* stream);
+/* softsplat(x, flow, metric, "soft"), the part before the summation splat: out [px, C+1] = (x * exp(zs*z), exp(zs*z)),
+ * flow_out [px, 2] = fs * flow (vfi_models/ops/cupy_ops/softsplat.py:408-409) */
+int vfi_splat_prep(const float* x_dev, int x_cs, const float* z_dev, int z_cs, const float* flow_dev, int flow_cs, float* out_dev,
+                   float* flow_out_dev, int C, int64_t pixels, float z_scale, float flow_scale, void* stream);
+/* ... and after it: out[p, 0:C] = splat[p, 0:C] / (splat[p, C] + 1e-7) (softsplat.py:415-432) */
+int vfi_splat_normalize(const float* splat_dev, float* out_dev, int out_cs, int C, int64_t pixels, void* stream);
+/* nn.PixelShuffle(2) on NHWC: in [N,H,W,4C] -> out [N,2H,2W,C] (IFBlock.lastconv rife_arch.py:215-218, GridNet tail :1564-1579) */
+int vfi_pixel_shuffle2(const float* in_dev, int in_cs, float* out_dev, int out_cs, int N, int H, int W, int C, void* stream);
+/* torch.clamp(x, 0, 1)[:, :, :H, :W] into a dense [H,W,C] frame (:1857, gmfss_fortuna/__init__.py:78) */
+int vfi_clamp_crop(const float* in_dev, int in_cs, int Hp, int Wp, float* out_dev, int H, int W, int C, void* stream);
+
 /* ---- RIFE 4.7 / 4.9 model --------------------------------------------------------------- */
 
 typedef struct vfi_rife vfi_rife_t;
