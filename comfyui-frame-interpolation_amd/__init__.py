@@ -11,6 +11,7 @@ _LAZY = {
     "FILM_VFI": ("film", "FILM_VFI"),
     "M2M_VFI": ("m2m", "M2M_VFI"),
     "IFRNet_VFI": ("ifrnet", "IFRNet_VFI"),
+    "GMFSS_Fortuna_VFI": ("gmfss", "GMFSS_Fortuna_VFI"),
     "MakeInterpolationStateList": ("schedule", "MakeInterpolationStateList"),
     "InterpolationStateList": ("schedule", "InterpolationStateList"),
 }
@@ -29,6 +30,7 @@ def __getattr__(name):
 
 def _node_class_mappings():
     from .film import FILM_VFI
+    from .gmfss import GMFSS_Fortuna_VFI
     from .ifrnet import IFRNet_VFI
     from .m2m import M2M_VFI
     from .rife import RIFE_VFI
@@ -39,6 +41,7 @@ def _node_class_mappings():
         "FILM VFI": FILM_VFI,
         "M2M VFI": M2M_VFI,
         "IFRNet VFI": IFRNet_VFI,
+        "GMFSS Fortuna VFI": GMFSS_Fortuna_VFI,
         "Make Interpolation State List": MakeInterpolationStateList,
     }
 
@@ -48,4 +51,5 @@ NODE_DISPLAY_NAME_MAPPINGS = {
     "FILM VFI": "FILM VFI (MI355X HIP)",
     "M2M VFI": "M2M VFI (MI355X HIP)",
     "IFRNet VFI": "IFRNet VFI (MI355X HIP)",
+    "GMFSS Fortuna VFI": "GMFSS Fortuna VFI (MI355X HIP; union model, first-correct path)",
 }

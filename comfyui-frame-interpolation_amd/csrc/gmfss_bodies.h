@@ -275,6 +275,30 @@ VFI_HD void flow_sample_body(const FlowSampleArgs& a, long idx) {
     for (int c = 0; c < a.C; ++c) o[c] = ztap_read(img, a.in_cs, a.W, a.H, t, c);
 }
 
+// ---- F.interpolate(x, size, mode="bilinear", align_corners=True) * post_mul (:1302-1307) ------------------------------------
+struct ResizeAcArgs {
+    const float* in; int in_cs;
+    float* out; int out_cs, N, Hi, Wi, Ho, Wo, C; float post_mul;
+};
+VFI_HD void resize_ac_body(const ResizeAcArgs& a, long idx) {
+    if (idx >= (long)a.N * a.Ho * a.Wo) return;
+    const int x = (int)(idx % a.Wo), y = (int)((idx / a.Wo) % a.Ho);
+    const int n = (int)(idx / ((long)a.Wo * a.Ho));
+    // area_pixel_compute_scale(align_corners=True) = (in - 1) / (out - 1); source index = scale * dst
+    const float ry = a.Ho > 1 ? (float)(a.Hi - 1) / (float)(a.Ho - 1) : 0.f, rx = a.Wo > 1 ? (float)(a.Wi - 1) / (float)(a.Wo - 1) : 0.f;
+    const float sy = ry * (float)y, sx = rx * (float)x;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < a.Hi - 1 ? 1 : 0), x1 = x0 + (x0 < a.Wi - 1 ? 1 : 0);
+    const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.0f - ly, hx = 1.0f - lx;
+    const float* b = a.in + (size_t)n * a.Hi * a.Wi * a.in_cs;
+    float* o = a.out + (size_t)idx * a.out_cs;
+    for (int c = 0; c < a.C; ++c) {
+        const float v00 = b[((size_t)y0 * a.Wi + x0) * a.in_cs + c], v01 = b[((size_t)y0 * a.Wi + x1) * a.in_cs + c];
+        const float v10 = b[((size_t)y1 * a.Wi + x0) * a.in_cs + c], v11 = b[((size_t)y1 * a.Wi + x1) * a.in_cs + c];
+        o[c] = (hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11)) * a.post_mul;
+    }
+}
+
 // ---- local_correlation_softmax (:846-913): flow delta = E[window coordinate] - pixel, softmax over (2r+1)^2 --------------
 struct LocalMatchArgs {
     const float* f0; int f0_cs; const float* f1; int f1_cs;

@@ -132,6 +132,14 @@ int vfi_flow_sample(const float* in_dev, int in_cs, const float* flow_dev, int f
     return run<FlowSampleArgs, flow_sample_body>(a, (long)N * H * W, stream, "flow_sample");
 }
 
+int vfi_resize_bilinear_ac(const float* in_dev, int in_cs, float* out_dev, int out_cs, int N, int Hin, int Win, int Hout, int Wout,
+                           int C, float post_mul, void* stream) {
+    VFI_REQUIRE(in_dev && out_dev && N > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0 && C > 0 && in_cs >= C && out_cs >= C,
+                "vfi_resize_bilinear_ac: bad arguments");
+    ResizeAcArgs a{in_dev, in_cs, out_dev, out_cs, N, Hin, Win, Hout, Wout, C, post_mul};
+    return run<ResizeAcArgs, resize_ac_body>(a, (long)N * Hout * Wout, stream, "resize_bilinear_ac");
+}
+
 int vfi_local_match(const float* f0_dev, int f0_cs, const float* f1_dev, int f1_cs, float* flow_dev, int flow_cs, int N, int H, int W,
                     int C, int radius, void* stream) {
     VFI_REQUIRE(f0_dev && f1_dev && flow_dev && N > 0 && H > 1 && W > 1 && C > 0 && f0_cs >= C && f1_cs >= C && flow_cs >= 2 &&

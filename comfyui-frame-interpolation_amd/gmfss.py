@@ -1,0 +1,666 @@
+"""GMFSS Fortuna VFI node, "union" model — host-side mirror of vfi_models/gmfss_fortuna/__init__.py over
+the HIP library.  FIRST-CORRECT device path: every convolution / linear layer runs on the fp32-MFMA layer objects
+(vfi_conv_*), everything else on the one-thread-per-element kernels of csrc/gmfss_ops.hip (their bodies are checked on the
+host by the CPU test suite, tests/test_gmfss_bodies_cpu.py; the orchestration below by tests/test_gmfss_engine_cpu.py
+through a test double of the C ABI).  The attention / matching products are plain VALU loops for now.
+
+Model.reuse (GMFSS_Fortuna_union_arch.py:1726-1782) = ``prepare(frame0, frame1)``: FeatureNet on both frames, GMFlow in both
+directions on the half-resolution pair, MetricNet.  The backbone and the first (global-matching) scale of GMFlow are
+symmetric in the two frames, so they are evaluated once for both directions; the second scale runs as a batch of two.
+Model.inference (:1784-1857) = ``render(t)``: eight soft splats, IFNet 4.6 on the half-resolution pair, GridNet, clamp.
+Every ``torch.cat`` is a channel window of a pre-allocated NHWC tensor.
+"""
+import ctypes as C
+import math
+import typing
+
+import torch
+
+from . import _lib
+from .gmfss_spec import PARTS, gmfss_union_shapes
+from .schedule import InterpolationStateList, generic_output_plan
+
+MODEL_TYPE = "gmfss_fortuna"
+CKPTS_PATH_CONFIG = {   # gmfss_fortuna/__init__.py:11-26
+    "GMFSS_fortuna_union": {
+        "ifnet": ("rife", "rife46.pth"),
+        "flownet": (MODEL_TYPE, "GMFSS_fortuna_flownet.pkl"),
+        "metricnet": (MODEL_TYPE, "GMFSS_fortuna_union_metric.pkl"),
+        "feat_ext": (MODEL_TYPE, "GMFSS_fortuna_union_feat.pkl"),
+        "fusionnet": (MODEL_TYPE, "GMFSS_fortuna_union_fusionnet.pkl"),
+    },
+}
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+
+def _p(t, off=0):
+    return t.data_ptr() + 4 * off
+
+
+def _cs(c):
+    return (c + 7) // 8 * 8
+
+
+class _Device:
+    """The real backend: libvfi_hip.so on the current GPU (there is no CPU fallback)."""
+
+    def __init__(self, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("GMFSS Fortuna VFI (HIP): no GPU visible; this node has no CPU fallback")
+        self.lib = _lib.load()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        _lib.check(self.lib.vfi_init(self.device.index or 0), "vfi_init")
+
+    @staticmethod
+    def stream():
+        return _lib.stream_ptr()
+
+    @staticmethod
+    def last_error():
+        return _lib.last_error()
+
+
+# ---- host-side constant tables (uploaded once per shape) ------------------------------------------------------------
+def sine_position(c, h, w, temperature=10000.0):
+    """PositionEmbeddingSine (:1015-1056) for a [h, w] window, num_pos_feats = c/2, normalize=True -> [h, w, c]"""
+    npf = c // 2
+    ones = torch.ones((1, h, w))
+    y = ones.cumsum(1, dtype=torch.float32)
+    x = ones.cumsum(2, dtype=torch.float32)
+    y = y / (y[:, -1:, :] + 1e-6) * (2 * math.pi)
+    x = x / (x[:, :, -1:] + 1e-6) * (2 * math.pi)
+    d = torch.arange(npf, dtype=torch.float32)
+    d = temperature ** (2 * (d // 2) / npf)
+    px, py = x[:, :, :, None] / d, y[:, :, :, None] / d
+    px = torch.stack((px[..., 0::2].sin(), px[..., 1::2].cos()), dim=4).flatten(3)
+    py = torch.stack((py[..., 0::2].sin(), py[..., 1::2].cos()), dim=4).flatten(3)
+    return torch.cat((py, px), dim=3)[0].contiguous()
+
+
+def shift_mask(h, w, k):
+    """generate_shift_window_attn_mask (:326-364) -> [k*k, lw, lw] with lw = (h/k)*(w/k)"""
+    wh, ww = h // k, w // k
+
+    def region(n, win):
+        r = torch.zeros(n)
+        r[n - win:n - win // 2] = 1
+        r[n - win // 2:] = 2
+        return r
+
+    label = region(h, wh)[:, None] * 3 + region(w, ww)[None, :]
+    win = label.view(k, wh, k, ww).permute(0, 2, 1, 3).reshape(k * k, wh * ww)
+    diff = win.unsqueeze(1) - win.unsqueeze(2)
+    return torch.where(diff != 0, torch.tensor(-100.0), torch.tensor(0.0)).contiguous()
+
+
+class GMFSSEngine:
+    def __init__(self, state_dicts, device=None, _test_backend=None):
+        self.be = _test_backend if _test_backend is not None else _Device(device)
+        self.lib, self.device = self.be.lib, self.be.device
+        shapes = gmfss_union_shapes()
+        for part in PARTS:
+            sd = state_dicts[part]
+            missing = [k for k in shapes[part] if k not in sd]
+            if missing:
+                raise KeyError(f"GMFSS {part} checkpoint: missing keys {missing[:4]}{'...' if len(missing) > 4 else ''}")
+            for k, shp in shapes[part].items():
+                if tuple(sd[k].shape) != tuple(shp):
+                    raise ValueError(f"GMFSS {part} checkpoint: {k} has shape {tuple(sd[k].shape)}, expected {tuple(shp)}")
+        self.handles = []
+        self._build(state_dicts)
+        self.scratch, self.consts = {}, {}
+        self.prepared = None
+
+    # ---- plumbing ---------------------------------------------------------------------------------------------------
+    def _c(self, name, *args):
+        rc = getattr(self.lib, name)(*args, self.be.stream())
+        if rc != 0:
+            raise RuntimeError(f"{name} failed (code {rc}): {self.be.last_error()}")
+
+    def _t(self, name, *shape):
+        key = (name,) + tuple(shape)
+        if key not in self.scratch:
+            self.scratch[key] = torch.zeros(shape, dtype=torch.float32, device=self.device)
+        return self.scratch[key]
+
+    def _const(self, key, make):
+        if key not in self.consts:
+            self.consts[key] = make().to(self.device, torch.float32).contiguous()
+        return self.consts[key]
+
+    def _layer(self, w, b=None, slopes=None, kind=0, stride=1, chan_map=None, cin_phys=None, scale_out=None):
+        """vfi_conv layer object from checkpoint tensors.  w: Conv2d [co,ci,k,k] / Linear [co,ci] / ConvTranspose2d [ci,co,4,4];
+        slopes: scalar PReLU slope (replicated) or per-channel vector; scale_out: per-output-channel factor folded into the
+        weights and bias (ResConv's beta)."""
+        w = w.detach().to("cpu", torch.float32)
+        if w.dim() == 2:
+            w = w[:, :, None, None]
+        cout, cin = (w.shape[0], w.shape[1]) if kind == 0 else (w.shape[1], w.shape[0])
+        b = torch.zeros(cout) if b is None else b.detach().to("cpu", torch.float32)
+        if scale_out is not None:
+            s = scale_out.detach().to("cpu", torch.float32).reshape(-1)
+            w = w * (s.view(-1, 1, 1, 1) if kind == 0 else s.view(1, -1, 1, 1))
+            b = b * s
+        w, b = w.contiguous(), b.contiguous()
+        pr = None
+        if slopes is not None:
+            pr = slopes.detach().to("cpu", torch.float32).reshape(-1)
+            pr = (pr.repeat(cout) if pr.numel() == 1 else pr).contiguous()
+        cin_phys = cin_phys or _cs(cin)
+        cm = (C.c_int * cin)(*chan_map) if chan_map is not None else None
+        h = self.lib.vfi_conv_create_ex(kind, w.data_ptr(), b.data_ptr(), cout, cin, w.shape[2], stride, 0, cm, cin_phys,
+                                        pr.data_ptr() if pr is not None else None)
+        if not h:
+            raise RuntimeError("vfi_conv_create_ex failed: " + self.be.last_error())
+        self.handles.append(h)
+        return dict(h=h, kind=kind, stride=stride, cout=cout, act=3 if pr is not None else 0)
+
+    def _conv(self, L, src, soff, dst, doff, act=None, slope=0.0, res=None):
+        n, hin, win, cs = src.shape
+        want = (hin * 2, win * 2) if L["kind"] == 1 else (hin // L["stride"], win // L["stride"])
+        assert tuple(dst.shape[1:3]) == want and dst.shape[0] == n, (src.shape, dst.shape, want)
+        self._c("vfi_conv_forward_ex", L["h"], _p(src, soff), cs, hin, win, _p(dst, doff), dst.shape[-1], n,
+                L["act"] if act is None else act, slope, 0.0, 0.0, _p(res) if res is not None else None,
+                res.shape[-1] if res is not None else 0)
+
+    def _ax(self, a, aoff, b, boff, out, ooff, c, alpha=1.0, beta=1.0, px=None):
+        px = px if px is not None else a.shape[0] * a.shape[1] * a.shape[2]
+        self._c("vfi_axpby", _p(a, aoff), a.shape[-1], _p(b, boff) if b is not None else None, b.shape[-1] if b is not None else 0,
+                _p(out, ooff), out.shape[-1], px, c, alpha, beta)
+
+    def _resize(self, src, soff, dst, doff, c, mul=1.0):
+        self._c("vfi_resize_bilinear", _p(src, soff), src.shape[-1], _p(dst, doff), dst.shape[-1], src.shape[0], src.shape[1], src.shape[2],
+                dst.shape[1], dst.shape[2], c, mul)
+
+    def close(self):
+        for h in self.handles:
+            self.lib.vfi_conv_destroy(h)
+        self.handles = []
+        self.release_workspace()
+
+    def release_workspace(self):
+        self.scratch, self.prepared = {}, None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # noqa: BLE001 — interpreter shutdown
+            pass
+
+    # ---- layer objects ----------------------------------------------------------------------------------------------
+    def _build(self, sds):
+        mk = self._layer
+        # FeatureNet (:1470-1500): PReLU -> conv s2 -> PReLU -> conv; the 2nd PReLU is the first conv's epilogue
+        fe = sds["feat_ext"]
+        self.fe = [(float(fe[f"block{k}.0.weight"]), mk(fe[f"block{k}.1.weight"], fe[f"block{k}.1.bias"], fe[f"block{k}.2.weight"], stride=2,
+                                                       cin_phys=8 if k == 1 else None),
+                    mk(fe[f"block{k}.3.weight"], fe[f"block{k}.3.bias"])) for k in (1, 2, 3)]
+        # GMFlow backbone (:218-312): convs without bias, InstanceNorm between them
+        fl = sds["flownet"]
+        dev = lambda t: t.detach().to(self.device, torch.float32).contiguous()   # noqa: E731
+        self.bb_head = (dev(fl["backbone.conv1.weight"].permute(2, 3, 1, 0)), dev(torch.zeros(64)), dev(torch.ones(64)))
+        self.bb = {}
+        for name, stride in (("layer1", 1), ("layer2", 2), ("layer3", 1)):
+            for blk in (0, 1):
+                p = f"backbone.{name}.{blk}."
+                s = stride if blk == 0 else 1
+                ds = mk(fl[p + "downsample.0.weight"], fl[p + "downsample.0.bias"]) if p + "downsample.0.weight" in fl else None
+                self.bb[(name, blk)] = (mk(fl[p + "conv1.weight"], stride=s), mk(fl[p + "conv2.weight"]), ds, s)
+        self.bb_conv2 = mk(fl["backbone.conv2.weight"], fl["backbone.conv2.bias"])
+        self.trident = (mk(fl["backbone.trident_conv.weight"]), mk(fl["backbone.trident_conv.weight"], stride=2))
+        # transformer (:439-686): Linear layers as 1x1 convs over [B,h,w,C] token maps
+        self.tf = []
+        for i in range(6):
+            blk = {}
+            for part in ("self_attn", "cross_attn_ffn"):
+                p = f"transformer.layers.{i}.{part}."
+                d = {n: mk(fl[p + n + ".weight"]) for n in ("q_proj", "k_proj", "v_proj", "merge")}
+                d["norm1"] = (dev(fl[p + "norm1.weight"]), dev(fl[p + "norm1.bias"]))
+                if part == "cross_attn_ffn":
+                    d["mlp0"], d["mlp2"] = mk(fl[p + "mlp.0.weight"]), mk(fl[p + "mlp.2.weight"])
+                    d["norm2"] = (dev(fl[p + "norm2.weight"]), dev(fl[p + "norm2.bias"]))
+                blk[part] = d
+            self.tf.append(blk)
+        self.prop_q = mk(fl["feature_flow_attn.q_proj.weight"], fl["feature_flow_attn.q_proj.bias"])
+        self.prop_k = mk(fl["feature_flow_attn.k_proj.weight"], fl["feature_flow_attn.k_proj.bias"])
+        # up-sampler (:1195-1199): input cat(flow 2, feature 128) held as [feature 128 | flow 2 | pad]
+        self.up0 = mk(fl["upsampler.0.weight"], fl["upsampler.0.bias"], chan_map=[128, 129] + list(range(128)), cin_phys=136)
+        self.up2 = mk(fl["upsampler.2.weight"], fl["upsampler.2.bias"])
+        # MetricNet (:1420-1467)
+        mn = sds["metricnet"]
+        self.m_in = mk(mn["metric_in.weight"], mn["metric_in.bias"], cin_phys=16)
+        self.m_net = [(float(mn[f"metric_net{k}.0.weight"]), mk(mn[f"metric_net{k}.1.weight"], mn[f"metric_net{k}.1.bias"])) for k in (1, 2, 3)]
+        self.m_out = (float(mn["metric_out.0.weight"]), mk(mn["metric_out.1.weight"], mn["metric_out.1.bias"]))
+        # GridNet (:1503-1688): Sequential(PReLU, conv | deconv, PReLU, conv) blocks
+        gn = sds["fusionnet"]
+
+        def pair(p, transposed=False, stride=1, cin_phys=None):
+            first = mk(gn[p + "1.weight"], gn[p + "1.bias"], gn[p + "2.weight"], kind=1 if transposed else 0, stride=2 if transposed else stride,
+                       cin_phys=cin_phys)
+            return float(gn[p + "0.weight"]), first, mk(gn[p + "3.weight"], gn[p + "3.bias"])
+
+        self.gn = {}
+        for name in ("head0", "head1", "head2", "head3", "01", "04", "05", "11", "14", "15", "21", "24", "25"):
+            self.gn["res" + name] = pair(f"residual_model_{name}.", cin_phys=16 if name == "head0" else None)
+        for name in ("10", "20", "11", "21"):
+            self.gn["down" + name] = pair(f"downsample_model_{name}.", stride=2)
+        for name in ("04", "14", "05", "15"):
+            self.gn["up" + name] = pair(f"upsample_model_{name}.", transposed=True)
+        p = "residual_model_tail."
+        self.tail = (mk(gn[p + "conv_before_upsample.0.weight"], gn[p + "conv_before_upsample.0.bias"], gn[p + "conv_before_upsample.1.weight"]),
+                     mk(gn[p + "upsample.0.weight"], gn[p + "upsample.0.bias"]), mk(gn[p + "conv_last.weight"], gn[p + "conv_last.bias"]))
+        # IFNet 4.6 (rife_arch.py:187-276,404-408): ResConv's beta folded into weights and bias
+        rf = sds["ifnet"]
+        self.rife = []
+        for b in range(4):
+            p = f"block{b}."
+            self.rife.append(dict(
+                c=rf[p + "conv0.1.0.weight"].shape[0],
+                c00=mk(rf[p + "conv0.0.0.weight"], rf[p + "conv0.0.0.bias"], stride=2, cin_phys=8 if b == 0 else 16),
+                c01=mk(rf[p + "conv0.1.0.weight"], rf[p + "conv0.1.0.bias"], stride=2),
+                res=[mk(rf[p + f"convblock.{i}.conv.weight"], rf[p + f"convblock.{i}.conv.bias"], scale_out=rf[p + f"convblock.{i}.beta"])
+                     for i in range(8)],
+                last=mk(rf[p + "lastconv.0.weight"], rf[p + "lastconv.0.bias"], kind=1, stride=2)))
+
+    # ---- small composite ops ----------------------------------------------------------------------------------------
+    def _prelu(self, src, soff, dst, doff, c, slope):
+        self._c("vfi_prelu_scalar", _p(src, soff), src.shape[-1], _p(dst, doff), dst.shape[-1], c, src.shape[0] * src.shape[1] * src.shape[2], slope)
+
+    def _pair(self, blk, src, soff, cin, dst, doff, tag, res=None):
+        """Sequential(PReLU(a), conv | deconv, PReLU(b), conv)(src[..., soff:soff+cin]) (+ res) -> dst[..., doff:]"""
+        a, first, second = blk
+        n, h, w, _ = src.shape
+        t = self._t("pair_in_" + tag, n, h, w, _cs(cin))
+        self._prelu(src, soff, t, 0, cin, a)
+        ho, wo = (2 * h, 2 * w) if first["kind"] == 1 else (h // first["stride"], w // first["stride"])
+        m = self._t("pair_mid_" + tag, n, ho, wo, _cs(first["cout"]))
+        self._conv(first, t, 0, m, 0)
+        self._conv(second, m, 0, dst, doff, res=res)
+
+    def _instnorm(self, x, c, relu1, add, relu2, out):
+        n, h, w, cs = x.shape
+        stats = self._t("in_stats", n, c, 2)
+        ws = self.scratch.setdefault(("in_ws", n, c), torch.zeros(n * 64 * c * 2, dtype=torch.float64, device=self.device))
+        self._c("vfi_instnorm_stats", _p(x), cs, c, n, h * w, _p(stats), ws.data_ptr(), ws.numel() * 8)
+        self._c("vfi_instnorm_apply", _p(x), cs, _p(stats), c, n, h * w, int(relu1), _p(add) if add is not None else None,
+                add.shape[-1] if add is not None else 0, int(relu2), _p(out), out.shape[-1])
+
+    def _res_block(self, key, x, cin):
+        """ResidualBlock_class.forward (:207-215)"""
+        c1, c2, ds, stride = self.bb[key]
+        n, h, w, _ = x.shape
+        ho, wo, c = h // stride, w // stride, c1["cout"]
+        tag = f"{key[0]}{key[1]}"
+        a, b, y = (self._t(f"bb_{tag}_{k}", n, ho, wo, c) for k in "aby")
+        self._conv(c1, x, 0, a, 0)
+        self._instnorm(a, c, True, None, False, a)
+        self._conv(c2, a, 0, b, 0)
+        short = x
+        if ds is not None:
+            xs = x
+            if stride == 2:   # 1x1 conv with stride 2 = sample the even pixels, then the 1x1 conv
+                xs = self._t(f"bb_{tag}_sub", n, ho, wo, x.shape[-1])
+                self._c("vfi_upsample_nearest", _p(x), x.shape[-1], _p(xs), xs.shape[-1], n, h, w, ho, wo, cin)
+            short = self._t(f"bb_{tag}_s", n, ho, wo, c)
+            self._conv(ds, xs, 0, short, 0)
+            self._instnorm(short, c, False, None, False, short)
+        self._instnorm(b, c, True, short, True, y)
+        return y
+
+    def _attention(self, q, k, v, out, h, w, splits, shifted):
+        """single_head_split_window_attention (:367-436) on [B,h,w,C] token maps"""
+        B, c = q.shape[0], q.shape[-1]
+        wh, ww = h // splits, w // splits
+        nb, lw = B * splits * splits, wh * ww
+        sh, sw = (wh // 2, ww // 2) if shifted else (0, 0)
+        qw, kw, vw, ow = (self._t("att_" + n, nb, lw, c) for n in ("q", "k", "v", "o"))
+        for src, dst in ((q, qw), (k, kw), (v, vw)):
+            self._c("vfi_window_partition", _p(src), src.shape[-1], _p(dst), c, B, h, w, c, splits, sh, sw, 0)
+        sc = self._t("att_s", nb, lw, lw)
+        self._c("vfi_bmm_nt", _p(qw), c, _p(kw), c, _p(sc), nb, lw, lw, c, 1.0 / c ** 0.5)
+        mask = self._const(("mask", h, w, splits), lambda: shift_mask(h, w, splits)) if shifted else None
+        self._c("vfi_softmax_rows", _p(sc), nb, lw, lw, _p(mask) if shifted else None, splits * splits)
+        self._c("vfi_bmm_nn", _p(sc), _p(vw), c, _p(ow), c, nb, lw, lw, c)
+        self._c("vfi_window_partition", _p(ow), c, _p(out), out.shape[-1], B, h, w, c, splits, sh, sw, 1)
+
+    def _pair_swap(self, a, o):
+        """o[2d + s] = a[2d + 1 - s]: concat1 of FeatureTransformer.forward (:664-678)"""
+        for i in range(a.shape[0]):
+            self._ax(a[i ^ 1:(i ^ 1) + 1], 0, None, 0, o[i:i + 1], 0, a.shape[-1])
+
+    def _transformer(self, a, splits):
+        """FeatureTransformer.forward on a [2D, h, w, 128] (per direction: source, target), in place"""
+        B, h, w, c = a.shape
+        o = self._t("tf_o", B, h, w, c)
+        self._pair_swap(a, o)
+        q, k, v, m = (self._t("tf_" + n, B, h, w, c) for n in ("q", "k", "v", "m"))
+        cat = self._t("tf_cat", B, h, w, 2 * c)
+        hid = self._t("tf_hid", B, h, w, 8 * c)
+        for i, blk in enumerate(self.tf):
+            shifted = i % 2 == 1
+            for part, tgt in (("self_attn", a), ("cross_attn_ffn", o)):
+                L = blk[part]
+                self._conv(L["q_proj"], a, 0, q, 0)
+                self._conv(L["k_proj"], tgt, 0, k, 0)
+                self._conv(L["v_proj"], tgt, 0, v, 0)
+                self._attention(q, k, v, m, h, w, splits, shifted)
+                self._conv(L["merge"], m, 0, q, 0)
+                ffn = part == "cross_attn_ffn"
+                dst, doff = (cat, c) if ffn else (m, 0)
+                self._c("vfi_layernorm", _p(q), c, c, B * h * w, _p(L["norm1"][0]), _p(L["norm1"][1]), _p(dst, doff), dst.shape[-1])
+                if ffn:
+                    self._ax(a, 0, None, 0, cat, 0, c)
+                    self._conv(L["mlp0"], cat, 0, hid, 0)
+                    self._c("vfi_gelu", _p(hid), 8 * c, 8 * c, B * h * w)
+                    self._conv(L["mlp2"], hid, 0, q, 0)
+                    self._c("vfi_layernorm", _p(q), c, c, B * h * w, _p(L["norm2"][0]), _p(L["norm2"][1]), _p(m), c)
+                self._ax(a, 0, m, 0, a, 0, c)
+            self._pair_swap(a, o)
+
+    def _add_position(self, t, splits):
+        B, h, w, c = t.shape
+        pos = self._const(("pos", B, h, w, c, splits),
+                          lambda: sine_position(c, h // splits, w // splits).repeat(splits, splits, 1)[None].repeat(B, 1, 1, 1))
+        self._ax(t, 0, pos, 0, t, 0, c)
+
+    # ---- Model.reuse ------------------------------------------------------------------------------------------------
+    def prepare(self, frame0, frame1):
+        H, W, Cc = frame0.shape
+        assert frame1.shape == frame0.shape and Cc >= 3 and frame0.is_contiguous() and frame1.is_contiguous()
+        Hp, Wp = ((H - 1) // 64 + 1) * 64, ((W - 1) // 64 + 1) * 64
+        Hh, Wh = Hp // 2, Wp // 2
+        img = self._t("img", 2, Hp, Wp, 8)
+        for i, f in enumerate((frame0, frame1)):
+            self._c("vfi_pad_rgb", f.data_ptr(), Cc, H, W, _p(img[i]), 8, Hp, Wp)
+        # FeatureNet on both frames
+        feats, x, cin = [], img, 3
+        for k, (a, first, second) in enumerate(self.fe):
+            n, h, w, _ = x.shape
+            t = self._t(f"fe_in{k}", 2, h, w, _cs(cin))
+            self._prelu(x, 0, t, 0, cin, a)
+            m = self._t(f"fe_mid{k}", 2, h // 2, w // 2, first["cout"])
+            self._conv(first, t, 0, m, 0)
+            f = self._t(f"feat{k}", 2, h // 2, w // 2, first["cout"])
+            self._conv(second, m, 0, f, 0)
+            feats.append(f)
+            x, cin = f, first["cout"]
+        himg = self._t("himg", 2, Hh, Wh, 8)
+        self._resize(img, 0, himg, 0, 3)
+        flows = self._gmflow(himg)
+        # MetricNet
+        mi = self._t("m_in", 1, Hh, Wh, 16)
+        self._c("vfi_gmfss_metric_inputs", _p(himg[0]), _p(himg[1]), 8, _p(flows[0]), _p(flows[1]), 2, _p(mi), 16, Hh, Wh)
+        feat, tmp, nxt = (self._t("m_" + n, 1, Hh, Wh, 64) for n in ("feat", "tmp", "nxt"))
+        self._conv(self.m_in, mi, 0, feat, 0)
+        for slope, conv in self.m_net:
+            self._prelu(feat, 0, tmp, 0, 64, slope)
+            self._conv(conv, tmp, 0, nxt, 0, res=feat)
+            feat, nxt = nxt, feat
+        metric = self._t("metric", 1, Hh, Wh, 8)
+        self._prelu(feat, 0, tmp, 0, 64, self.m_out[0])
+        self._conv(self.m_out[1], tmp, 0, metric, 0)
+        self._c("vfi_tanh_scale", _p(metric), 8, 2, Hh * Wh, 10.0)
+        self.prepared = dict(H=H, W=W, Hp=Hp, Wp=Wp, img=img, himg=himg, feats=feats, flows=flows, metric=metric)
+        return self.prepared
+
+    def _gmflow(self, himg):
+        """GMFlow.forward (:1262-1372) for both directions -> flows [2, Hh, Wh, 2] (index 0 = flow01, 1 = flow10)"""
+        _, Hh, Wh, _ = himg.shape
+        nimg = self._t("nimg", 2, Hh, Wh, 8)
+        mean, std = (C.c_float * 3)(*IMAGENET_MEAN), (C.c_float * 3)(*IMAGENET_STD)
+        self._c("vfi_normalize_channels", _p(himg), 8, _p(nimg), 8, 3, 2 * Hh * Wh, mean, std)
+        h2, w2 = Hh // 2, Wh // 2
+        c1 = self._t("bb_c1", 2, h2, w2, 64)
+        wt, bs, sl = self.bb_head
+        self._c("vfi_conv7x7s2_prelu", _p(nimg), 8, _p(wt), _p(bs), _p(sl), 64, _p(c1), 64, 2, Hh, Wh)   # bias 0, slope 1: plain conv
+        self._instnorm(c1, 64, True, None, False, c1)
+        x, cin = c1, 64
+        for name in ("layer1", "layer2", "layer3"):
+            for blk in (0, 1):
+                x = self._res_block((name, blk), x, cin)
+                cin = x.shape[-1]
+        h4, w4 = x.shape[1:3]
+        f4 = self._t("bb_f4", 2, h4, w4, 128)
+        self._conv(self.bb_conv2, x, 0, f4, 0)
+        fhi, flo = self._t("f_hi", 2, h4, w4, 128), self._t("f_lo", 2, h4 // 2, w4 // 2, 128)
+        self._conv(self.trident[0], f4, 0, fhi, 0)
+        self._conv(self.trident[1], f4, 0, flo, 0)
+        # ---- scale 0: global matching at 1/8, both directions from one transformer pass
+        h8, w8 = h4 // 2, w4 // 2
+        L = h8 * w8
+        a = self._t("s0_a", 2, h8, w8, 128)
+        self._ax(flo, 0, None, 0, a, 0, 128)
+        self._add_position(a, 2)
+        self._transformer(a, 2)
+        o = self._t("s0_o", 2, h8, w8, 128)
+        self._pair_swap(a, o)
+        sc = self._t("s0_scores", 2, L, L)
+        self._c("vfi_bmm_nt", _p(a), 128, _p(o), 128, _p(sc), 2, L, L, 128, 1.0 / 128 ** 0.5)
+        self._c("vfi_softmax_rows", _p(sc), 2, L, L, None, 0)
+        grid = self._const(("grid", h8, w8), lambda: torch.stack(torch.meshgrid(torch.arange(h8), torch.arange(w8), indexing="ij")[::-1], -1)
+                           .float()[None].repeat(2, 1, 1, 1))
+        flow8 = self._t("s0_flow", 2, h8, w8, 2)
+        self._c("vfi_bmm_nn", _p(sc), _p(grid), 2, _p(flow8), 2, 2, L, L, 2)
+        self._ax(flow8, 0, grid, 0, flow8, 0, 2, 1.0, -1.0)
+        # propagation: key projected from the PROJECTED query (:728-735)
+        q, k = self._t("s0_q", 2, h8, w8, 128), self._t("s0_k", 2, h8, w8, 128)
+        self._conv(self.prop_q, a, 0, q, 0)
+        self._conv(self.prop_k, q, 0, k, 0)
+        self._c("vfi_bmm_nt", _p(q), 128, _p(k), 128, _p(sc), 2, L, L, 128, 1.0 / 128 ** 0.5)
+        self._c("vfi_softmax_rows", _p(sc), 2, L, L, None, 0)
+        flow8p = self._t("s0_flowp", 2, h8, w8, 2)
+        self._c("vfi_bmm_nn", _p(sc), _p(flow8), 2, _p(flow8p), 2, 2, L, L, 2)
+        # ---- scale 1: local refinement at 1/4, one batch entry pair per direction
+        flow4 = self._t("s1_flow", 2, h4, w4, 2)
+        self._c("vfi_resize_bilinear_ac", _p(flow8p), 2, _p(flow4), 2, 2, h8, w8, h4, w4, 2, 2.0)
+        fsw = self._t("s1_fsw", 2, h4, w4, 128)
+        self._pair_swap(fhi, fsw)                                     # target image of each direction
+        b = self._t("s1_a", 4, h4, w4, 128)                           # [src d0, tgt d0, src d1, tgt d1]
+        for d in (0, 1):
+            self._ax(fhi[d:d + 1], 0, None, 0, b[2 * d:2 * d + 1], 0, 128)
+            self._c("vfi_flow_sample", _p(fsw[d]), 128, _p(flow4[d]), 2, _p(b[2 * d + 1]), 128, 1, h4, w4, 128)
+        self._add_position(b, 8)
+        self._transformer(b, 8)
+        q1, k1 = self._t("s1_q", 1, h4, w4, 128), self._t("s1_k", 1, h4, w4, 128)
+        flow4p = self._t("s1_flowp", 2, h4, w4, 2)
+        cat = self._t("s1_cat", 2, h4, w4, 136)
+        for d in (0, 1):
+            src = b[2 * d:2 * d + 1]
+            self._c("vfi_local_match", _p(src), 128, _p(b[2 * d + 1]), 128, _p(flow4[d]), 2, 1, h4, w4, 128, 4)
+            self._conv(self.prop_q, src, 0, q1, 0)
+            self._conv(self.prop_k, src, 0, k1, 0)
+            self._c("vfi_local_propagate", _p(q1), 128, _p(k1), 128, _p(flow4[d]), 2, _p(flow4p[d]), 2, 1, h4, w4, 128, 1)
+            self._ax(src, 0, None, 0, cat[d:d + 1], 0, 128)
+            self._ax(flow4p[d:d + 1], 0, None, 0, cat[d:d + 1], 128, 2)
+        u = self._t("s1_up", 2, h4, w4, 256)
+        self._conv(self.up0, cat, 0, u, 0, act=1, slope=0.0)          # ReLU
+        msk = self._t("s1_mask", 2, h4, w4, 144)
+        self._conv(self.up2, u, 0, msk, 0)
+        flows = self._t("flows", 2, Hh, Wh, 2)
+        self._c("vfi_convex_upsample", _p(msk), 144, _p(flow4p), 2, _p(flows), 2, 2, h4, w4, 4)
+        return flows
+
+    # ---- Model.inference --------------------------------------------------------------------------------------------
+    def render(self, t, out):
+        P = self.prepared
+        assert P is not None, "prepare() first"
+        H, W, Hp, Wp = P["H"], P["W"], P["Hp"], P["Wp"]
+        Hh, Wh = Hp // 2, Wp // 2
+        t = float(t)
+        himg, flows, metric, feats = P["himg"], P["flows"], P["metric"], P["feats"]
+        ft, zt = self._t("ft", 2, Hh, Wh, 2), self._t("zt", 2, Hh, Wh, 1)
+        for d, tt in ((0, t), (1, 1 - t)):
+            self._ax(flows[d:d + 1], 0, None, 0, ft[d:d + 1], 0, 2, tt)          # F_t = t * flow01, (1 - t) * flow10
+            self._ax(metric, d, None, 0, zt[d:d + 1], 0, 1, tt)                  # Z_t
+        g_in = [self._t("g_in0", 1, Hh, Wh, 16), self._t("g_in1", 1, Hh, Wh, 128), self._t("g_in2", 1, Hh // 2, Wh // 2, 256),
+                self._t("g_in3", 1, Hh // 4, Wh // 4, 384)]
+        for lvl in range(3):
+            s = 1 << lvl
+            h, w = Hh // s, Wh // s
+            if lvl == 0:
+                fl, zl = ft, zt
+            else:   # F.interpolate(F_t, 1/s) * (1/s), F.interpolate(Z_t, 1/s)
+                fl, zl = self._t(f"ft{lvl}", 2, h, w, 2), self._t(f"zt{lvl}", 2, h, w, 1)
+                self._resize(ft, 0, fl, 0, 2, 1.0 / s)
+                self._resize(zt, 0, zl, 0, 1)
+            c = feats[lvl].shape[-1]
+            for d in (0, 1):
+                if lvl == 0:
+                    self._splat(himg[d:d + 1], 3, zl[d:d + 1], fl[d:d + 1], g_in[0], 6 * d)      # I1t -> 0:3, I2t -> 6:9
+                self._splat(feats[lvl][d:d + 1], c, zl[d:d + 1], fl[d:d + 1], g_in[lvl + 1], c * d)
+        self._ifnet46(himg, t, g_in[0], 3)
+        y = self._gridnet(g_in)
+        self._c("vfi_clamp_crop", _p(y), y.shape[-1], Hp, Wp, out.data_ptr(), H, W, 3)
+        return out
+
+    def _splat(self, x, c, z, flow, dst, doff):
+        """softsplat(x, flow, z, "soft") -> dst[..., doff:doff+c]"""
+        _, h, w, _ = x.shape
+        pre, fo, s = self._t("sp_pre", h * w, c + 1), self._t("sp_flow", h * w, 2), self._t("sp_out", h * w, c + 1)
+        self._c("vfi_splat_prep", _p(x), x.shape[-1], _p(z), z.shape[-1], _p(flow), flow.shape[-1], _p(pre), _p(fo), c, h * w, 1.0, 1.0)
+        self._c("vfi_softsplat_sum", _p(pre), _p(fo), _p(s), 1, h, w, c + 1)
+        self._c("vfi_splat_normalize", _p(s), _p(dst, doff), dst.shape[-1], c, h * w)
+
+    def _ifnet46(self, himg, t, dst, doff):
+        """IFNet("4.6").forward (rife_arch.py:465-732) on the half-resolution pair -> dst[..., doff:doff+3]"""
+        _, Hh, Wh, _ = himg.shape
+        Hq, Wq = ((Hh - 1) // 64 + 1) * 64, ((Wh - 1) // 64 + 1) * 64
+        x7 = self._t("r_x7", 1, Hq, Wq, 8)          # clamp(img0), clamp(img1), t, 0
+        self._c("vfi_rife40_prep", _p(himg[0]), _p(himg[1]), 8, Hh, Wh, t, _p(x7), Hq, Wq)
+        xin = self._t("r_xin", 1, Hq, Wq, 8)        # warped img0, warped img1, t, mask
+        self._ax(x7, 6, None, 0, xin, 6, 1)
+        flow, df, dm = self._t("r_flow", 1, Hq, Wq, 4), self._t("r_df", 1, Hq, Wq, 4), self._t("r_dm", 1, Hq, Wq, 1)
+        for i, scale in enumerate((8, 4, 2, 1)):
+            B = self.rife[i]
+            c = B["c"]
+            hs, ws = Hq // scale, Wq // scale
+            xs = self._t(f"r_xs{i}", 1, hs, ws, 8 if i == 0 else 16)
+            self._resize(x7 if i == 0 else xin, 0, xs, 0, 7 if i == 0 else 8)
+            if i > 0:
+                self._resize(flow, 0, xs, 8, 4, 1.0 / scale)
+            a = self._t(f"r_a{i}", 1, hs // 2, ws // 2, c // 2)
+            p, q = self._t(f"r_p{i}", 1, hs // 4, ws // 4, c), self._t(f"r_q{i}", 1, hs // 4, ws // 4, c)
+            self._conv(B["c00"], xs, 0, a, 0, act=1, slope=0.2)
+            self._conv(B["c01"], a, 0, p, 0, act=1, slope=0.2)
+            cur, nxt = p, q
+            for L in B["res"]:                      # lrelu(conv(x) * beta + x)
+                self._conv(L, cur, 0, nxt, 0, act=1, slope=0.2, res=cur)
+                cur, nxt = nxt, cur
+            t24 = self._t(f"r_t24{i}", 1, hs // 2, ws // 2, 24)
+            self._conv(B["last"], cur, 0, t24, 0)
+            t6 = self._t(f"r_t6{i}", 1, hs, ws, 8)
+            self._c("vfi_pixel_shuffle2", _p(t24), 24, _p(t6), 8, 1, hs // 2, ws // 2, 6)
+            self._resize(t6, 0, df, 0, 4, float(scale))
+            self._resize(t6, 4, dm, 0, 1)
+            if i == 0:
+                self._ax(df, 0, None, 0, flow, 0, 4)
+                self._ax(dm, 0, None, 0, xin, 7, 1)
+            else:
+                self._ax(flow, 0, df, 0, flow, 0, 4)
+                self._ax(xin, 7, dm, 0, xin, 7, 1)
+            for k in (0, 1):                        # warped_img0 = warp(img0, flow[:, :2]), warped_img1 = warp(img1, flow[:, 2:4])
+                self._c("vfi_warp_rife", _p(x7, 3 * k), 8, _p(flow, 2 * k), 4, _p(xin, 3 * k), 8, 1, Hq, Wq, 3)
+        rife = self._t("r_out", 1, Hh, Wh, 3)
+        self._c("vfi_rife40_output", _p(xin), 8, _p(xin, 7), 8, None, 0, _p(rife), 1, Hq, Wq, Hh, Wh)
+        self._ax(rife, 0, None, 0, dst, doff, 3)
+
+    def _gridnet(self, g_in):
+        """GridNet.forward (:1639-1688) -> [1, Hp, Wp, 8] (3 channels used)"""
+        x, x1, x2, x3 = g_in
+        _, h, w, _ = x.shape
+        T = lambda name, s, c: self._t("gn_" + name, 1, h // s, w // s, c)   # noqa: E731
+        P = self._pair
+        a = T("h0", 1, 64)
+        P(self.gn["reshead0"], x, 0, 9, a, 0, "h0")
+        x00 = T("x00", 1, 64)
+        P(self.gn["reshead1"], x1, 0, 128, x00, 0, "h1", res=a)
+        x01 = T("x01", 1, 64)
+        P(self.gn["res01"], x00, 0, 64, x01, 0, "r0", res=x00)
+        b = T("h2", 2, 128)
+        P(self.gn["reshead2"], x2, 0, 256, b, 0, "h2")
+        x10 = T("x10", 2, 128)
+        P(self.gn["down10"], x00, 0, 64, x10, 0, "d1", res=b)
+        c = T("h3", 4, 192)
+        P(self.gn["reshead3"], x3, 0, 384, c, 0, "h3")
+        x20 = T("x20", 4, 192)
+        P(self.gn["down20"], x10, 0, 128, x20, 0, "d2", res=c)
+        r11 = T("r11", 2, 128)
+        P(self.gn["res11"], x10, 0, 128, r11, 0, "r1", res=x10)
+        x11 = T("x11", 2, 128)
+        P(self.gn["down11"], x01, 0, 64, x11, 0, "d1", res=r11)          # residual_11 + downsample_11 (the sum commutes)
+        r21 = T("r21", 4, 192)
+        P(self.gn["res21"], x20, 0, 192, r21, 0, "r2", res=x20)
+        x21 = T("x21", 4, 192)
+        P(self.gn["down21"], x11, 0, 128, x21, 0, "d2", res=r21)
+        x24 = T("x24", 4, 192)
+        P(self.gn["res24"], x21, 0, 192, x24, 0, "r2", res=x21)
+        x25 = T("x25", 4, 192)
+        P(self.gn["res25"], x24, 0, 192, x25, 0, "r2", res=x24)
+        r14 = T("r14", 2, 128)
+        P(self.gn["res14"], x11, 0, 128, r14, 0, "r1", res=x11)
+        x14 = T("x14", 2, 128)
+        P(self.gn["up14"], x24, 0, 192, x14, 0, "u1", res=r14)
+        r04 = T("r04", 1, 64)
+        P(self.gn["res04"], x01, 0, 64, r04, 0, "r0", res=x01)
+        x04 = T("x04", 1, 64)
+        P(self.gn["up04"], x14, 0, 128, x04, 0, "u0", res=r04)
+        r15 = T("r15", 2, 128)
+        P(self.gn["res15"], x14, 0, 128, r15, 0, "r1", res=x14)
+        x15 = T("x15", 2, 128)
+        P(self.gn["up15"], x25, 0, 192, x15, 0, "u1", res=r15)
+        r05 = T("r05", 1, 64)
+        P(self.gn["res05"], x04, 0, 64, r05, 0, "r0", res=x04)
+        x05 = T("x05", 1, 64)
+        P(self.gn["up05"], x15, 0, 128, x05, 0, "u0", res=r05)
+        t0, t1 = T("t0", 1, 64), T("t1", 1, 256)
+        self._conv(self.tail[0], x05, 0, t0, 0)
+        self._conv(self.tail[1], t0, 0, t1, 0)
+        ps = self._t("gn_ps", 1, 2 * h, 2 * w, 64)
+        self._c("vfi_pixel_shuffle2", _p(t1), 256, _p(ps), 64, 1, h, w, 64)
+        y = self._t("gn_y", 1, 2 * h, 2 * w, 8)
+        self._conv(self.tail[2], ps, 0, y, 0)
+        return y
+
+    def forward(self, frame0, frame1, t, out):
+        self.prepare(frame0, frame1)
+        return self.render(t, out)
+
+
+def _load(path):
+    sd = torch.load(path, map_location="cpu", weights_only=False)
+    return sd["state_dict"] if isinstance(sd, dict) and "state_dict" in sd else sd
+
+
+class GMFSS_Fortuna_VFI:
+    @classmethod
+    def INPUT_TYPES(s):
+        return {
+            "required": {
+                "ckpt_name": (list(CKPTS_PATH_CONFIG.keys()),),
+                "frames": ("IMAGE",),
+                "clear_cache_after_n_frames": ("INT", {"default": 10, "min": 1, "max": 1000}),
+                "multiplier": ("INT", {"default": 2, "min": 2, "max": 1000}),
+            },
+            "optional": {"optional_interpolation_states": ("INTERPOLATION_STATES",)},
+        }
+
+    RETURN_TYPES = ("IMAGE",)
+    FUNCTION = "vfi"
+    CATEGORY = "ComfyUI-Frame-Interpolation/VFI"
+
+    def vfi(self, ckpt_name: typing.AnyStr, frames: torch.Tensor, clear_cache_after_n_frames=10, multiplier: typing.SupportsInt = 2,
+            optional_interpolation_states: InterpolationStateList = None, **kwargs):
+        from .ckpt import load_file_from_github_release
+        from .m2m import run_plan
+
+        assert len(frames) >= 2, f"VFI model GMFSS Fortuna requires at least 2 frames to work with, only found {frames.shape[0]}."
+        if ckpt_name not in CKPTS_PATH_CONFIG:
+            raise KeyError(ckpt_name)     # "GMFSS_fortuna" (non-union FusionNet) is not on the HIP path yet
+        sds = {part: _load(load_file_from_github_release(*loc)) for part, loc in CKPTS_PATH_CONFIG[ckpt_name].items()}
+        engine = GMFSSEngine(sds)         # (the reference rebuilds the model on every call, gmfss_fortuna/__init__.py:129-130)
+        try:
+            plan, tasks = generic_output_plan(len(frames), multiplier, optional_interpolation_states)
+            return (run_plan(engine, frames, plan, tasks, name="GMFSS Fortuna VFI"),)
+        finally:
+            torch.cuda.synchronize(engine.device)
+            engine.close()

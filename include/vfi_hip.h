@@ -254,6 +254,10 @@ int vfi_softmax_rows(float* x_dev, int nb, int rows, int cols, const float* mask
 /* flow_warp / bilinear_sample: grid_sample(zeros, align_corners=True) at pixel + flow (:955-991) */
 int vfi_flow_sample(const float* in_dev, int in_cs, const float* flow_dev, int flow_cs, float* out_dev, int out_cs, int N, int H, int W,
                     int C, void* stream);
+/* F.interpolate(x, size=(Hout,Wout), mode="bilinear", align_corners=True) * post_mul: the x2 flow up-sampling between GMFlow's
+ * scales (:1302-1307) */
+int vfi_resize_bilinear_ac(const float* in_dev, int in_cs, float* out_dev, int out_cs, int N, int Hin, int Win, int Hout, int Wout,
+                           int C, float post_mul, void* stream);
 /* flow[:, 0:2] += local_correlation_softmax(f0, f1, radius) (:846-913,1335) */
 int vfi_local_match(const float* f0_dev, int f0_cs, const float* f1_dev, int f1_cs, float* flow_dev, int flow_cs, int N, int H, int W,
                     int C, int radius, void* stream);

@@ -422,3 +422,19 @@ def gmfss_forward(sds, i0, i1, timestep):
     ph, pw = ((h - 1) // 64 + 1) * 64, ((w - 1) // 64 + 1) * 64
     i0, i1 = F.pad(i0, (0, pw - w, 0, ph - h)), F.pad(i1, (0, pw - w, 0, ph - h))
     return inference(sds, i0, i1, reuse(sds, i0, i1), timestep)[:, :, :h, :w]
+
+
+def gmfss_vfi(sds, frames, multiplier=2, states=None):
+    """Node-level oracle (gmfss_fortuna/__init__.py:110-143 + generic_frame_loop, vfi_utils.py:149-389, int multiplier);
+    frames [N,H,W,C] fp32 -> [N',H,W,3]"""
+    x = frames[..., :3].permute(0, 3, 1, 2).float()
+    out = []
+    with torch.inference_mode():
+        for i in range(len(x) - 1):
+            out.append(x[i:i + 1])
+            if states is not None and states.is_frame_skipped(i):
+                continue
+            for k in range(1, multiplier):
+                out.append(gmfss_forward(sds, x[i:i + 1], x[i + 1:i + 2], k / multiplier))
+        out.append(x[-1:])
+    return torch.cat(out, 0).permute(0, 2, 3, 1).contiguous()

@@ -203,3 +203,14 @@ def test_splat_wrapper_and_pixel_shuffle(lib):
     yy = nhwc(y)
     ok(lib.vfi_pixel_shuffle2(P(yy), 24, P(ps, 1), 8, 2, 5, 7, 6, None))
     assert torch.equal(nchw(ps[..., 1:7]), F.pixel_shuffle(y, 2))
+
+
+def test_resize_align_corners(lib):
+    torch.manual_seed(8)
+    x = torch.randn(2, 2, 9, 15)
+    want = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True) * 2
+    xi = torch.zeros(2, 9, 15, 4)
+    xi[..., 1:3] = nhwc(x)
+    out = torch.zeros(2, 18, 30, 2)
+    ok(lib.vfi_resize_bilinear_ac(P(xi, 1), 4, P(out), 2, 2, 9, 15, 18, 30, 2, 2.0, None))
+    assert (nchw(out) - want).abs().max() <= 1e-5
