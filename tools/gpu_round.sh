@@ -1,3 +1,5 @@
 #!/bin/bash
 export TMPDIR=/tmp
-timeout 100 python -m pytest tests/test_gpu_ifrnet.py tests/test_gpu_m2m.py -x -q -m gpu -k "1080p_node_default or node or plan" 2>&1 | tail -4
+mkdir -p gpurun_out
+timeout 100 python -m pytest tests/test_gpu_gmfss.py -q -m gpu -s 2>&1 | grep -v "Warning\|_VF\|amdgpu.ids" > gpurun_out/gmfss_tests.log
+grep "^GMFSS\|passed\|failed" gpurun_out/gmfss_tests.log | cut -c1-500
