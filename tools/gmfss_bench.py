@@ -1,0 +1,48 @@
+"""GMFSS Fortuna (union) at 1080p on one MI355X, first-correct path: time of prepare() (Model.reuse: FeatureNet, GMFlow both
+directions, MetricNet) and render(t) (Model.inference), with the kernel split."""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+ge.build()
+ge.load_package()
+from cfi_amd import _lib, synth  # noqa: E402
+from cfi_amd.gmfss import GMFSSEngine  # noqa: E402
+
+if __name__ == "__main__":
+    H, W = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1080, 1920)
+    eng = GMFSSEngine(synth.gmfss_synth_state_dicts(1234))
+    fr = synth.smooth_frames(2, H, W, seed=2, shift=4.0)
+    x0, x1 = fr[0].cuda().contiguous(), fr[1].cuda().contiguous()
+    out = torch.empty(H, W, 3, device="cuda")
+    lib = _lib.load()
+    for rep in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.prepare(x0, x1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        eng.render(0.5, out)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        print(f"GMFSS union {H}x{W} (rep {rep}): prepare {1e3 * (t1 - t0):.1f} ms/pair, render {1e3 * (t2 - t1):.1f} ms/frame; "
+              f"device memory {torch.cuda.memory_allocated() / 2**30:.2f} GiB", flush=True)
+    lib.vfi_trace_reset(); lib.vfi_trace_enable(1)
+    eng.prepare(x0, x1)
+    eng.render(0.5, out)
+    torch.cuda.synchronize()
+    lib.vfi_trace_enable(0)
+    rep = _lib.trace_report()
+    groups = {}
+    for k, v in rep.items():
+        g = k.split("_")[0] if k.startswith(("conv", "deconv")) else k
+        groups[g] = groups.get(g, 0.0) + v[1]
+    tot = sum(groups.values())
+    print("   " + ", ".join(f"{k} {v:.1f}" for k, v in sorted(groups.items(), key=lambda kv: -kv[1])[:14]) + f"  (sum {tot:.1f} ms)", flush=True)
+    print(f"   output finite: {bool(torch.isfinite(out).all())}, range [{out.min().item():.3f}, {out.max().item():.3f}]")
