@@ -109,6 +109,8 @@ int vfi_bmm_nt(const float* a_dev, int a_cs, const float* b_dev, int b_cs, float
                void* stream) {
     VFI_REQUIRE(a_dev && b_dev && out_dev && nb > 0 && M > 0 && N > 0 && K > 0 && a_cs >= K && b_cs >= K, "vfi_bmm_nt: bad arguments");
     BmmNtArgs a{a_dev, a_cs, b_dev, b_cs, out_dev, nb, M, N, K, alpha};
+    if (K % 4 == 0 && a_cs % 4 == 0 && b_cs % 4 == 0 && ((uintptr_t)a_dev & 15) == 0 && ((uintptr_t)b_dev & 15) == 0)
+        return run<BmmNtArgs, bmm_nt4_body>(a, (long)nb * ((M + 3) / 4) * ((N + 3) / 4), stream, "bmm_nt");
     return run<BmmNtArgs, bmm_nt_body>(a, (long)nb * M * N, stream, "bmm_nt");
 }
 

@@ -214,3 +214,13 @@ def test_resize_align_corners(lib):
     out = torch.zeros(2, 18, 30, 2)
     ok(lib.vfi_resize_bilinear_ac(P(xi, 1), 4, P(out), 2, 2, 9, 15, 18, 30, 2, 2.0, None))
     assert (nchw(out) - want).abs().max() <= 1e-5
+
+
+@pytest.mark.parametrize("nb,m,n,k,acs", [(3, 10, 13, 16, 16), (2, 8, 8, 128, 136), (1, 5, 3, 6, 6), (2, 7, 9, 12, 14)])
+def test_bmm_nt_tiled_and_scalar_paths(lib, nb, m, n, k, acs):
+    """K % 4 == 0 with aligned rows takes the 4x4-tile body (edge tiles: M, N not multiples of 4), otherwise the scalar body"""
+    torch.manual_seed(9)
+    a, b = torch.randn(nb, m, acs), torch.randn(nb, n, acs)
+    out = torch.full((nb, m, n), 7.0)
+    ok(lib.vfi_bmm_nt(P(a), acs, P(b), acs, P(out), nb, m, n, k, 0.5, None))
+    assert (out - 0.5 * torch.matmul(a[..., :k], b[..., :k].transpose(1, 2))).abs().max() <= 1e-5
