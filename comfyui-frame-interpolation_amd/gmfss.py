@@ -1,4 +1,4 @@
-"""GMFSS Fortuna VFI node, "union" model — host-side mirror of vfi_models/gmfss_fortuna/__init__.py over
+"""GMFSS Fortuna VFI node, "union" and base models — host-side mirror of vfi_models/gmfss_fortuna/__init__.py over
 the HIP library.  FIRST-CORRECT device path: every convolution / linear layer runs on the fp32-MFMA layer objects
 (vfi_conv_*), everything else on the one-thread-per-element kernels of csrc/gmfss_ops.hip (their bodies are checked on the
 host by the CPU test suite, tests/test_gmfss_bodies_cpu.py; the orchestration below by tests/test_gmfss_engine_cpu.py
@@ -17,7 +17,7 @@ import typing
 import torch
 
 from . import _lib
-from .gmfss_spec import PARTS, gmfss_union_shapes
+from .gmfss_spec import gmfss_shapes
 from .schedule import InterpolationStateList, generic_output_plan
 
 MODEL_TYPE = "gmfss_fortuna"
@@ -28,6 +28,12 @@ CKPTS_PATH_CONFIG = {   # gmfss_fortuna/__init__.py:11-26
         "metricnet": (MODEL_TYPE, "GMFSS_fortuna_union_metric.pkl"),
         "feat_ext": (MODEL_TYPE, "GMFSS_fortuna_union_feat.pkl"),
         "fusionnet": (MODEL_TYPE, "GMFSS_fortuna_union_fusionnet.pkl"),
+    },
+    "GMFSS_fortuna": {   # base model: no IFNet, GridNet head on (img0, I1t, I2t, img1)
+        "flownet": (MODEL_TYPE, "GMFSS_fortuna_flownet.pkl"),
+        "metricnet": (MODEL_TYPE, "GMFSS_fortuna_metric.pkl"),
+        "feat_ext": (MODEL_TYPE, "GMFSS_fortuna_feat.pkl"),
+        "fusionnet": (MODEL_TYPE, "GMFSS_fortuna_fusionnet.pkl"),
     },
 }
 IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
@@ -97,8 +103,9 @@ class GMFSSEngine:
     def __init__(self, state_dicts, device=None, _test_backend=None):
         self.be = _test_backend if _test_backend is not None else _Device(device)
         self.lib, self.device = self.be.lib, self.be.device
-        shapes = gmfss_union_shapes()
-        for part in PARTS:
+        self.union = "ifnet" in state_dicts      # the union model carries rife46.pth; the base model has no IFNet
+        shapes = gmfss_shapes("union" if self.union else "base")
+        for part in shapes:
             sd = state_dicts[part]
             missing = [k for k in shapes[part] if k not in sd]
             if missing:
@@ -240,8 +247,9 @@ class GMFSSEngine:
             return float(gn[p + "0.weight"]), first, mk(gn[p + "3.weight"], gn[p + "3.bias"])
 
         self.gn = {}
-        for name in ("head0", "head1", "head2", "head3", "01", "04", "05", "11", "14", "15", "21", "24", "25"):
-            self.gn["res" + name] = pair(f"residual_model_{name}.", cin_phys=16 if name == "head0" else None)
+        self.gn["reshead0"] = pair("residual_model_head0." if self.union else "residual_model_head.", cin_phys=16)   # 9 / 12 channels
+        for name in ("head1", "head2", "head3", "01", "04", "05", "11", "14", "15", "21", "24", "25"):
+            self.gn["res" + name] = pair(f"residual_model_{name}.")
         for name in ("10", "20", "11", "21"):
             self.gn["down" + name] = pair(f"downsample_model_{name}.", stride=2)
         for name in ("04", "14", "05", "15"):
@@ -250,9 +258,9 @@ class GMFSSEngine:
         self.tail = (mk(gn[p + "conv_before_upsample.0.weight"], gn[p + "conv_before_upsample.0.bias"], gn[p + "conv_before_upsample.1.weight"]),
                      mk(gn[p + "upsample.0.weight"], gn[p + "upsample.0.bias"]), mk(gn[p + "conv_last.weight"], gn[p + "conv_last.bias"]))
         # IFNet 4.6 (rife_arch.py:187-276,404-408): ResConv's beta folded into weights and bias
-        rf = sds["ifnet"]
+        rf = sds.get("ifnet", {})
         self.rife = []
-        for b in range(4):
+        for b in range(4 if self.union else 0):
             p = f"block{b}."
             self.rife.append(dict(
                 c=rf[p + "conv0.1.0.weight"].shape[0],
@@ -505,10 +513,14 @@ class GMFSSEngine:
                 self._resize(zt, 0, zl, 0, 1)
             c = feats[lvl].shape[-1]
             for d in (0, 1):
-                if lvl == 0:
-                    self._splat(himg[d:d + 1], 3, zl[d:d + 1], fl[d:d + 1], g_in[0], 6 * d)      # I1t -> 0:3, I2t -> 6:9
+                if lvl == 0:   # union head: (I1t, rife, I2t); base head: (img0, I1t, I2t, img1)
+                    self._splat(himg[d:d + 1], 3, zl[d:d + 1], fl[d:d + 1], g_in[0], 6 * d if self.union else 3 + 3 * d)
                 self._splat(feats[lvl][d:d + 1], c, zl[d:d + 1], fl[d:d + 1], g_in[lvl + 1], c * d)
-        self._ifnet46(himg, t, g_in[0], 3)
+        if self.union:
+            self._ifnet46(himg, t, g_in[0], 3)
+        else:
+            self._ax(himg[0:1], 0, None, 0, g_in[0], 0, 3)
+            self._ax(himg[1:2], 0, None, 0, g_in[0], 9, 3)
         y = self._gridnet(g_in)
         self._c("vfi_clamp_crop", _p(y), y.shape[-1], Hp, Wp, out.data_ptr(), H, W, 3)
         return out
@@ -571,7 +583,7 @@ class GMFSSEngine:
         T = lambda name, s, c: self._t("gn_" + name, 1, h // s, w // s, c)   # noqa: E731
         P = self._pair
         a = T("h0", 1, 64)
-        P(self.gn["reshead0"], x, 0, 9, a, 0, "h0")
+        P(self.gn["reshead0"], x, 0, 9 if self.union else 12, a, 0, "h0")
         x00 = T("x00", 1, 64)
         P(self.gn["reshead1"], x1, 0, 128, x00, 0, "h1", res=a)
         x01 = T("x01", 1, 64)
@@ -655,7 +667,7 @@ class GMFSS_Fortuna_VFI:
 
         assert len(frames) >= 2, f"VFI model GMFSS Fortuna requires at least 2 frames to work with, only found {frames.shape[0]}."
         if ckpt_name not in CKPTS_PATH_CONFIG:
-            raise KeyError(ckpt_name)     # "GMFSS_fortuna" (non-union FusionNet) is not on the HIP path yet
+            raise KeyError(ckpt_name)
         sds = {part: _load(load_file_from_github_release(*loc)) for part, loc in CKPTS_PATH_CONFIG[ckpt_name].items()}
         engine = GMFSSEngine(sds)         # (the reference rebuilds the model on every call, gmfss_fortuna/__init__.py:129-130)
         try:

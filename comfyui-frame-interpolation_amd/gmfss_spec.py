@@ -88,10 +88,11 @@ def featurenet_shapes():
     return d
 
 
-def gridnet_shapes(cin=9, c1=128, c2=256, c3=384, cout=3):
-    """GridNet (union): head inputs 9 / 128 / 256 / 384 channels (GMFSS_Fortuna_union_arch.py:1582-1637)"""
+def gridnet_shapes(cin=9, c1=128, c2=256, c3=384, cout=3, head="head0"):
+    """GridNet: head inputs 9 (union: I1t, rife, I2t; key residual_model_head0) or 12 (base model: img0, I1t, I2t, img1; key
+    residual_model_head) / 128 / 256 / 384 channels (GMFSS_Fortuna_union_arch.py:1582-1637, GMFSS_Fortuna_arch.py:1583-1638)"""
     d = OrderedDict()
-    for name, (a, b) in (("head0", (cin, 64)), ("head1", (c1, 64)), ("head2", (c2, 128)), ("head3", (c3, 192)),
+    for name, (a, b) in ((head, (cin, 64)), ("head1", (c1, 64)), ("head2", (c2, 128)), ("head3", (c3, 192)),
                          ("01", (64, 64)), ("04", (64, 64)), ("05", (64, 64))):
         _pair(d, f"residual_model_{name}.", a, b)
     p = "residual_model_tail."
@@ -114,3 +115,13 @@ def gridnet_shapes(cin=9, c1=128, c2=256, c3=384, cout=3):
 def gmfss_union_shapes():
     return {"ifnet": ifnet46_shapes(), "flownet": gmflow_shapes(), "metricnet": metricnet_shapes(), "feat_ext": featurenet_shapes(),
             "fusionnet": gridnet_shapes()}
+
+
+def gmfss_base_shapes():
+    """"GMFSS_fortuna" (gmfss_fortuna/__init__.py:19-24, GMFSS_Fortuna_arch.py): no IFNet, 12-channel GridNet head"""
+    return {"flownet": gmflow_shapes(), "metricnet": metricnet_shapes(), "feat_ext": featurenet_shapes(),
+            "fusionnet": gridnet_shapes(cin=12, head="head")}
+
+
+def gmfss_shapes(variant):
+    return {"union": gmfss_union_shapes, "base": gmfss_base_shapes}[variant]()

@@ -140,13 +140,13 @@ def ifrnet_synth_state_dict(kind="L", seed=1234, gain=1.0):
     return sd
 
 
-def gmfss_synth_state_dicts(seed=1234):
-    """GMFSS Fortuna (union): the five state_dicts.  Conv / linear weights U(+-sqrt(3/fan_in)), biases U(+-0.05), PReLU
+def gmfss_synth_state_dicts(seed=1234, variant="union"):
+    """GMFSS Fortuna: the five ("union") or four ("base") state_dicts.  Conv / linear weights U(+-sqrt(3/fan_in)), biases U(+-0.05), PReLU
     slopes U(0.1, 0.4), LayerNorm weights 1 +- 0.1, ResConv betas 1 +- 0.25 (as rife47)."""
-    from .gmfss_spec import gmfss_union_shapes
+    from .gmfss_spec import gmfss_shapes
 
     out = {}
-    for part, shapes in gmfss_union_shapes().items():
+    for part, shapes in gmfss_shapes(variant).items():
         sd = {}
         for k, shp in shapes.items():
             g = _gen(seed, part + "/" + k)

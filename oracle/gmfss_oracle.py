@@ -322,7 +322,7 @@ def gridnet(sd, x, x1, x2, x3):
     def up(name, t):
         return _prelu_conv_pair(sd, f"upsample_model_{name}.", t, 2, transposed=True)
 
-    x00 = res("head0", x) + res("head1", x1)
+    x00 = res("head0" if "residual_model_head0.0.weight" in sd else "head", x) + res("head1", x1)
     x01 = res("01", x00) + x00
     x10 = down("10", x00) + res("head2", x2)
     x20 = down("20", x10) + res("head3", x3)
@@ -401,7 +401,8 @@ def inference(sds, img0, img1, state, timestep):
     h1 = F.interpolate(img1, scale_factor=0.5, mode="bilinear", align_corners=False)
     i1t = softsplat_soft(h0, f1t, z1t)
     i2t = softsplat_soft(h1, f2t, z2t)
-    rife = ifnet46_forward(sds["ifnet"], h0, h1, timestep)
+    # union model: IFNet 4.6 between the two splats; base model (GMFSS_Fortuna_arch.py:1843-1849): the two half-res images
+    head = [i1t, ifnet46_forward(sds["ifnet"], h0, h1, timestep), i2t] if "ifnet" in sds else [h0, i1t, i2t, h1]
     levels = []
     for lvl, s in enumerate((1.0, 0.5, 0.25)):
         if s == 1.0:
@@ -412,7 +413,7 @@ def inference(sds, img0, img1, state, timestep):
             fb = F.interpolate(f2t, scale_factor=s, mode="bilinear", align_corners=False) * s
             zb = F.interpolate(z2t, scale_factor=s, mode="bilinear", align_corners=False)
         levels.append(torch.cat([softsplat_soft(feats0[lvl], fa, za), softsplat_soft(feats1[lvl], fb, zb)], dim=1))
-    out = gridnet(sds["fusionnet"], torch.cat([i1t, rife, i2t], dim=1), *levels)
+    out = gridnet(sds["fusionnet"], torch.cat(head, dim=1), *levels)
     return torch.clamp(out, 0, 1)
 
 

@@ -114,6 +114,31 @@ def main():
             ok &= d == 0.0
             if (h, w) == (100, 150):
                 golden["frames"], golden["t"], golden["out"] = fr.numpy(), np.float32(t), r.permute(0, 2, 3, 1).contiguous().numpy()
+        # ---- the base model ("GMFSS_fortuna": no IFNet, 12-channel GridNet head), GMFSS_Fortuna_arch.py
+        from vfi_models.gmfss_fortuna import GMFSS_Fortuna_arch as B
+
+        bsds = synth.gmfss_synth_state_dicts(1234, "base")
+        bmodel = B.Model()
+        bmodel.eval()
+        bnets = {"flownet": bmodel.flownet, "metricnet": bmodel.metricnet, "feat_ext": bmodel.feat_ext, "fusionnet": bmodel.fusionnet}
+        bshapes = gmfss_spec.gmfss_base_shapes()
+        for part, net in bnets.items():
+            assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == {k: tuple(v) for k, v in bshapes[part].items()}, part
+            assert list(net.state_dict()) == list(bshapes[part]), f"{part}: key order differs"
+            net.load_state_dict(bsds[part], strict=True)
+        cmb = N.CommonModelInference.__new__(N.CommonModelInference)
+        torch.nn.Module.__init__(cmb)
+        cmb.model = bmodel
+        for (h, w, t) in ((100, 150, 0.5), (64, 64, 0.3)):
+            fr = synth.smooth_frames(2, h, w, seed=h, shift=2.5)
+            x = fr.permute(0, 3, 1, 2).contiguous()
+            r = cmb(x[0:1], x[1:2], t, 1)
+            o = G.gmfss_forward(bsds, x[0:1], x[1:2], t)
+            d = (r - o).abs().max().item()
+            log(f"GMFSS base forward {h}x{w} t={t}: max|ref-oracle| = {d:.3e}   out std {r.std().item():.3f}")
+            ok &= d == 0.0
+            if (h, w) == (100, 150):
+                golden["base_out"] = r.permute(0, 2, 3, 1).contiguous().numpy()
     log("RESULT: " + ("oracle == reference, bit-exact on every case (summation splat via the C restatement on both sides)" if ok
                       else "MISMATCH"))
     np.savez_compressed(os.path.join(OUT, "gmfss_union.npz"), **golden)

@@ -10,11 +10,11 @@ from emu_backend import EmuBackend
 from oracle import gmfss_oracle as G
 
 
-@pytest.fixture(scope="module")
-def setup():
+@pytest.fixture(scope="module", params=["union", "base"])
+def setup(request):
     from cfi_amd.gmfss import GMFSSEngine
 
-    sds = synth.gmfss_synth_state_dicts(1234)
+    sds = synth.gmfss_synth_state_dicts(1234, request.param)
     eng = GMFSSEngine(sds, _test_backend=EmuBackend())
     yield sds, eng
     eng.close()

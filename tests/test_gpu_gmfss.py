@@ -16,12 +16,12 @@ from test_gmfss_engine_cpu import check_against_oracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def setup(hip_lib):
+@pytest.fixture(scope="module", params=["union", "base"])
+def setup(request, hip_lib):
     from cfi_amd.gmfss import GMFSSEngine
 
     torch.cuda.set_device(0)
-    sds = synth.gmfss_synth_state_dicts(1234)
+    sds = synth.gmfss_synth_state_dicts(1234, request.param)
     eng = GMFSSEngine(sds)
     yield sds, eng
     eng.close()
@@ -57,4 +57,4 @@ def test_node_against_oracle_loop(hip_lib, tmp_path, monkeypatch):
     d = (out - want).abs()
     assert d.mean().item() <= 3e-3 and (d > 2e-2).float().mean().item() <= 0.05, f"max {d.max().item()} mean {d.mean().item()}"
     with pytest.raises(KeyError):
-        M.GMFSS_Fortuna_VFI().vfi("GMFSS_fortuna", frames)
+        M.GMFSS_Fortuna_VFI().vfi("GMFSS_fortuna_v2", frames)

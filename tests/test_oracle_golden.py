@@ -263,10 +263,12 @@ def test_gmfss_union_matches_reference_golden(golden_dir):
     x = torch.from_numpy(g["frames"]).permute(0, 3, 1, 2).contiguous()
     with torch.inference_mode():
         out = gmfss_oracle.gmfss_forward(synth.gmfss_synth_state_dicts(1234), x[0:1], x[1:2], float(g["t"])).permute(0, 2, 3, 1)
+        base = gmfss_oracle.gmfss_forward(synth.gmfss_synth_state_dicts(1234, "base"), x[0:1], x[1:2], float(g["t"])).permute(0, 2, 3, 1)
     assert out.shape == g["out"].shape
     # the matching softmax over ~200 random-feature candidates amplifies last-bit differences of other CPUs' matmul
     # kernels; on the build container the agreement is bit-exact (oracle/VALIDATION_GMFSS.log)
     assert np.abs(out.numpy() - g["out"]).mean() <= 1e-4
+    assert np.abs(base.numpy() - g["base_out"]).mean() <= 1e-4
 
 
 def test_gmfss_spec_tables():
@@ -274,5 +276,7 @@ def test_gmfss_spec_tables():
 
     sh = gmfss_spec.gmfss_union_shapes()
     assert [len(sh[p]) for p in gmfss_spec.PARTS] == [120, 124, 14, 18, 133]
+    base = gmfss_spec.gmfss_base_shapes()
+    assert "ifnet" not in base and base["fusionnet"]["residual_model_head.1.weight"] == (64, 12, 3, 3)
     sds = synth.gmfss_synth_state_dicts(3)
     assert all(tuple(sds[p][k].shape) == tuple(v) for p in gmfss_spec.PARTS for k, v in sh[p].items())
