@@ -168,6 +168,36 @@ def gmfss_synth_state_dicts(seed=1234, variant="union"):
     return out
 
 
+def ifunet_synth_state_dict(seed=1234):
+    """IFUNet.pth: conv / linear weights U(+-sqrt(3/fan_in)) (the IFBlocks' flow convs x1.5, ResynNet's last convs x0.5: flows of a few
+    pixels), biases U(+-0.05), PReLU slopes U(0.1, 0.4), BatchNorm weight 1 +- 0.1,
+    bias +-0.05, running_mean +-0.1, running_var U(0.5, 1.5)."""
+    from .ifunet_spec import ifunet_shapes
+
+    sd = {}
+    for k, shp in ifunet_shapes().items():
+        g = _gen(seed, "ifunet/" + k)
+        if k.endswith("num_batches_tracked"):
+            t = torch.tensor(100, dtype=torch.int64)
+        elif len(shp) >= 2:
+            fan_in = 1
+            for d in shp[1:]:
+                fan_in *= d
+            t = (torch.rand(shp, generator=g) * 2 - 1) * math.sqrt(3.0 / fan_in) * (1.5 if "flowconv" in k else 0.5 if "lastconv" in k else 1.0)
+        elif k.endswith("running_var"):
+            t = 0.5 + torch.rand(shp, generator=g)
+        elif k.endswith("running_mean"):
+            t = (torch.rand(shp, generator=g) * 2 - 1) * 0.1
+        elif ".bn." in k or k.split(".")[-2] == "1" and "refinenet.block" in k:   # BatchNorm affine
+            t = 1.0 + 0.1 * (torch.rand(shp, generator=g) * 2 - 1) if k.endswith("weight") else (torch.rand(shp, generator=g) * 2 - 1) * 0.05
+        elif k.endswith("bias"):
+            t = (torch.rand(shp, generator=g) * 2 - 1) * 0.05
+        else:  # PReLU slopes
+            t = 0.1 + 0.3 * torch.rand(shp, generator=g)
+        sd[k] = t.contiguous() if t.dtype == torch.int64 else t.to(torch.float32).contiguous()
+    return sd
+
+
 def smooth_frames(n, h, w, seed=0, shift=3.0, c=3):
     """[n,h,w,c] f32 in [0,1]: low-pass noise drifting ``shift`` px/frame (ComfyUI IMAGE layout)."""
     g = torch.Generator(device="cpu")

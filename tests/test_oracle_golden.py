@@ -280,3 +280,30 @@ def test_gmfss_spec_tables():
     assert "ifnet" not in base and base["fusionnet"]["residual_model_head.1.weight"] == (64, 12, 3, 3)
     sds = synth.gmfss_synth_state_dicts(3)
     assert all(tuple(sds[p][k].shape) == tuple(v) for p in gmfss_spec.PARTS for k, v in sh[p].items())
+
+
+# ---- IFUNet (second half): goldens written by oracle/validate_ifunet_vs_reference.py from the reference node --
+IFUNET_NODE_CASES = {
+    "x2": dict(multiplier=2),
+    "x2_noens_s05": dict(multiplier=2, scale_factor=0.5, ensemble=False),
+    "x3_skip0": dict(multiplier=3, states=InterpolationStateList([0], True)),
+}
+
+
+@pytest.mark.parametrize("name", list(IFUNET_NODE_CASES))
+def test_ifunet_node_matches_reference_golden(golden_dir, name):
+    from oracle import ifunet_oracle
+
+    g = np.load(os.path.join(golden_dir, "ifunet_node.npz"))
+    out = ifunet_oracle.ifunet_vfi(synth.ifunet_synth_state_dict(1234), torch.from_numpy(g["frames"]), **IFUNET_NODE_CASES[name])
+    assert out.shape == g[name].shape
+    assert np.abs(out.numpy() - g[name]).max() <= 5 * TOL
+
+
+def test_ifunet_spec_table():
+    from cfi_amd import ifunet_spec
+
+    sh = ifunet_spec.ifunet_shapes()
+    assert len(sh) == 608 and sh["flownet.block0.maskconvx16.weight"] == (2304, 256, 1, 1) and sh["refinenet.block1.conv0.0.0.weight"] == (64, 12, 3, 3)
+    sd = synth.ifunet_synth_state_dict(2)
+    assert all(tuple(sd[k].shape) == tuple(v) for k, v in sh.items())
