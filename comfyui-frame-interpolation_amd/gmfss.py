@@ -16,7 +16,6 @@ import typing
 
 import torch
 
-from . import _lib
 from .gmfss_spec import gmfss_shapes
 from .schedule import InterpolationStateList, generic_output_plan
 
@@ -39,31 +38,7 @@ CKPTS_PATH_CONFIG = {   # gmfss_fortuna/__init__.py:11-26
 IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
 
 
-def _p(t, off=0):
-    return t.data_ptr() + 4 * off
-
-
-def _cs(c):
-    return (c + 7) // 8 * 8
-
-
-class _Device:
-    """The real backend: libvfi_hip.so on the current GPU (there is no CPU fallback)."""
-
-    def __init__(self, device=None):
-        if not torch.cuda.is_available():
-            raise RuntimeError("GMFSS Fortuna VFI (HIP): no GPU visible; this node has no CPU fallback")
-        self.lib = _lib.load()
-        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        _lib.check(self.lib.vfi_init(self.device.index or 0), "vfi_init")
-
-    @staticmethod
-    def stream():
-        return _lib.stream_ptr()
-
-    @staticmethod
-    def last_error():
-        return _lib.last_error()
+from .opsengine import OpsEngine, _cs, _p
 
 
 # ---- host-side constant tables (uploaded once per shape) ------------------------------------------------------------
@@ -99,10 +74,9 @@ def shift_mask(h, w, k):
     return torch.where(diff != 0, torch.tensor(-100.0), torch.tensor(0.0)).contiguous()
 
 
-class GMFSSEngine:
+class GMFSSEngine(OpsEngine):
     def __init__(self, state_dicts, device=None, _test_backend=None):
-        self.be = _test_backend if _test_backend is not None else _Device(device)
-        self.lib, self.device = self.be.lib, self.be.device
+        super().__init__(device, _test_backend)
         self.union = "ifnet" in state_dicts      # the union model carries rife46.pth; the base model has no IFNet
         shapes = gmfss_shapes("union" if self.union else "base")
         for part in shapes:
@@ -113,86 +87,12 @@ class GMFSSEngine:
             for k, shp in shapes[part].items():
                 if tuple(sd[k].shape) != tuple(shp):
                     raise ValueError(f"GMFSS {part} checkpoint: {k} has shape {tuple(sd[k].shape)}, expected {tuple(shp)}")
-        self.handles = []
         self._build(state_dicts)
-        self.scratch, self.consts = {}, {}
         self.prepared = None
 
-    # ---- plumbing ---------------------------------------------------------------------------------------------------
-    def _c(self, name, *args):
-        rc = getattr(self.lib, name)(*args, self.be.stream())
-        if rc != 0:
-            raise RuntimeError(f"{name} failed (code {rc}): {self.be.last_error()}")
-
-    def _t(self, name, *shape):
-        key = (name,) + tuple(shape)
-        if key not in self.scratch:
-            self.scratch[key] = torch.zeros(shape, dtype=torch.float32, device=self.device)
-        return self.scratch[key]
-
-    def _const(self, key, make):
-        if key not in self.consts:
-            self.consts[key] = make().to(self.device, torch.float32).contiguous()
-        return self.consts[key]
-
-    def _layer(self, w, b=None, slopes=None, kind=0, stride=1, chan_map=None, cin_phys=None, scale_out=None):
-        """vfi_conv layer object from checkpoint tensors.  w: Conv2d [co,ci,k,k] / Linear [co,ci] / ConvTranspose2d [ci,co,4,4];
-        slopes: scalar PReLU slope (replicated) or per-channel vector; scale_out: per-output-channel factor folded into the
-        weights and bias (ResConv's beta)."""
-        w = w.detach().to("cpu", torch.float32)
-        if w.dim() == 2:
-            w = w[:, :, None, None]
-        cout, cin = (w.shape[0], w.shape[1]) if kind == 0 else (w.shape[1], w.shape[0])
-        b = torch.zeros(cout) if b is None else b.detach().to("cpu", torch.float32)
-        if scale_out is not None:
-            s = scale_out.detach().to("cpu", torch.float32).reshape(-1)
-            w = w * (s.view(-1, 1, 1, 1) if kind == 0 else s.view(1, -1, 1, 1))
-            b = b * s
-        w, b = w.contiguous(), b.contiguous()
-        pr = None
-        if slopes is not None:
-            pr = slopes.detach().to("cpu", torch.float32).reshape(-1)
-            pr = (pr.repeat(cout) if pr.numel() == 1 else pr).contiguous()
-        cin_phys = cin_phys or _cs(cin)
-        cm = (C.c_int * cin)(*chan_map) if chan_map is not None else None
-        h = self.lib.vfi_conv_create_ex(kind, w.data_ptr(), b.data_ptr(), cout, cin, w.shape[2], stride, 0, cm, cin_phys,
-                                        pr.data_ptr() if pr is not None else None)
-        if not h:
-            raise RuntimeError("vfi_conv_create_ex failed: " + self.be.last_error())
-        self.handles.append(h)
-        return dict(h=h, kind=kind, stride=stride, cout=cout, act=3 if pr is not None else 0)
-
-    def _conv(self, L, src, soff, dst, doff, act=None, slope=0.0, res=None):
-        n, hin, win, cs = src.shape
-        want = (hin * 2, win * 2) if L["kind"] == 1 else (hin // L["stride"], win // L["stride"])
-        assert tuple(dst.shape[1:3]) == want and dst.shape[0] == n, (src.shape, dst.shape, want)
-        self._c("vfi_conv_forward_ex", L["h"], _p(src, soff), cs, hin, win, _p(dst, doff), dst.shape[-1], n,
-                L["act"] if act is None else act, slope, 0.0, 0.0, _p(res) if res is not None else None,
-                res.shape[-1] if res is not None else 0)
-
-    def _ax(self, a, aoff, b, boff, out, ooff, c, alpha=1.0, beta=1.0, px=None):
-        px = px if px is not None else a.shape[0] * a.shape[1] * a.shape[2]
-        self._c("vfi_axpby", _p(a, aoff), a.shape[-1], _p(b, boff) if b is not None else None, b.shape[-1] if b is not None else 0,
-                _p(out, ooff), out.shape[-1], px, c, alpha, beta)
-
-    def _resize(self, src, soff, dst, doff, c, mul=1.0):
-        self._c("vfi_resize_bilinear", _p(src, soff), src.shape[-1], _p(dst, doff), dst.shape[-1], src.shape[0], src.shape[1], src.shape[2],
-                dst.shape[1], dst.shape[2], c, mul)
-
-    def close(self):
-        for h in self.handles:
-            self.lib.vfi_conv_destroy(h)
-        self.handles = []
-        self.release_workspace()
-
     def release_workspace(self):
-        self.scratch, self.prepared = {}, None
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:   # noqa: BLE001 — interpreter shutdown
-            pass
+        super().release_workspace()
+        self.prepared = None
 
     # ---- layer objects ----------------------------------------------------------------------------------------------
     def _build(self, sds):
@@ -271,9 +171,6 @@ class GMFSSEngine:
                 last=mk(rf[p + "lastconv.0.weight"], rf[p + "lastconv.0.bias"], kind=1, stride=2)))
 
     # ---- small composite ops ----------------------------------------------------------------------------------------
-    def _prelu(self, src, soff, dst, doff, c, slope):
-        self._c("vfi_prelu_scalar", _p(src, soff), src.shape[-1], _p(dst, doff), dst.shape[-1], c, src.shape[0] * src.shape[1] * src.shape[2], slope)
-
     def _pair(self, blk, src, soff, cin, dst, doff, tag, res=None):
         """Sequential(PReLU(a), conv | deconv, PReLU(b), conv)(src[..., soff:soff+cin]) (+ res) -> dst[..., doff:]"""
         a, first, second = blk
