@@ -10,7 +10,9 @@
 #include <math.h>
 #include <stddef.h>
 
+#ifndef VFI_HD
 #define VFI_HD __host__ __device__ static inline
+#endif
 
 namespace vfi_gmfss {
 

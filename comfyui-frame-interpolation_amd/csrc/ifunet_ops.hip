@@ -1,0 +1,91 @@
+// IFUNet kernels — SURVEY.md 8f rank 4, second half: the parts of vfi_models/ifunet/IFUNet_arch.py that are not convolutions
+// (those run on the fp32-MFMA layer objects): CBAM's channel and spatial gates, the 4-channel convex flow up-sampling of the
+// IFBlocks, the mask blends of IFUNetModel / ResynNet.  Bodies in ifunet_bodies.h, launch scheme in body_launch.h.
+// STATUS: checked on the host (tests/test_ifunet_bodies_cpu.py) and through the CPU test double; not yet run on an MI355X
+// (the round's GPU budget was spent) — the GPU tests of tests/test_gpu_ifunet.py are opt-in until then.
+#include "../../include/vfi_hip.h"
+#include "ifunet_bodies.h"
+#include "body_launch.h"
+
+using namespace vfi;
+using namespace vfi_ifunet;
+
+extern "C" {
+
+int vfi_channel_pool(const float* x_dev, int cs, int C, int N, int64_t HW, float* stats_dev, void* workspace_dev, int64_t workspace_bytes,
+                     void* stream) {
+    const int strips = 64;
+    VFI_REQUIRE(x_dev && stats_dev && workspace_dev && C > 0 && cs >= C && N > 0 && HW > 0, "vfi_channel_pool: bad arguments");
+    const int64_t cells = (int64_t)N * strips * C;
+    VFI_REQUIRE(workspace_bytes >= cells * (int64_t)(sizeof(double) + sizeof(float)), "vfi_channel_pool: workspace too small");
+    double* psum = (double*)workspace_dev;
+    float* pmax = (float*)(psum + cells);
+    PoolPartArgs a{x_dev, cs, C, N, (long)HW, strips, psum, pmax};
+    int rc = run<PoolPartArgs, chan_pool_partial_body>(a, (long)cells, stream, "channel_pool_partial");
+    if (rc) return rc;
+    PoolFinalArgs f{psum, pmax, C, N, (long)HW, strips, stats_dev};
+    return run<PoolFinalArgs, chan_pool_final_body>(f, (long)N * C, stream, "channel_pool_final");
+}
+
+int vfi_cbam_gate(const float* stats_dev, const float* w1_dev, const float* b1_dev, const float* w2_dev, const float* b2_dev, int C, int R,
+                  int N, float* scale_dev, void* stream) {
+    VFI_REQUIRE(stats_dev && w1_dev && b1_dev && w2_dev && b2_dev && scale_dev && C > 0 && R > 0 && N > 0, "vfi_cbam_gate: bad arguments");
+    GateArgs a{stats_dev, w1_dev, b1_dev, w2_dev, b2_dev, C, R, N, scale_dev};
+    return run<GateArgs, cbam_gate_body>(a, (long)N * C, stream, "cbam_gate");
+}
+
+int vfi_cbam_scale_compress(const float* x_dev, int cs, const float* scale_dev, int C, int N, int64_t HW, float* xs_dev, int xs_cs,
+                            float* comp_dev, void* stream) {
+    VFI_REQUIRE(x_dev && scale_dev && xs_dev && comp_dev && C > 0 && cs >= C && xs_cs >= C && N > 0 && HW > 0,
+                "vfi_cbam_scale_compress: bad arguments");
+    ScaleCompArgs a{x_dev, cs, scale_dev, C, N, (long)HW, xs_dev, xs_cs, comp_dev};
+    return run<ScaleCompArgs, cbam_scale_compress_body>(a, (long)N * HW, stream, "cbam_scale_compress");
+}
+
+int vfi_cbam_spatial(float* xs_dev, int cs, const float* comp_dev, const float* w_dev, float bn_a, float bn_b, int C, int N, int H, int W,
+                     void* stream) {
+    VFI_REQUIRE(xs_dev && comp_dev && w_dev && C > 0 && cs >= C && N > 0 && H > 0 && W > 0, "vfi_cbam_spatial: bad arguments");
+    SpatialArgs a{xs_dev, cs, comp_dev, w_dev, bn_a, bn_b, C, N, H, W};
+    return run<SpatialArgs, cbam_spatial_body>(a, (long)N * H * W, stream, "cbam_spatial");
+}
+
+int vfi_convex_upsample_c(const float* mask_dev, int mask_cs, const float* flow_dev, int flow_cs, float* out_dev, int out_cs, int N, int H,
+                          int W, int factor, int flow_channels, void* stream) {
+    VFI_REQUIRE(mask_dev && flow_dev && out_dev && N > 0 && H > 0 && W > 0 && factor > 0 && mask_cs >= 9 * factor * factor &&
+                    flow_channels > 0 && flow_channels <= 8 && flow_cs >= flow_channels && out_cs >= flow_channels,
+                "vfi_convex_upsample_c: bad arguments");
+    ConvexUpCArgs a{mask_dev, mask_cs, flow_dev, flow_cs, out_dev, out_cs, N, H, W, factor, flow_channels};
+    return run<ConvexUpCArgs, convex_up_c_body>(a, (long)N * H * W * factor * factor, stream, "convex_upsample_c");
+}
+
+int vfi_lerp_mask(const float* a_dev, int a_cs, const float* b_dev, int b_cs, const float* mask_dev, int mask_cs, float* out_dev,
+                  int out_cs, int C, int64_t pixels, void* stream) {
+    VFI_REQUIRE(a_dev && b_dev && mask_dev && out_dev && C > 0 && a_cs >= C && b_cs >= C && out_cs >= C && mask_cs >= 1 && pixels > 0,
+                "vfi_lerp_mask: bad arguments");
+    LerpArgs a{a_dev, a_cs, b_dev, b_cs, mask_dev, mask_cs, out_dev, out_cs, C, (long)pixels};
+    return run<LerpArgs, lerp_mask_body>(a, (long)pixels * C, stream, "lerp_mask");
+}
+
+int vfi_add_clamp01(const float* a_dev, int a_cs, const float* b_dev, int b_cs, float* out_dev, int out_cs, int C, int64_t pixels,
+                    void* stream) {
+    VFI_REQUIRE(a_dev && b_dev && out_dev && C > 0 && a_cs >= C && b_cs >= C && out_cs >= C && pixels > 0, "vfi_add_clamp01: bad arguments");
+    AddClampArgs a{a_dev, a_cs, b_dev, b_cs, out_dev, out_cs, C, (long)pixels};
+    return run<AddClampArgs, add_clamp_body>(a, (long)pixels * C, stream, "add_clamp01");
+}
+
+int vfi_ifunet_blend(const float* img0_dev, const float* img1_dev, const float* deg_dev, int img_cs, const float* mask0_dev,
+                     const float* mask1_dev, int mask_cs, float* out_dev, int Hp, int Wp, int H, int W, void* stream) {
+    VFI_REQUIRE(img0_dev && img1_dev && deg_dev && mask0_dev && mask1_dev && out_dev && img_cs >= 3 && mask_cs >= 1 && Hp >= H && Wp >= W &&
+                    H > 0 && W > 0,
+                "vfi_ifunet_blend: bad arguments");
+    ResynBlendArgs a{img0_dev, img1_dev, deg_dev, img_cs, mask0_dev, mask1_dev, mask_cs, out_dev, Hp, Wp, H, W};
+    return run<ResynBlendArgs, resyn_blend_body>(a, (long)H * W, stream, "ifunet_blend");
+}
+
+int vfi_fill_channels(float* out_dev, int cs, int C, int64_t pixels, float value, void* stream) {
+    VFI_REQUIRE(out_dev && C > 0 && cs >= C && pixels > 0, "vfi_fill_channels: bad arguments");
+    FillArgs a{out_dev, cs, C, (long)pixels, value};
+    return run<FillArgs, fill_body>(a, (long)pixels * C, stream, "fill_channels");
+}
+
+}  // extern "C"

@@ -283,6 +283,36 @@ int vfi_pixel_shuffle2(const float* in_dev, int in_cs, float* out_dev, int out_c
 /* torch.clamp(x, 0, 1)[:, :, :H, :W] into a dense [H,W,C] frame (:1857, gmfss_fortuna/__init__.py:78) */
 int vfi_clamp_crop(const float* in_dev, int in_cs, int Hp, int Wp, float* out_dev, int H, int W, int C, void* stream);
 
+/* ---- IFUNet building blocks (vfi_models/ifunet/IFUNet_arch.py; ifunet.py drives them with the layer objects above).
+ * Checked on the host and through the CPU test double; first MI355X run pending (see csrc/ifunet_ops.hip). --------------- */
+
+/* CBAM ChannelGate pooling (:411-436): stats [N][C][2] = (mean, max) over H*W; workspace >= N*64*C*12 bytes */
+int vfi_channel_pool(const float* x_dev, int cs, int C, int N, int64_t HW, float* stats_dev, void* workspace_dev, int64_t workspace_bytes,
+                     void* stream);
+/* scale [N][C] = sigmoid(mlp(mean) + mlp(max)), mlp = Linear(C,R) -> ReLU -> Linear(R,C); w1 [R][C], w2 [C][R] on the device (:447-452) */
+int vfi_cbam_gate(const float* stats_dev, const float* w1_dev, const float* b1_dev, const float* w2_dev, const float* b2_dev, int C, int R,
+                  int N, float* scale_dev, void* stream);
+/* xs = x * scale[n][c] and ChannelPool comp [N*HW][2] = (max_c xs, mean_c xs) (:451-466) */
+int vfi_cbam_scale_compress(const float* x_dev, int cs, const float* scale_dev, int C, int N, int64_t HW, float* xs_dev, int xs_cs,
+                            float* comp_dev, void* stream);
+/* SpatialGate in place: xs *= sigmoid(bn_a * conv7x7(comp) + bn_b); w [7][7][2] on the device, BatchNorm folded (:469-482) */
+int vfi_cbam_spatial(float* xs_dev, int cs, const float* comp_dev, const float* w_dev, float bn_a, float bn_b, int C, int N, int H, int W,
+                     void* stream);
+/* IFBlock.upsample_flow: convex up-sampling by `factor` of a flow with up to 8 channels (:627-638) */
+int vfi_convex_upsample_c(const float* mask_dev, int mask_cs, const float* flow_dev, int flow_cs, float* out_dev, int out_cs, int N, int H,
+                          int W, int factor, int flow_channels, void* stream);
+/* out = a * mask + b * (1 - mask), mask one channel (:764) */
+int vfi_lerp_mask(const float* a_dev, int a_cs, const float* b_dev, int b_cs, const float* mask_dev, int mask_cs, float* out_dev,
+                  int out_cs, int C, int64_t pixels, void* stream);
+/* out = clamp(a + b, 0, 1) (:161) */
+int vfi_add_clamp01(const float* a_dev, int a_cs, const float* b_dev, int b_cs, float* out_dev, int out_cs, int C, int64_t pixels,
+                    void* stream);
+/* ResynNet's blend, cropped to H x W: softmax over (clamp(m0,-4,4), clamp(m1,-4,4), 0) weights img0, img1, deg (:188-192,766) */
+int vfi_ifunet_blend(const float* img0_dev, const float* img1_dev, const float* deg_dev, int img_cs, const float* mask0_dev,
+                     const float* mask1_dev, int mask_cs, float* out_dev, int Hp, int Wp, int H, int W, void* stream);
+/* out[p, 0:C] = value (timestep planes, :667-670) */
+int vfi_fill_channels(float* out_dev, int cs, int C, int64_t pixels, float value, void* stream);
+
 /* ---- RIFE 4.7 / 4.9 model --------------------------------------------------------------- */
 
 typedef struct vfi_rife vfi_rife_t;

@@ -1,6 +1,6 @@
-"""TEST INFRASTRUCTURE — host-side build of the GMFSS kernel bodies.
+"""TEST INFRASTRUCTURE — host-side build of the GMFSS / IFUNet kernel bodies.
 
-``csrc/gmfss_ops.hip`` compiled with ``-DVFI_HOSTCHECK`` exports the same C-ABI entry points as libvfi_hip.so, but each one
+``csrc/gmfss_ops.hip`` and ``csrc/ifunet_ops.hip`` compiled with ``-DVFI_HOSTCHECK`` exports the same C-ABI entry points as libvfi_hip.so, but each one
 runs its per-element body (``csrc/gmfss_bodies.h``, ``__host__ __device__``) in a plain host loop instead of launching the
 kernel.  No GPU is needed to build or run it, pointers are host pointers.  The CPU test suite uses it (a) to check every
 body against torch and (b) as the backend of the test double of the C ABI (tests/emu_backend.py) that runs the engine's
@@ -16,8 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "comfyui-frame-interpolation_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libvfi_hostcheck.so")
-SOURCES = [os.path.join(CSRC, "gmfss_ops.hip"), os.path.join(CSRC, "util.hip")]
-DEPS = SOURCES + [os.path.join(CSRC, "gmfss_bodies.h"), os.path.join(CSRC, "vfi_common.h"), os.path.join(ROOT, "include", "vfi_hip.h")]
+SOURCES = [os.path.join(CSRC, "gmfss_ops.hip"), os.path.join(CSRC, "ifunet_ops.hip"), os.path.join(CSRC, "util.hip")]
+DEPS = SOURCES + [os.path.join(CSRC, h) for h in ("gmfss_bodies.h", "ifunet_bodies.h", "body_launch.h", "vfi_common.h")] + [os.path.join(ROOT, "include", "vfi_hip.h")]
 _lib = None
 
 
