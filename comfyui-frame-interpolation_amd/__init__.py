@@ -12,6 +12,7 @@ _LAZY = {
     "M2M_VFI": ("m2m", "M2M_VFI"),
     "IFRNet_VFI": ("ifrnet", "IFRNet_VFI"),
     "GMFSS_Fortuna_VFI": ("gmfss", "GMFSS_Fortuna_VFI"),
+    "IFUnet_VFI": ("ifunet", "IFUnet_VFI"),
     "MakeInterpolationStateList": ("schedule", "MakeInterpolationStateList"),
     "InterpolationStateList": ("schedule", "InterpolationStateList"),
 }
@@ -31,6 +32,7 @@ def __getattr__(name):
 def _node_class_mappings():
     from .film import FILM_VFI
     from .gmfss import GMFSS_Fortuna_VFI
+    from .ifunet import IFUnet_VFI
     from .ifrnet import IFRNet_VFI
     from .m2m import M2M_VFI
     from .rife import RIFE_VFI
@@ -42,6 +44,7 @@ def _node_class_mappings():
         "M2M VFI": M2M_VFI,
         "IFRNet VFI": IFRNet_VFI,
         "GMFSS Fortuna VFI": GMFSS_Fortuna_VFI,
+        "IFUnet VFI": IFUnet_VFI,
         "Make Interpolation State List": MakeInterpolationStateList,
     }
 
@@ -51,5 +54,6 @@ NODE_DISPLAY_NAME_MAPPINGS = {
     "FILM VFI": "FILM VFI (MI355X HIP)",
     "M2M VFI": "M2M VFI (MI355X HIP)",
     "IFRNet VFI": "IFRNet VFI (MI355X HIP)",
-    "GMFSS Fortuna VFI": "GMFSS Fortuna VFI (MI355X HIP; union model, first-correct path)",
+    "GMFSS Fortuna VFI": "GMFSS Fortuna VFI (MI355X HIP; first-correct path)",
+    "IFUnet VFI": "IFUnet VFI (MI355X HIP; CPU-verified, first GPU run pending)",
 }

@@ -59,10 +59,11 @@ class OpsEngine:
             self.consts[key] = make().to(self.device, torch.float32).contiguous()
         return self.consts[key]
 
-    def _layer(self, w, b=None, slopes=None, kind=0, stride=1, chan_map=None, cin_phys=None, scale_out=None):
+    def _layer(self, w, b=None, slopes=None, kind=0, stride=1, chan_map=None, cin_phys=None, scale_out=None, shift_out=None):
         """vfi_conv layer object from checkpoint tensors.  w: Conv2d [co,ci,k,k] / Linear [co,ci] / ConvTranspose2d [ci,co,4,4];
         slopes: scalar PReLU slope (replicated) or per-channel vector; scale_out: per-output-channel factor folded into the
-        weights and bias (ResConv's beta)."""
+        weights and bias (ResConv's beta; an eval-mode BatchNorm's gamma / sqrt(var + eps)); shift_out: added to the bias afterwards
+        (BatchNorm's beta - mean * scale)."""
         w = w.detach().to("cpu", torch.float32)
         if w.dim() == 2:
             w = w[:, :, None, None]
@@ -72,6 +73,8 @@ class OpsEngine:
             s = scale_out.detach().to("cpu", torch.float32).reshape(-1)
             w = w * (s.view(-1, 1, 1, 1) if kind == 0 else s.view(1, -1, 1, 1))
             b = b * s
+        if shift_out is not None:
+            b = b + shift_out.detach().to("cpu", torch.float32).reshape(-1)
         w, b = w.contiguous(), b.contiguous()
         pr = None
         if slopes is not None:
