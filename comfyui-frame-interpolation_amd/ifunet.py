@@ -16,7 +16,7 @@ import typing
 import torch
 
 from .ifunet_spec import CKPT_NAMES, ifunet_shapes
-from .opsengine import OpsEngine, _cs, _p
+from .opsengine import OpsEngine, _p
 from .schedule import InterpolationStateList, generic_output_plan
 
 MODEL_TYPE = "ifunet"

@@ -15,7 +15,6 @@ Differences that do not change results:
 """
 import ctypes as C
 import os
-import pathlib
 import typing
 import warnings
 

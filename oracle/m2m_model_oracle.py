@@ -12,7 +12,6 @@ Restated (file:line in vfi_models/m2m/M2M_arch.py): backwarp :24-92; Basic DSL (
 Network.Extractor / Decoder / bidir :415-546; forwarp_mframe_mask :551-581; conv/deconv/Conv2/ImgPyramid :589-663;
 EncDec :665-848; M2M_PWC.forward :894-1037; node loop vfi_utils.py:149-389 (generic_frame_loop, timestep mode).
 """
-import numpy as np
 import torch
 import torch.nn.functional as F
 

@@ -2,7 +2,6 @@
 host through tests/hostcheck and compared with the torch expression of the reference it replaces
 (vfi_models/gmfss_fortuna/GMFSS_Fortuna_union_arch.py; restated in oracle/gmfss_oracle.py)."""
 import ctypes as C
-import math
 
 import pytest
 import torch

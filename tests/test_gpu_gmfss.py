@@ -3,7 +3,6 @@ reference's model here, oracle/VALIDATION_GMFSS.log).  Same stage-by-stage proce
 (tests/test_gmfss_engine_cpu.py: check_against_oracle), now with the real backend: the MFMA layer kernels on GMFSS's shapes
 and the launch side of csrc/gmfss_ops.hip.  The 1e-3 gate applies to render() on the oracle's state; see the docstring of
 check_against_oracle for why end-to-end agreement with random GMFlow weights is asserted statistically."""
-import os
 
 import pytest
 import torch

@@ -1,6 +1,5 @@
 """Pin the oracle: oracle/rife_oracle.py must reproduce outputs of the REAL reference
 (tests/golden/*.npz, written by oracle/make_golden.py from /root/reference) — CPU only."""
-import json
 import os
 
 import numpy as np
