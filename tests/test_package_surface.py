@@ -1,0 +1,28 @@
+"""CPU: the custom-node package surface ComfyUI reads (reference: __init__.py:24-48): NODE_CLASS_MAPPINGS and, per node class,
+INPUT_TYPES / RETURN_TYPES / FUNCTION / CATEGORY with the reference's widget names."""
+import cfi_amd
+
+
+def test_node_class_mappings():
+    m = cfi_amd.NODE_CLASS_MAPPINGS
+    assert set(m) == {"RIFE VFI", "FILM VFI", "M2M VFI", "IFRNet VFI", "GMFSS Fortuna VFI", "IFUnet VFI", "Make Interpolation State List"}
+    assert set(cfi_amd.NODE_DISPLAY_NAME_MAPPINGS) <= set(m)
+    for name, cls in m.items():
+        it = cls.INPUT_TYPES()
+        assert "required" in it and hasattr(cls, "RETURN_TYPES") and isinstance(cls.FUNCTION, str) and hasattr(cls, cls.FUNCTION)
+        if name.endswith("VFI"):
+            req = list(it["required"])
+            assert req[:2] == ["ckpt_name", "frames"] and "multiplier" in req and cls.RETURN_TYPES == ("IMAGE",) and cls.FUNCTION == "vfi"
+            assert cls.CATEGORY == "ComfyUI-Frame-Interpolation/VFI" and "optional_interpolation_states" in it["optional"]
+
+
+def test_widget_lists_match_the_reference():
+    m = cfi_amd.NODE_CLASS_MAPPINGS
+    req = lambda n: list(m[n].INPUT_TYPES()["required"])   # noqa: E731
+    assert req("RIFE VFI") == ["ckpt_name", "frames", "clear_cache_after_n_frames", "multiplier", "fast_mode", "ensemble", "scale_factor",
+                               "dtype", "torch_compile", "batch_size"]                                  # rife/__init__.py:36-66
+    assert req("IFRNet VFI") == ["ckpt_name", "frames", "clear_cache_after_n_frames", "multiplier", "scale_factor"]      # ifrnet/__init__.py:13-25
+    assert req("IFUnet VFI") == ["ckpt_name", "frames", "clear_cache_after_n_frames", "multiplier", "scale_factor", "ensemble"]   # ifunet
+    assert req("GMFSS Fortuna VFI") == ["ckpt_name", "frames", "clear_cache_after_n_frames", "multiplier"]           # gmfss_fortuna
+    assert m["GMFSS Fortuna VFI"].INPUT_TYPES()["required"]["ckpt_name"][0] == ["GMFSS_fortuna_union", "GMFSS_fortuna"]
+    assert req("M2M VFI") == ["ckpt_name", "frames", "clear_cache_after_n_frames", "multiplier"]
