@@ -36,6 +36,53 @@ def nchw(x):
     return x.permute(0, 3, 1, 2)
 
 
+# ---- host-side contract of the MFMA convolution launcher ---------------------------------------------------------------------
+# Mirror (test infrastructure) of conv_pick_variant + the VFI_REQUIREs of launch_t / launch2_e in csrc/conv_mfma.hip and
+# csrc/conv_mfma2.hip: which tile variant a layer call gets on the MI355X and the divisibility that variant demands.  The test
+# double asserts it on every vfi_conv_forward_ex call, so a layer shape the real launcher would refuse ("Cin_p=72 not a multiple
+# of the K chunk 16" — how IFRNet's first GPU run failed) is caught on the CPU.  Keep in sync with those two files.
+_K2 = 32                                                   # kConv2Base
+_V1 = {0: (16, 64), 1: (16, 96), 2: (16, 64), 3: (16, 96), 4: (16, 32), 5: (16, 32), 6: (16, 64), 7: (16, 128), 8: (8, 64), 9: (8, 96),
+       10: (8, 32), 11: (8, 64), 12: (16, 32), 13: (16, 32)}                       # variant -> (K chunk, N tile)
+_V2 = {0: (8, 64), 1: (8, 96), 2: (8, 64), 3: (8, 96), 4: (8, 128), 5: (8, 128), 6: (16, 64), 7: (8, 64), 8: (8, 64), 9: (8, 96), 10: (8, 32),
+       11: (8, 32), 12: (8, 32), 13: (8, 32), 14: (8, 64), 15: (8, 64), 16: (8, 64), 17: (8, 64), 18: (8, 32), 19: (8, 32), 20: (8, 32), 21: (8, 64)}
+
+
+def conv_variant(grouped, taps, stride, cin_p, cout_p, px, out_mode=0, n_cus=256):
+    if not grouped and stride == 2 and taps == 4:
+        return _K2 + (21 if cout_p % 64 == 0 else 20)
+    if not grouped and stride == 1 and taps != 9:
+        big = px * (cout_p // 32) >= 256 * 4 * n_cus
+        if cout_p % 64 == 0:
+            return _K2 + ((14 if big else 15) if taps == 4 else (16 if big else 17))
+        return _K2 + (19 if taps == 4 else 18)
+    if grouped:
+        if out_mode == 1 and px >= 250000:
+            return _K2 + 11
+        return 13 if cin_p % 16 == 0 else _K2 + 11
+    n3, n2 = cout_p % 96 == 0, cout_p % 64 == 0
+    if stride == 2:
+        return _K2 + 7 if n2 else (9 if n3 else 10)
+    if n2:
+        return _K2 + (0 if cout_p == 64 else 2)
+    if n3:
+        return _K2 + 3 if (px >= 100000 or cin_p % 16) else 4
+    return 4 if (cin_p % 16 == 0 and px < 20000) else _K2 + 13
+
+
+def assert_conv_contract(L, n, hin, win, in_cs):
+    grouped = L["kind"] == 1
+    taps = 4 if grouped else L["k"] * L["k"]
+    cout_p = (L["cout"] + 31) // 32 * 32
+    hout, wout = (hin, win) if grouped else (hin // L["stride"], win // L["stride"])
+    v = conv_variant(grouped, taps, 1 if grouped else L["stride"], L["cin_phys"], cout_p, n * hout * wout, 2 if grouped else 0)
+    ck, bn = _V2[v - _K2] if v >= _K2 else _V1[v]
+    what = f"conv k={L['k']} s={L['stride']} kind={L['kind']} {L['cin_phys']}->{L['cout']} on {n}x{hin}x{win}: variant {v}"
+    assert L["cin_phys"] % ck == 0, f"{what}: Cin_p not a multiple of the K chunk {ck}"
+    assert cout_p % bn == 0, f"{what}: Cout_p={cout_p} not a multiple of the N tile {bn}"
+    assert hin * win * in_cs * 4 < 0x7FFFFFFF, f"{what}: image larger than 2 GiB"
+
+
 class EmuLib:
     def __init__(self):
         self._hc = hostcheck.load()
@@ -73,6 +120,7 @@ class EmuLib:
         L = self._layers[h]
         assert in_cs >= L["cin_phys"] and in_cs % 4 == 0 and int(in_ptr) % 16 == 0, "input window must hold Cin_phys channels, 16-byte aligned"
         assert act != 3 or L["prelu"] is not None
+        assert_conv_contract(L, n, hin, win, in_cs)
         x = nchw(view(in_ptr, n, hin, win, in_cs, L["cin_phys"])[..., L["cm"]])
         if L["kind"] == 1:
             assert not res_ptr

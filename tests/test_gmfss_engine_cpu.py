@@ -94,3 +94,17 @@ def test_constant_tables_match_oracle():
     assert torch.equal(sine_position(128, 6, 10), G._sine_position(x)[0].permute(1, 2, 0))
     assert torch.equal(shift_mask(8, 12, 2), G._shift_mask(8, 12, 4, 6))
     assert torch.equal(shift_mask(16, 16, 8), G._shift_mask(16, 16, 2, 2))
+
+
+def test_conv_contract_mirror_catches_the_ifrnet_failure():
+    """the case that failed on IFRNet's first GPU run: 3x3 s1, Cin_p=72, Cout 72 (Cout_p 96), small image -> v1 variant 4
+    (K chunk 16) before the picker fix, v2 variant 3 after it"""
+    from emu_backend import _K2, assert_conv_contract, conv_variant
+
+    assert conv_variant(False, 9, 1, 72, 96, 1000) == _K2 + 3
+    assert conv_variant(False, 9, 1, 96, 96, 1000) == 4
+    assert_conv_contract(dict(kind=0, k=3, stride=1, cin_phys=72, cout=72), 1, 16, 16, 72)
+    # the pre-fix choice (variant 4, K chunk 16) is what the contract refuses:
+    from emu_backend import _V1
+
+    assert 72 % _V1[4][0] != 0
