@@ -55,5 +55,5 @@ NODE_DISPLAY_NAME_MAPPINGS = {
     "M2M VFI": "M2M VFI (MI355X HIP)",
     "IFRNet VFI": "IFRNet VFI (MI355X HIP)",
     "GMFSS Fortuna VFI": "GMFSS Fortuna VFI (MI355X HIP; first-correct path)",
-    "IFUnet VFI": "IFUnet VFI (MI355X HIP; CPU-verified, first GPU run pending)",
+    "IFUnet VFI": "IFUnet VFI (MI355X HIP)",
 }

@@ -204,7 +204,7 @@ def copy_rows_async(out, rows, frames, idx, workers=WORKERS[2]):
 # A fresh torch.empty() of N_out x 24.9 MB is untouched anonymous memory: every 4 KiB written for the first time is a
 # page fault (measured 2.9 GB/s per thread on the GPU box = 8.5 ms per 1080p frame, 4x the device time).  The output
 # is therefore populated up front by a few threads with madvise(MADV_HUGEPAGE) + madvise(MADV_POPULATE_WRITE)
-# (Linux >= 5.14; falls back to a memset), overlapping the uploads and the first batches.
+# (Linux >= 5.14; skipped on older kernels), overlapping the uploads and the first batches.
 _MADV_HUGEPAGE, _MADV_POPULATE_WRITE = 14, 23
 _libc = None
 
@@ -219,11 +219,20 @@ def _madvise(addr, nbytes, advice):
     return (a, n, _libc.madvise(a, n, advice)) if n > 0 else (a, 0, 0)
 
 
+_populate_ok = True
+
+
 def _populate(addr, nbytes):
+    """Runs concurrently with the writers of the same tensor, so it must never modify contents: MADV_POPULATE_WRITE
+    faults pages in without touching data.  Where the kernel lacks it (< 5.14: EINVAL) the prefault is simply skipped
+    — the writers then take the first-touch faults themselves (slower, never wrong)."""
+    global _populate_ok
+    if not _populate_ok:
+        return
     with _T("prefault"):
         a, n, rc = _madvise(addr, nbytes, _MADV_POPULATE_WRITE)
-        if n > 0 and rc != 0:      # old kernel: touch the pages the slow way
-            ctypes.memset(a, 0, n)
+        if n > 0 and rc != 0:
+            _populate_ok = False
 
 
 def prefault_async(t, chunk=16 << 20, workers=None):

@@ -369,15 +369,17 @@ def run_plan(engine, frames, plan, tasks, name="M2M VFI"):
                 if f not in held:
                     held[f] = up.get(item_of[f])
             engine.prepare(held[pair], held[pair + 1])
-            while released < item_of[pair + 1]:       # frames before pair+1 are never needed again (tasks ascend)
-                up.release(released)
-                held.pop(order[released], None)
-                released += 1
             for t in ts:
                 engine.render(t, local[pos])
                 if ws == 1:
                     wr.put_dev(new_row[first_new + pos], local[pos])
                 pos += 1
+            # Release only after the LAST render of the pair: some engines' prepare() keeps references to the ring-slot
+            # tensors and render() re-reads them (IFRNet, IFUNet), so the `consumed` event must follow those reads.
+            while released < item_of[pair + 1]:       # frames before pair+1 are never needed again (tasks ascend)
+                up.release(released)
+                held.pop(order[released], None)
+                released += 1
         if ws > 1:
             new = all_gather_frames(local, counts)
             for k in range(new.shape[0]):

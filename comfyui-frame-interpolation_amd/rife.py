@@ -312,16 +312,17 @@ class RIFE_VFI:
         if dtype not in DTYPE_OPTIONS:
             raise KeyError(dtype)
         if dtype != "float32":
-            # The reference casts model, inputs and the returned IMAGE tensor to the widget's dtype
-            # (rife/__init__.py:120-134,195-198,210,227-230).  Here the hot path always computes in fp32: the clip is
-            # rounded to the requested dtype on the way in (so pass-through frames are bit-identical to the
-            # reference's) and the result is returned in that dtype; new frames are the fp32 result, rounded once.
+            # The reference casts model and inputs to the widget's dtype, rounds every output frame through it
+            # (rife/__init__.py:120-134,195-198,210,227-230) and ALWAYS returns float32 (:237-238).  Here the hot path
+            # computes in fp32: the clip is rounded to the requested dtype on the way in (so pass-through frames are
+            # bit-identical to the reference's), new frames are the fp32 result rounded once through that dtype, and
+            # the IMAGE tensor comes back as float32 like the reference's.
             torch_dtype = DTYPE_MAP[dtype]
             warnings.warn(f"RIFE VFI (HIP): dtype={dtype}: I/O in {dtype}, compute in float32.")
             (out,) = self.vfi(ckpt_name, frames.to(torch_dtype).to(torch.float32), clear_cache_after_n_frames, multiplier,
                               fast_mode, ensemble, scale_factor, "float32", torch_compile, batch_size,
                               optional_interpolation_states, **kwargs)
-            return (out.to(torch_dtype),)
+            return (out.to(torch_dtype).to(torch.float32),)
         arch_ver = CKPT_NAME_VER_DICT[ckpt_name]
         cache_key = (ckpt_name,)
         if cache_key not in _model_cache:

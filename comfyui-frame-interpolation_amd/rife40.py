@@ -274,7 +274,7 @@ def run_tasks40(engine, frames, tasks, batch_size, scale_list, fast_mode, ensemb
     bs = max(1, int(batch_size))
     order = sorted({f for p, _ in tasks for f in (p, p + 1)})
     item_of = {f: k for k, f in enumerate(order)}
-    up = Uploader(frames, order, dev, torch.cuda.current_stream(dev), depth=min(len(order), bs + 4) or 1)
+    up = Uploader(frames, order, dev, torch.cuda.current_stream(dev), depth=min(len(order), 2 * bs + 2) or 1)   # a batch over disjoint pairs holds 2*bs frames at once
     held, released = {}, 0
     keep = []
     try:

@@ -1,9 +1,11 @@
 /* ORACLE — test infrastructure only.  Never linked into or called by the product path.
  *
  * Plain-C restatement of the two custom CUDA ops on M2M's hot path, following the CUDA kernel TEXT of the
- * reference (the reference has no CPU implementation of either op; its Taichi backend is broken at import,
- * SURVEY.md App. C4 — so parity for these ops is UNPINNED by the reference's own tests and by execution:
- * the semantics of record are the kernel strings cited below).
+ * reference.  PINNED BY EXECUTION of that text: oracle/validate_m2m_vs_reference.py lets the reference's own
+ * cuda_kernel() specialise its kernel strings, compiles them with g++ behind a serial __global__/atomicAdd shim
+ * (oracle/stubs/cupy) and requires bit-equality with the functions below on edge-case inputs (oracle/VALIDATION_M2M.log;
+ * outputs kept as tests/golden/m2m_ops_ref.npz; prebuilt kernels under oracle/_ref for the GPU box).  On a GPU the
+ * reference's atomics commit in an unspecified order; both sides here use the thread-index order.
  *
  *   softsplat_out  vfi_models/ops/cupy_ops/softsplat.py:140-192   (launch :205-224, zero-init :201-203)
  *   costvol_out    vfi_models/ops/cupy_ops/costvol.py:4-43         (launch :143-179)

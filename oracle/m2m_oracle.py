@@ -1,8 +1,8 @@
 """ORACLE — test infrastructure only: ctypes wrapper of oracle/m2m_ops.c (softsplat sum, 9x9 cost volume).
 
-Parity status: UNPINNED (the reference has neither a CPU path nor tests for these ops; the C code restates
-vfi_models/ops/cupy_ops/softsplat.py:140-192 and costvol.py:4-43 line by line).  The only executable
-cross-check available here is against independent torch formulations (tests/test_oracle_m2m_ops.py)."""
+Parity status: PINNED BY EXECUTION of the reference's kernel text (oracle/validate_m2m_vs_reference.py: the reference's own
+cupy_ops package on a host shim, bit-exact; oracle/VALIDATION_M2M.log, tests/golden/m2m_ops_ref.npz, oracle/_ref).  The C
+code restates vfi_models/ops/cupy_ops/softsplat.py:140-192 and costvol.py:4-43 line by line."""
 import ctypes as C
 import os
 import subprocess

@@ -54,7 +54,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "film_net.npz"), frames=fr.numpy(), out=out.permute(0, 2, 3, 1).contiguous().numpy())
 
     # ---- M2M model
-    ma = load_m2m_arch()
+    ma, _ops = load_m2m_arch()          # the reference's M2M_arch on the reference's own (host-compiled) cupy_ops
     sd = synth.m2m_synth_state_dict(1234)
     net = ma.M2M_PWC()
     net.load_state_dict(sd, strict=True)

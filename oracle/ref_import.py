@@ -51,3 +51,22 @@ def vfi_utils():
     import vfi_utils as m
 
     return m
+
+
+def reference_ops():
+    """The reference's OWN ``vfi_models.ops`` (config.yaml: ops_backend "cupy" -> vfi_models/ops/cupy_ops) running on the
+    host: oracle/stubs/cupy compiles the kernel text the reference's ``cuda_kernel`` specialises (cupy_ops/utils.py:29-213)
+    with g++ behind a serial shim.  The op wrappers insist on CUDA tensors (softsplat.py:205,226: ``assert False`` for
+    CPU tensors), so for the life of this process host tensors report ``is_cuda`` and the two torch.cuda calls on the
+    launch path (utils.py:31 get_device_name, softsplat.py:221 current_stream) are answered by constants."""
+    import collections
+
+    import torch
+
+    setup()
+    torch.Tensor.is_cuda = property(lambda self: True)
+    torch.cuda.get_device_name = lambda *a, **k: "host-shim"
+    torch.cuda.current_stream = lambda *a, **k: collections.namedtuple("S", "cuda_stream")(0)
+    import vfi_models.ops as ops
+
+    return ops

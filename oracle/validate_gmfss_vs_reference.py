@@ -1,12 +1,12 @@
 """ORACLE tooling — pin oracle/gmfss_oracle.py against the reference's own GMFSS Fortuna (union) modules and the
 GMFSS_Fortuna_VFI node, here, on CPU, with seeded synthetic checkpoints; write tests/golden/gmfss_union.npz (outputs of
-the REFERENCE).  The reference imports ``vfi_models.ops.softsplat`` (CuPy / Taichi, neither usable here): a stand-in
-module provides ``softsplat`` with the reference's own wrapper semantics around the plain-C restatement of the CUDA
-kernel text (oracle/m2m_ops.c) — so this pins everything EXCEPT the summation splat itself, exactly as for M2M.
+the REFERENCE).  The reference imports ``vfi_models.ops.softsplat``: it is the reference's own CuPy op package running on the host
+(oracle/stubs/cupy compiles the kernel text the reference specialises with g++ behind a serial shim, see
+oracle/ref_import.reference_ops), so the reference side runs its own splat kernel and wrapper; the oracle side runs
+oracle/m2m_ops.c.
 Bit-exact agreement is required.  Writes oracle/VALIDATION_GMFSS.log."""
 import os
 import sys
-import types
 
 import numpy as np
 import torch
@@ -17,23 +17,9 @@ from pkgload import load_package  # noqa: E402
 
 load_package()
 from cfi_amd import gmfss_spec, synth  # noqa: E402
-from oracle import gmfss_oracle as G, m2m_oracle, ref_import  # noqa: E402
+from oracle import gmfss_oracle as G, ref_import  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
-
-
-def install_ops_stub():
-    ops = types.ModuleType("vfi_models.ops")
-
-    def softsplat(tenIn, tenFlow, tenMetric, strMode):
-        """the reference wrapper (cupy_ops/softsplat.py:382-435), "soft" mode, around the C splat"""
-        assert strMode == "soft" and tenMetric is not None
-        x = torch.cat([tenIn * tenMetric.exp(), tenMetric.exp()], 1)
-        out = torch.from_numpy(m2m_oracle.softsplat_sum(x.detach().contiguous().numpy(), tenFlow.detach().contiguous().numpy()))
-        return out[:, :-1, :, :] / (out[:, -1:, :, :] + 0.0000001)
-
-    ops.softsplat = softsplat
-    sys.modules["vfi_models.ops"] = ops
 
 
 def main():
@@ -43,8 +29,7 @@ def main():
         print(s, flush=True)
         lines.append(s)
 
-    ref_import.setup()
-    install_ops_stub()
+    ref_import.reference_ops()     # the reference's own vfi_models.ops (cupy_ops) on the host shim, oracle/stubs/cupy
     import vfi_models.gmfss_fortuna as N
     from vfi_models.gmfss_fortuna import GMFSS_Fortuna_union_arch as A
 
@@ -139,7 +124,7 @@ def main():
             ok &= d == 0.0
             if (h, w) == (100, 150):
                 golden["base_out"] = r.permute(0, 2, 3, 1).contiguous().numpy()
-    log("RESULT: " + ("oracle == reference, bit-exact on every case (summation splat via the C restatement on both sides)" if ok
+    log("RESULT: " + ("oracle == reference, bit-exact on every case (the reference side ran its own softsplat kernel text, host-compiled; the oracle side oracle/m2m_ops.c)" if ok
                       else "MISMATCH"))
     np.savez_compressed(os.path.join(OUT, "gmfss_union.npz"), **golden)
     log(f"wrote tests/golden/gmfss_union.npz ({os.path.getsize(os.path.join(OUT, 'gmfss_union.npz')) / 1e6:.2f} MB)")

@@ -198,3 +198,36 @@ def test_node_against_reference_golden(hip_lib, golden_dir, tmp_path, monkeypatc
     assert torch.equal(frames, before), "input tensor was mutated"
     assert out.dtype == torch.float32 and out.device.type == "cpu" and out.shape == want.shape
     assert (out - want).abs().max().item() <= TOL, describe_diff(out, want, f"IFRNet_{kind} node {name}")
+
+
+@pytest.mark.parametrize("kind", ["L", "S"])
+def test_node_long_clip_keeps_frames_until_the_last_render(hip_lib, tmp_path, monkeypatch, kind):
+    """9 frames x4: more frames than the upload ring has slots (4) and three renders per pair.  IFRNetEngine.prepare() only
+    keeps references to the ring-slot tensors, so a slot released before the pair's last render would be overwritten by a
+    later frame.  Every new frame must equal the engine run on that pair alone."""
+    import cfi_amd.ifrnet as I
+    from cfi_amd import ckpt
+    from cfi_amd.ifrnet import IFRNetEngine
+
+    sd = synth.ifrnet_synth_state_dict(kind, 1234)
+    pth = tmp_path / f"IFRNet_{kind}_Vimeo90K.pth"
+    torch.save(sd, pth)
+    monkeypatch.setattr(I, "load_file_from_github_release", lambda model_type, ckpt_name: str(pth))
+    frames = torch.cat([synth.smooth_frames(3, 128, 192, seed=s, shift=3.0) for s in (1, 2, 3)])     # 9 distinct frames
+    try:
+        (out,) = I.IFRNet_VFI().vfi(pth.name, frames, clear_cache_after_n_frames=10, multiplier=4)
+    finally:
+        ckpt.clear_engine_cache()
+    assert out.shape == (33, 128, 192, 3)
+    e = IFRNetEngine(sd, kind)
+    tmp = torch.empty(1, 128, 192, 3, device="cuda")
+    for pair in range(8):
+        a, b = frames[pair].cuda().contiguous(), frames[pair + 1].cuda().contiguous()
+        for k in (1, 2, 3):
+            if (128 * k) % 64 or (192 * k) % 64:      # working resolution k/4 must be a multiple of 16
+                continue
+            e.forward([a], [b], k / 4, 1.0, tmp)
+            want, got = tmp[0].cpu(), out[4 * pair + k]
+            assert (got - want).abs().max().item() <= 1e-6, describe_diff(got, want, f"IFRNet_{kind} pair {pair} k {k}")
+        assert torch.equal(out[4 * pair], frames[pair])
+    e.close()
