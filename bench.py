@@ -16,7 +16,13 @@ Rank 0 prints ONE JSON line.  Extra objects:
                  per launch / average launch duration measured with HIP events on the launch stream
                  (library-side tracing, second pass of the same K steps); peak = 157.3 TFLOP/s.
   cpu_baseline — the oracle (torch-CPU restatement, bit-exact vs the reference in the build container)
-                 timed on this host's cores on a bounded sample (N=1, rank 0 only).
+                 timed on this host's cores on a bounded sample (N=1, rank 0 only); host CPU model and core count stated.
+  e2e          — SURVEY 8(d) config 2, PCIe-inclusive (never `value`): a host clip [33,1080,1920,3] fp32
+                 (torch.manual_seed(0); torch.rand) through the node class RIFE_VFI.vfi to a host tensor, wall clock from the
+                 call to the returned tensor (first H2D ... last D2H + host assembly), warm, median of 3; plus the measured
+                 pinned H2D / D2H rates of this box.
+  other_paths  — device-resident ms per interpolated 1080p frame of FILM (configs[2]) and M2M (configs[4]), same box, same
+                 process (not the headline metric).
 """
 import argparse
 import json
@@ -32,9 +38,121 @@ import torch  # noqa: E402
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip table
 
 
+def host_cpu_model():
+    try:
+        import subprocess
+
+        for line in subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout.splitlines():
+            if line.startswith("Model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def pcie_rates(dev, nbytes=256 << 20):
+    """Pinned H2D / D2H GB/s of this box (one 256 MiB copy each way after a warm-up, HIP events)."""
+    h = torch.empty(nbytes // 4, dtype=torch.float32, pin_memory=True)
+    d = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    out = {}
+    for name, (dst, src) in {"h2d": (d, h), "d2h": (h, d)}.items():
+        dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        dst.copy_(src, non_blocking=True)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        out[name] = round(nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9, 2)
+    return out
+
+
+def e2e_leg(sd, dev, H, W, n_frames=33, reps=3):
+    """SURVEY 8(d) config 2 through the drop-in node: host clip in, host tensor out, wall clock."""
+    import tempfile
+
+    import cfi_amd.rife as R
+
+    torch.manual_seed(0)
+    frames = torch.rand(n_frames, H, W, 3)          # i.i.d. U[0,1): SURVEY's worst-case-gradient clip
+    with tempfile.TemporaryDirectory() as td:
+        pth = os.path.join(td, "rife47.pth")
+        torch.save(sd, pth)
+        saved = R.load_file_from_github_release
+        R.load_file_from_github_release = lambda model_type, ckpt: pth
+        try:
+            node = R.RIFE_VFI()
+            times = []
+            for i in range(reps + 1):               # the first call is the warm-up (checkpoint load, workspace, pinned rings)
+                t0 = time.perf_counter()
+                res = node.vfi("rife47.pth", frames, multiplier=2, batch_size=16)
+                dt = time.perf_counter() - t0
+                n_out = res[0].shape[0]
+                del res                             # release of the 1.6 GB result happens outside the timed region
+                if i > 0:
+                    times.append(dt)
+        finally:
+            R.load_file_from_github_release = saved
+            for e in R._model_cache.values():
+                e.close()
+            R._model_cache.clear()
+    med = sorted(times)[len(times) // 2]
+    new = n_frames - 1
+    rates = pcie_rates(dev)
+    return {
+        "workload": f"RIFE_VFI.vfi('rife47.pth', frames[{n_frames},{H},{W},3] fp32 host, torch.manual_seed(0) torch.rand, multiplier=2) -> host "
+                    f"tensor [{n_out},{H},{W},3]; wall clock of the call, warm, median of {reps}",
+        "value": round(new / med, 2),
+        "unit": "interpolated frames/s (PCIe-inclusive, host tensor to host tensor)",
+        "seconds": [round(t, 4) for t in times],
+        "h2d_bytes": n_frames * H * W * 3 * 4,
+        "d2h_bytes": new * H * W * 3 * 4,
+        "pcie_pinned_GBps": rates,
+    }
+
+
+def other_paths(dev, H, W):
+    """FILM and M2M, device-resident, ms per interpolated frame (BASELINE.json configs[2] / configs[4])."""
+    from cfi_amd import synth
+    from cfi_amd.film import FilmEngine
+    from cfi_amd.m2m import M2MEngine
+
+    fr = synth.smooth_frames(2, H, W, seed=2, shift=4.0)
+    x0, x1 = fr[0].to(dev).contiguous(), fr[1].to(dev).contiguous()
+
+    def timed(fn, n):
+        fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / n
+
+    out = {}
+    eng = FilmEngine(synth.film_synth_state_dict(1234))
+    t = timed(lambda: eng.forward(x0, x1), 3)
+    out["film_2x"] = {"ms_per_frame": round(t * 1e3, 2), "frames_per_s": round(1 / t, 2),
+                      "tflops": round(8823.8 * (H * W) / (1080 * 1920) / t / 1e3, 1), "flop_per_frame": "8.82 TFLOP @1080p (SURVEY 8d)"}
+    eng.close()
+    eng = M2MEngine(synth.m2m_synth_state_dict(1234))
+    tp = timed(lambda: eng.prepare(x0, x1), 5)
+    tr = timed(lambda: eng.render(0.5), 10)
+    out["m2m"] = {"prepare_ms_per_pair": round(tp * 1e3, 3), "render_ms_per_frame": round(tr * 1e3, 3),
+                  "frames_per_s_2x": round(1 / (tp + tr), 1), "frames_per_s_8x": round(7 / (tp + 7 * tr), 1)}
+    eng.close()
+    return out
+
+
 def cpu_baseline(sd, H, W, budget_s=25.0):
     """Oracle on the host cores, bounded sample: for a few thread counts (all cores is often NOT the fastest
-    on a many-core host), 1 warm-up + 2 timed 1080p forwards each; report the best median."""
+    on a many-core host), 1 warm-up + 3 timed 1080p forwards each; report the best median."""
     from cfi_amd import synth
     from oracle import rife_oracle
 
@@ -52,7 +170,7 @@ def cpu_baseline(sd, H, W, budget_s=25.0):
                 break
             torch.set_num_threads(nt)
             times = []
-            for i in range(3):
+            for i in range(4):
                 t0 = time.time()
                 rife_oracle.ifnet47_forward(sd, x[0:1], x[1:2], ts)
                 if i > 0:
@@ -66,9 +184,11 @@ def cpu_baseline(sd, H, W, budget_s=25.0):
         "value": round(1.0 / best[1], 4),
         "unit": "interpolated frames/s",
         "cores": best[0],
+        "host_cpu": host_cpu_model(),
+        "host_logical_cpus": os.cpu_count(),
         "kind": "port",
         "sample": f"oracle.rife_oracle.ifnet47_forward (torch-CPU fp32 restatement, bit-exact vs the reference's IFNet('4.7') "
-                  f"in the build container), 1 pair {H}x{W}; per thread count 1 warm-up + 2 timed forwards, "
+                  f"in the build container), 1 pair {H}x{W}; per thread count 1 warm-up + 3 timed forwards (median), "
                   f"(threads, median s/frame) tried: {tried}; best reported",
     }
 
@@ -82,6 +202,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive node leg")
+    ap.add_argument("--no-extras", action="store_true", help="skip the FILM / M2M device-resident numbers")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather of new frames")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) | gloo (plumbing test on one GPU)")
     args = ap.parse_args()
@@ -122,10 +244,12 @@ def main():
     n_slots = B + 1
     eng.configure(H, W, B, max(n_slots, 2), 1.0)
 
-    # synthetic stream, resident in HBM before timing: B+1 distinct raw frames [H,W,3] fp32
-    base = synth.smooth_frames(3, H, W, seed=100 + rank, shift=4.0).to(dev)
-    noise = torch.rand((B + 1, 1, 1, 3), device=dev) * 0.05
-    raw = (base[torch.arange(B + 1) % 3] * 0.95 + noise).contiguous()
+    # synthetic stream, resident in HBM before timing: SURVEY 8(d) config 2's clip — 2B+1 frames (33 at the default batch),
+    # torch.manual_seed(0) torch.rand i.i.d. U[0,1) (seed + rank for N>1) — walked B pairs per step: step i interpolates pairs
+    # (b, b+1) for b in [B*(i&1), B*(i&1) + B)
+    n_clip = 2 * B + 1
+    g = torch.Generator(device="cpu").manual_seed(rank)
+    raw = torch.rand((n_clip, H, W, 3), generator=g, dtype=torch.float32).to(dev)
     outs = [torch.empty((B, H, W, 3), dtype=torch.float32, device=dev) for _ in range(2)]
     gathered = [torch.empty((world * B, H, W, 3), dtype=torch.float32, device=dev) for _ in range(2)] \
         if world > 1 and not args.no_gather and args.backend == "nccl" else None
@@ -133,17 +257,17 @@ def main():
     slot0 = list(range(B))
     slot1 = list(range(1, B + 1))
     ts = [0.5] * B
-    eng.load_frame(0, raw[0])
 
     def step(i):
         k = i & 1
         if pending[k] is not None:
             pending[k].wait()  # the buffer's previous all-gather must be done before it is overwritten
             pending[k] = None
-        # frame 0 of this step's stream is the last frame of the previous step in a real clip; here the
-        # slot contents are re-used and B NEW frames are prepared + encoded per step.
-        for j in range(1, B + 1):
-            eng.load_frame(j, raw[j])
+        # Every frame of the step is prepared + encoded inside the timed region: B + 1 frames for B pairs (in a real clip the
+        # first one would be the previous step's last and already resident: one frame more work than the node does).
+        base = B * k
+        for j in range(B + 1):
+            eng.load_frame(j, raw[base + j])
         eng.interpolate(slot0, slot1, ts, outs[k])
         if world > 1 and not args.no_gather:
             if gathered is not None:
@@ -227,7 +351,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"RIFE 4.7 2x, {H}x{W} synthetic frame-pair stream, {B} pairs/step/GPU resident in HBM "
-                            f"(BASELINE.json configs[1]); seeded random-init weights",
+                            f"(BASELINE.json configs[1]; SURVEY 8d config 2 clip: {2 * B + 1} frames torch.manual_seed(0) torch.rand); "
+                            f"seeded random-init weights",
                 "pairs_per_step_per_gpu": B,
                 "per_gpu_frames_per_s": round(B * K / elapsed, 3),
                 "new_frame_collective": "none" if world == 1 or args.no_gather else
@@ -250,8 +375,14 @@ def main():
             "conv_tflops_whole_net": round(conv_flop * B * K / elapsed / 1e12, 3),
             "kernels": kernels,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(sd, H, W)
+        if world == 1:
+            eng.close()
+            if not args.no_e2e:
+                res["e2e"] = e2e_leg(sd, dev, H, W)
+            if not args.no_extras:
+                res["other_paths"] = other_paths(dev, H, W)
+            if not args.no_cpu_baseline:
+                res["cpu_baseline"] = cpu_baseline(sd, H, W)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

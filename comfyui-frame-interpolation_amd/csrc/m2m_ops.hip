@@ -30,20 +30,6 @@ constexpr int SPLAT_T = 32;
 constexpr int SPLAT_RCAP = 64;
 constexpr int SPLAT_CMAX = 8;   // channels per pass (LDS tile 32x32x8 floats = 32 KiB)
 
-__global__ void flow_absmax_kernel(const float* __restrict__ flow, long n2, unsigned* __restrict__ out_bits) {
-    float m = 0.f;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long)gridDim.x * blockDim.x) {
-        const float v = fabsf(flow[i]);
-        if (isfinite(v)) m = fmaxf(m, v);
-    }
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    __shared__ float wm[4];
-    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0)  // one device-scope atomic per workgroup; non-negative floats order as uints
-        atomicMax(out_bits, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
-}
-
 __device__ static inline void splat_weights(float fx, float fy, int& x0, int& y0, float (&w)[4]) {
     x0 = (int)floorf(fx);
     y0 = (int)floorf(fy);
@@ -54,6 +40,50 @@ __device__ static inline void splat_weights(float fx, float fy, int& x0, int& y0
     w[3] = __fmul_rn(__fsub_rn(fx, (float)x0), __fsub_rn(fy, (float)y0));   // south-east
 }
 
+// Source window of a tile: the bounding box of the sources that can reach it, from the per-32x32-block flow RANGES of
+// flow_blockrange_kernel ([fx_min, fx_max, fy_min, fy_max] over the block's near, finite sources) — a source s reaches the
+// tile iff floor(s + f) lies in [X0-1, X0+31] x [Y0-1, Y0+31], so block b contributes its pixels inside
+// (tile - [f_min, f_max]); blocks further than two away cannot reach it (|f| <= 63).  For a smooth field this is the tile
+// shifted against the flow, about 34 x 34 whatever the flow magnitude; for an incoherent field the tile dilated by max|f|.
+// Call with all 256 threads; rq = 4 x 32 ints of LDS.  The window is at most 160 x 160.
+struct SplatWin {
+    int x0, x1, y0, y1;   // [x0, x1) x [y0, y1), empty when x1 <= x0
+};
+__device__ static inline SplatWin tile_window(const float4* __restrict__ brange, int n, int ty, int tx, int tiles_x, int tiles_y,
+                                              int H, int W, int* rq) {
+    const int tid = threadIdx.x;
+    if (tid < 32) {
+        int wx0 = 1 << 30, wx1 = -(1 << 30), wy0 = 1 << 30, wy1 = -(1 << 30);
+        if (tid < 25) {
+            const int dy = tid / 5 - 2, dx = tid % 5 - 2;
+            const int by = ty + dy, bx = tx + dx;
+            if (by >= 0 && by < tiles_y && bx >= 0 && bx < tiles_x) {
+                const float4 r = brange[(n * tiles_y + by) * tiles_x + bx];
+                if (r.x <= r.y && r.z <= r.w) {
+                    const int X0 = tx * 32, Y0 = ty * 32;
+                    const int lx = max((int)floorf((float)(X0 - 1) - r.y) - 1, bx * 32);
+                    const int hx = min((int)ceilf((float)(X0 + 32) - r.x) + 1, min(bx * 32 + 32, W));
+                    const int ly = max((int)floorf((float)(Y0 - 1) - r.w) - 1, by * 32);
+                    const int hy = min((int)ceilf((float)(Y0 + 32) - r.z) + 1, min(by * 32 + 32, H));
+                    if (lx < hx && ly < hy) wx0 = lx, wx1 = hx, wy0 = ly, wy1 = hy;
+                }
+            }
+        }
+        rq[tid] = wx0, rq[32 + tid] = wx1, rq[64 + tid] = wy0, rq[96 + tid] = wy1;
+    }
+    __syncthreads();
+    SplatWin w = {1 << 30, -(1 << 30), 1 << 30, -(1 << 30)};
+#pragma unroll
+    for (int i = 0; i < 25; ++i) {
+        w.x0 = min(w.x0, rq[i]);
+        w.x1 = max(w.x1, rq[32 + i]);
+        w.y0 = min(w.y0, rq[64 + i]);
+        w.y1 = max(w.y1, rq[96 + i]);
+    }
+    if (w.x1 <= w.x0 || w.y1 <= w.y0) w = SplatWin{0, 0, 0, 0};
+    return w;
+}
+
 // LDS accumulator layout is planar, acc[c][pixel] (64 consecutive targets = 64 different banks per ds_add_f32); NCT > 0
 // fixes the channel count at compile time (M2M: 4, one float4 load per source).  Measured against the interleaved
 // [pixel][c] layout: no change (179 vs 180 us per [1,1088,1920,4] splat, profiles/r01b_splat_bench_v3.txt) — the kernel is
@@ -61,8 +91,10 @@ __device__ static inline void splat_weights(float fx, float fy, int& x0, int& y0
 // flow magnitude (sigma 0 ... 8 px), of bank conflicts and of the window size.
 template <int NCT>
 __global__ __launch_bounds__(256) void softsplat_tile_kernel(const float* __restrict__ in, const float* __restrict__ flow,
-                                                             float* __restrict__ out, const unsigned* __restrict__ absmax_bits,
+                                                             float* __restrict__ out, const float4* __restrict__ brange,
+                                                             const unsigned* __restrict__ run_if_above, unsigned threshold,
                                                              int H, int W, int C, int c0, int nc_rt, int tiles_x, int tiles_y) {
+    if (run_if_above && !(*run_if_above > threshold)) return;     // fallback of the list kernel: only when its spill list overflowed
     constexpr int PLANE = SPLAT_T * SPLAT_T;
     const int nc = NCT > 0 ? NCT : nc_rt;
     __shared__ float acc[PLANE * (NCT > 0 ? NCT : SPLAT_CMAX)];
@@ -72,14 +104,11 @@ __global__ __launch_bounds__(256) void softsplat_tile_kernel(const float* __rest
     const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
     const int X0 = tx * SPLAT_T, Y0 = ty * SPLAT_T;
     for (int i = tid; i < SPLAT_T * SPLAT_T * nc; i += 256) acc[i] = 0.f;
-    __syncthreads();
-    const float amax = __uint_as_float(*absmax_bits);
-    int R = (int)ceilf(amax) + 1;
-    if (R > SPLAT_RCAP) R = SPLAT_RCAP;
+    __shared__ int rq[128];
+    const SplatWin win = tile_window(brange, n, ty, tx, tiles_x, tiles_y, H, W, rq);     // (its barrier also covers the zeroing above)
     const float cap = (float)(SPLAT_RCAP - 1);
-    const int wx0 = max(X0 - R, 0), wx1 = min(X0 + SPLAT_T + R, W);
-    const int wy0 = max(Y0 - R, 0), wy1 = min(Y0 + SPLAT_T + R, H);
-    const int ww = wx1 - wx0, wh = wy1 - wy0;
+    const int wx0 = win.x0, wy0 = win.y0;
+    const int ww = win.x1 - win.x0, wh = win.y1 - win.y0;
     const size_t nbase = (size_t)n * H * W;
     // window scan, 4 source pixels per thread and iteration so that 4 flow loads are in flight together
     constexpr int U = 4;
@@ -166,55 +195,332 @@ __global__ __launch_bounds__(256) void softsplat_tile_kernel(const float* __rest
     }
 }
 
-// second pass: sources displaced by more than the cap (rare) -> device-scope atomics, as the CUDA original
-__global__ void softsplat_far_kernel(const float* __restrict__ in, const float* __restrict__ flow, float* __restrict__ out,
-                                     const unsigned* __restrict__ absmax_bits, int N, int H, int W, int C) {
-    if (__uint_as_float(*absmax_bits) <= (float)(SPLAT_RCAP - 1)) return;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)N * H * W) return;
-    const int x = idx % W, y = (idx / W) % H;
-    const long nbase = idx - ((long)y * W + x);
-    const float2 f = ((const float2*)flow)[idx];
-    const float fx = (float)x + f.x, fy = (float)y + f.y;
-    if (!isfinite(fx) || !isfinite(fy)) return;
-    if (!(fmaxf(fabsf(f.x), fabsf(f.y)) > (float)(SPLAT_RCAP - 1))) return;
-    int x0, y0;
-    float w[4];
-    splat_weights(fx, fy, x0, y0, w);
-    const float* ip = in + idx * C;
+// ---- the list splat: owner-computes GATHER, no floating-point atomics ---------------------------------------------------------
+// The tile kernel above is bound by the ds_add_f32 issue rate (16 per source, 8 with the DPP hand-off; 0.34 lanes per clock per
+// CU, profiles/r01b_splat_bench_v4.txt: 180-240 us per [1,1088,1920,4] splat = 5 % of the HBM roofline).  A splat needs no
+// floating-point atomic at all if every OUTPUT pixel knows which sources reach it.  So each workgroup (still the owner of a
+// 32x32 output tile) first files every source of its window under the tile cell its north-west target falls into — ONE
+// integer ds_add_rtn_u32 per source and a 2-byte list entry (the source's window coordinates) — and then every output pixel
+// gathers: it walks the lists of the four cells (p, p-1 in x and y) whose 2x2 footprints cover it, recomputes the reference's
+// bilinear weights from the flow (cached loads) and accumulates in registers, in a fixed order (lists sorted by source raster
+// position; south-east, south-west, north-east, north-west contribution — for a uniform translation exactly the ascending-source
+// order of the sequential oracle, bit-identical; always bit-identical run to run).  One coalesced float4 store per pixel.  Any
+// channel count walks the same lists.
+//   * window: per-tile bounding box of the sources that can reach it, from a 32x32-block table of flow ranges (pre-pass);
+//   * a cell holding more than SPLAT_K sources (strongly convergent flow) spills the excess to a global overflow list that a
+//     small second kernel adds with global atomics; if that list overflows too (pathological fields), the whole launch is
+//     redone by the LDS-atomic tile kernel above — always correct, never silently truncated;
+//   * sources displaced by more than SPLAT_RCAP-1 px go to the far pass, as before.
+constexpr int SPLAT_K = 8;
+constexpr int SPLAT_CW = SPLAT_T + 1;                 // cells per row: north-west targets lx in [-1, 31]
+constexpr int SPLAT_CELLS = SPLAT_CW * SPLAT_CW;
+constexpr unsigned SPLAT_OVF_CAP = 1u << 20;          // entries of the global overflow list (8 MiB); VFI_SPLAT_SPILL_CAP lowers it (tests)
+
+struct SplatCtl {            // device-side control words, zeroed per call
+    unsigned absmax_bits;    // max |flow| over the launch, only maintained above the cap (far pass switch)
+    unsigned ovf_count;      // overflow entries appended (may exceed SPLAT_OVF_CAP: then the fallback runs)
+};
+
+// pre-pass: brange[n][ty][tx] = [fx_min, fx_max, fy_min, fy_max] over the block's near (|f|inf <= cap), finite sources
+// (non-finite flows never splat; far ones go to the far pass); an empty block gets an inverted range
+__global__ __launch_bounds__(256) void flow_blockrange_kernel(const float* __restrict__ flow, int H, int W, int tiles_x,
+                                                              int tiles_y, float4* __restrict__ brange, SplatCtl* __restrict__ ctl) {
+    const int tid = threadIdx.x;
+    const int n = blockIdx.x / (tiles_x * tiles_y);
+    const int trem = blockIdx.x - n * tiles_x * tiles_y;
+    const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+    const int x = tx * SPLAT_T + (tid & 31);
+    const float big = 3.0e38f;
+    float x0 = big, x1 = -big, y0 = big, y1 = -big, all = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int tx = x0 + (k & 1), ty = y0 + (k >> 1);
-        if (tx < 0 || tx >= W || ty < 0 || ty >= H) continue;
-        float* o = out + (nbase + (long)ty * W + tx) * C;
-        for (int c = 0; c < C; ++c) unsafeAtomicAdd(o + c, __fmul_rn(ip[c], w[k]));
+    for (int q = 0; q < 4; ++q) {
+        const int y = ty * SPLAT_T + (tid >> 5) + 8 * q;
+        if (x < W && y < H) {
+            const float2 f = ((const float2*)flow)[((size_t)n * H + y) * W + x];
+            const float v = fmaxf(fabsf(f.x), fabsf(f.y));
+            if (isfinite(f.x) && isfinite(f.y)) {
+                all = fmaxf(all, v);
+                if (!(v > (float)(SPLAT_RCAP - 1))) x0 = fminf(x0, f.x), x1 = fmaxf(x1, f.x), y0 = fminf(y0, f.y), y1 = fmaxf(y1, f.y);
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        x0 = fminf(x0, __shfl_xor(x0, o)), x1 = fmaxf(x1, __shfl_xor(x1, o));
+        y0 = fminf(y0, __shfl_xor(y0, o)), y1 = fmaxf(y1, __shfl_xor(y1, o));
+        all = fmaxf(all, __shfl_xor(all, o));
+    }
+    __shared__ float wr[4][5];
+    if ((tid & 63) == 0) {
+        float* r = wr[tid >> 6];
+        r[0] = x0, r[1] = x1, r[2] = y0, r[3] = y1, r[4] = all;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        brange[blockIdx.x] = make_float4(fminf(fminf(wr[0][0], wr[1][0]), fminf(wr[2][0], wr[3][0])),
+                                         fmaxf(fmaxf(wr[0][1], wr[1][1]), fmaxf(wr[2][1], wr[3][1])),
+                                         fminf(fminf(wr[0][2], wr[1][2]), fminf(wr[2][2], wr[3][2])),
+                                         fmaxf(fmaxf(wr[0][3], wr[1][3]), fmaxf(wr[2][3], wr[3][3])));
+        const float a = fmaxf(fmaxf(wr[0][4], wr[1][4]), fmaxf(wr[2][4], wr[3][4]));
+        if (a > (float)(SPLAT_RCAP - 1)) atomicMax(&ctl->absmax_bits, __float_as_uint(a));   // rare: only far sources
     }
 }
 
+template <int NCT>   // 4: C == 4, float4 path (M2M);  0: any C, 4 channels per walk
+__global__ __launch_bounds__(256) void softsplat_list_kernel(const float* __restrict__ in, const float* __restrict__ flow,
+                                                             float* __restrict__ out, const float4* __restrict__ brange,
+                                                             SplatCtl* __restrict__ ctl, uint2* __restrict__ ovf, unsigned ovf_cap,
+                                                             int H, int W, int C, int tiles_x, int tiles_y) {
+#pragma clang fp contract(off)   // in * w, then +: the reference's atomicAdd(out, in * w) cannot fuse either
+    __shared__ int cnt[SPLAT_CELLS];
+    __shared__ unsigned short lst[SPLAT_CELLS * SPLAT_K];
+    __shared__ int rq[128];
+    const int tid = threadIdx.x;
+    const int n = blockIdx.x / (tiles_x * tiles_y);
+    const int trem = blockIdx.x - n * tiles_x * tiles_y;
+    const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+    const int X0 = tx * SPLAT_T, Y0 = ty * SPLAT_T;
+    for (int i = tid; i < SPLAT_CELLS; i += 256) cnt[i] = 0;
+    const SplatWin win = tile_window(brange, n, ty, tx, tiles_x, tiles_y, H, W, rq);     // (its barrier also covers the zeroing above)
+    const float cap = (float)(SPLAT_RCAP - 1);
+    const int wx0 = win.x0, wy0 = win.y0;
+    const int ww = win.x1 - win.x0, wh = win.y1 - win.y0;
+    const size_t nbase = (size_t)n * H * W;
+    // ---- phase 1: file every source of the window under its north-west target cell
+    constexpr int U = 4;
+    for (int i0 = tid; i0 < ww * wh; i0 += 256 * U) {
+        float2 fl[U];
+        int dxs[U], dys[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * 256;
+            ok[u] = i < ww * wh;
+            const int ii = ok[u] ? i : 0;
+            dys[u] = ii / ww;
+            dxs[u] = ii - dys[u] * ww;
+            fl[u] = ((const float2*)flow)[nbase + (size_t)(wy0 + dys[u]) * W + wx0 + dxs[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int sx = wx0 + dxs[u], sy = wy0 + dys[u];
+            const float2 f = fl[u];
+            const float fx = (float)sx + f.x, fy = (float)sy + f.y;
+            // softsplat.py:157-158 (non-finite targets are skipped); far sources go to the far pass
+            if (!(ok[u] && isfinite(fx) && isfinite(fy) && !(fmaxf(fabsf(f.x), fabsf(f.y)) > cap))) continue;
+            const int lx = (int)floorf(fx) - X0, ly = (int)floorf(fy) - Y0;      // tile-local north-west target
+            if (lx < -1 || lx >= SPLAT_T || ly < -1 || ly >= SPLAT_T) continue;
+            const int cell = (ly + 1) * SPLAT_CW + lx + 1;
+            const int slot = atomicAdd(&cnt[cell], 1);
+            if (slot < SPLAT_K) {
+                lst[cell * SPLAT_K + slot] = (unsigned short)((dys[u] << 8) | dxs[u]);     // window <= 160 x 160
+            } else {
+                const unsigned g = atomicAdd(&ctl->ovf_count, 1u);
+                if (g < ovf_cap) ovf[g] = make_uint2((unsigned)(nbase + (size_t)sy * W + sx), blockIdx.x);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: sort each list by source raster position (fixed summation order, run to run and vs the oracle)
+    for (int c = tid; c < SPLAT_CELLS; c += 256) {
+        const int k = min(cnt[c], SPLAT_K);
+        unsigned short* l = &lst[c * SPLAT_K];
+        for (int i = 1; i < k; ++i) {
+            const unsigned short v = l[i];
+            int j = i - 1;
+            while (j >= 0 && l[j] > v) {
+                l[j + 1] = l[j];
+                --j;
+            }
+            l[j + 1] = v;
+        }
+    }
+    __syncthreads();
+    // ---- phase 3: gather
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+        const int px = tid & 31, py = (tid >> 5) + 8 * q;
+        const int x = X0 + px, y = Y0 + py;
+        if (x >= W || y >= H) continue;
+        float* op = out + (nbase + (size_t)y * W + x) * C;
+        for (int c0 = 0; c0 < (NCT == 4 ? 4 : C); c0 += 4) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int k = 3; k >= 0; --k) {                           // k = dx + 2 dy: SE, SW, NE, NW contribution of the source
+                const int cell = (py + 1 - (k >> 1)) * SPLAT_CW + px + 1 - (k & 1);
+                const int ne = min(cnt[cell], SPLAT_K);
+                for (int e = 0; e < ne; ++e) {
+                    const unsigned ent = lst[cell * SPLAT_K + e];
+                    const int sx = wx0 + (int)(ent & 255u), sy = wy0 + (int)(ent >> 8);
+                    const size_t sp = nbase + (size_t)sy * W + sx;
+                    const float2 f = ((const float2*)flow)[sp];
+                    int x0, y0;
+                    float w[4];
+                    splat_weights((float)sx + f.x, (float)sy + f.y, x0, y0, w);
+                    const float wk = w[k];
+                    const float* ip = in + sp * C + c0;
+                    if (NCT == 4) {
+                        const float4 iv = *(const float4*)ip;
+                        a0 += iv.x * wk, a1 += iv.y * wk, a2 += iv.z * wk, a3 += iv.w * wk;
+                    } else {
+                        a0 += ip[0] * wk;
+                        if (c0 + 1 < C) a1 += ip[1] * wk;
+                        if (c0 + 2 < C) a2 += ip[2] * wk;
+                        if (c0 + 3 < C) a3 += ip[3] * wk;
+                    }
+                }
+            }
+            if (NCT == 4) {
+                *(float4*)op = make_float4(a0, a1, a2, a3);
+            } else {
+                op[c0] = a0;
+                if (c0 + 1 < C) op[c0 + 1] = a1;
+                if (c0 + 2 < C) op[c0 + 2] = a2;
+                if (c0 + 3 < C) op[c0 + 3] = a3;
+            }
+        }
+    }
+}
+
+// the spilled sources of over-full cells: global atomics onto the tile the list kernel has already written
+__device__ static inline void splat_spill_pass(const float* __restrict__ in, const float* __restrict__ flow, float* __restrict__ out,
+                                               unsigned total, const uint2* __restrict__ ovf, int H, int W, int C, int tiles_x,
+                                               int tiles_y) {
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const uint2 e = ovf[i];
+        const size_t sp = e.x;
+        const int n = e.y / (tiles_x * tiles_y);
+        const int trem = e.y - n * tiles_x * tiles_y;
+        const int X0 = (trem % tiles_x) * SPLAT_T, Y0 = (trem / tiles_x) * SPLAT_T;
+        const size_t nbase = (size_t)n * H * W;
+        const int sy = (int)((sp - nbase) / W), sx = (int)((sp - nbase) - (size_t)sy * W);
+        const float2 f = ((const float2*)flow)[sp];
+        int x0, y0;
+        float w[4];
+        splat_weights((float)sx + f.x, (float)sy + f.y, x0, y0, w);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int tx = x0 + (k & 1), ty = y0 + (k >> 1);
+            if (tx < X0 || tx >= X0 + SPLAT_T || ty < Y0 || ty >= Y0 + SPLAT_T || tx >= W || ty >= H) continue;   // this tile's share
+            float* o = out + (nbase + (size_t)ty * W + tx) * C;
+            for (int c = 0; c < C; ++c) unsafeAtomicAdd(o + c, __fmul_rn(in[sp * C + c], w[k]));
+        }
+    }
+}
+
+// sources displaced by more than the cap (rare) -> device-scope atomics, as the CUDA original
+__device__ static inline void splat_far_pass(const float* __restrict__ in, const float* __restrict__ flow, float* __restrict__ out,
+                                             int N, int H, int W, int C) {
+    const long total = (long)N * H * W;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int x = idx % W, y = (idx / W) % H;
+        const long nbase = idx - ((long)y * W + x);
+        const float2 f = ((const float2*)flow)[idx];
+        const float fx = (float)x + f.x, fy = (float)y + f.y;
+        if (!isfinite(fx) || !isfinite(fy)) continue;
+        if (!(fmaxf(fabsf(f.x), fabsf(f.y)) > (float)(SPLAT_RCAP - 1))) continue;
+        int x0, y0;
+        float w[4];
+        splat_weights(fx, fy, x0, y0, w);
+        const float* ip = in + idx * C;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int tx = x0 + (k & 1), ty = y0 + (k >> 1);
+            if (tx < 0 || tx >= W || ty < 0 || ty >= H) continue;
+            float* o = out + (nbase + (long)ty * W + tx) * C;
+            for (int c = 0; c < C; ++c) unsafeAtomicAdd(o + c, __fmul_rn(ip[c], w[k]));
+        }
+    }
+}
+
+// one tail launch after the tile kernels: spilled sources (when the list kernel produced any and its list did not overflow —
+// otherwise the fallback has redone the launch) and far sources; both usually absent, then every workgroup exits at once
+__global__ __launch_bounds__(256) void softsplat_tail_kernel(const float* __restrict__ in, const float* __restrict__ flow,
+                                                             float* __restrict__ out, const SplatCtl* __restrict__ ctl,
+                                                             const uint2* __restrict__ ovf, unsigned ovf_cap, int do_spill, int N,
+                                                             int H, int W, int C, int tiles_x, int tiles_y) {
+    const unsigned spilled = ctl->ovf_count;
+    if (do_spill && spilled > 0 && spilled <= ovf_cap) splat_spill_pass(in, flow, out, spilled, ovf, H, W, C, tiles_x, tiles_y);
+    if (__uint_as_float(ctl->absmax_bits) > (float)(SPLAT_RCAP - 1)) splat_far_pass(in, flow, out, N, H, W, C);
+}
+
+// per-device workspace of the splat (control words, block maxima, spill list); grows, never shrinks
+struct SplatWs {
+    SplatCtl* ctl = nullptr;
+    uint2* ovf = nullptr;
+    float4* brange = nullptr;
+    size_t brange_n = 0;
+};
+static SplatWs g_splat_ws[16];
+
+static int splat_ws(size_t n_blocks, SplatWs** out) {
+    int dev = 0;
+    VFI_CHECK_HIP(hipGetDevice(&dev));
+    VFI_REQUIRE(dev >= 0 && dev < 16, "splat: device index %d out of range", dev);
+    SplatWs& w = g_splat_ws[dev];
+    if (!w.ctl) {
+        VFI_CHECK_HIP(hipMalloc((void**)&w.ctl, sizeof(SplatCtl)));
+        VFI_CHECK_HIP(hipMalloc((void**)&w.ovf, sizeof(uint2) * (size_t)SPLAT_OVF_CAP));
+    }
+    if (w.brange_n < n_blocks) {
+        if (w.brange) VFI_CHECK_HIP(hipFree(w.brange));    // (synchronises; only on growth)
+        VFI_CHECK_HIP(hipMalloc((void**)&w.brange, sizeof(float4) * n_blocks));
+        w.brange_n = n_blocks;
+    }
+    *out = &w;
+    return 0;
+}
+
+static unsigned g_splat_cap = SPLAT_OVF_CAP;
+static int g_splat_mode = -1;   // VFI_SPLAT_MODE=atomic forces the LDS-atomic tile kernel (A/B measurements, tests of the fallback)
+
 int softsplat_sum_launch(const float* in, const float* flow, float* out, int N, int H, int W, int C, hipStream_t s) {
-    static unsigned* d_absmax = nullptr;  // one in-flight call per process
-    if (!d_absmax) VFI_CHECK_HIP(hipMalloc((void**)&d_absmax, sizeof(unsigned)));
-    const long px = (long)N * H * W;
-    VFI_CHECK_HIP(hipMemsetAsync(d_absmax, 0, sizeof(unsigned), s));
-    {
-        TraceScope ts("splat_absmax", s);
-        hipLaunchKernelGGL(flow_absmax_kernel, dim3(256), dim3(256), 0, s, flow, px * 2, d_absmax);
+    if (g_splat_mode < 0) {
+        const char* e = getenv("VFI_SPLAT_MODE");
+        g_splat_mode = (e && e[0] == 'a') ? 1 : 0;
+        if (const char* c = getenv("VFI_SPLAT_SPILL_CAP")) {
+            const long v = atol(c);
+            if (v >= 0 && v < (long)SPLAT_OVF_CAP) g_splat_cap = (unsigned)v;
+        }
     }
     const int tiles_x = cdiv(W, SPLAT_T), tiles_y = cdiv(H, SPLAT_T);
-    for (int c0 = 0; c0 < C; c0 += SPLAT_CMAX) {
-        const int nc = C - c0 < SPLAT_CMAX ? C - c0 : SPLAT_CMAX;
-        TraceScope ts("softsplat_sum", s);
-        if (nc == 4)
-            hipLaunchKernelGGL(softsplat_tile_kernel<4>, dim3(N * tiles_x * tiles_y), dim3(256), 0, s, in, flow, out, d_absmax, H,
-                               W, C, c0, nc, tiles_x, tiles_y);
-        else
-            hipLaunchKernelGGL(softsplat_tile_kernel<0>, dim3(N * tiles_x * tiles_y), dim3(256), 0, s, in, flow, out, d_absmax, H,
-                               W, C, c0, nc, tiles_x, tiles_y);
+    const unsigned n_tiles = (unsigned)N * tiles_x * tiles_y;
+    SplatWs* ws = nullptr;
+    if (int rc = splat_ws(n_tiles, &ws)) return rc;
+    VFI_CHECK_HIP(hipMemsetAsync(ws->ctl, 0, sizeof(SplatCtl), s));
+    {
+        TraceScope ts("splat_blockrange", s);
+        hipLaunchKernelGGL(flow_blockrange_kernel, dim3(n_tiles), dim3(256), 0, s, flow, H, W, tiles_x, tiles_y, ws->brange, ws->ctl);
+    }
+    const unsigned* ovf_count = &ws->ctl->ovf_count;
+    if (g_splat_mode == 0) {
+        {
+            TraceScope ts("softsplat_sum", s);
+            if (C == 4 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0)
+                hipLaunchKernelGGL(softsplat_list_kernel<4>, dim3(n_tiles), dim3(256), 0, s, in, flow, out, ws->brange, ws->ctl, ws->ovf,
+                                   g_splat_cap, H, W, C, tiles_x, tiles_y);
+            else
+                hipLaunchKernelGGL(softsplat_list_kernel<0>, dim3(n_tiles), dim3(256), 0, s, in, flow, out, ws->brange, ws->ctl, ws->ovf,
+                                   g_splat_cap, H, W, C, tiles_x, tiles_y);
+        }
+    }
+    // LDS-atomic tile kernel: the whole job when forced, otherwise only if the spill list overflowed (it then rewrites `out`)
+    {
+        TraceScope ts(g_splat_mode ? "softsplat_sum" : "splat_fallback", s);
+        const unsigned* guard = g_splat_mode ? nullptr : ovf_count;
+        for (int c0 = 0; c0 < C; c0 += SPLAT_CMAX) {
+            const int nc = C - c0 < SPLAT_CMAX ? C - c0 : SPLAT_CMAX;
+            if (nc == 4)
+                hipLaunchKernelGGL(softsplat_tile_kernel<4>, dim3(n_tiles), dim3(256), 0, s, in, flow, out, ws->brange, guard,
+                                   g_splat_cap, H, W, C, c0, nc, tiles_x, tiles_y);
+            else
+                hipLaunchKernelGGL(softsplat_tile_kernel<0>, dim3(n_tiles), dim3(256), 0, s, in, flow, out, ws->brange, guard,
+                                   g_splat_cap, H, W, C, c0, nc, tiles_x, tiles_y);
+        }
     }
     {
-        TraceScope ts("splat_far", s);
-        hipLaunchKernelGGL(softsplat_far_kernel, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, s, in, flow, out, d_absmax,
-                           N, H, W, C);
+        TraceScope ts("splat_tail", s);
+        hipLaunchKernelGGL(softsplat_tail_kernel, dim3(1024), dim3(256), 0, s, in, flow, out, ws->ctl, ws->ovf, g_splat_cap,
+                           g_splat_mode == 0 ? 1 : 0, N, H, W, C, tiles_x, tiles_y);
     }
     VFI_CHECK_HIP(hipGetLastError());
     return 0;

@@ -27,10 +27,11 @@ def nchw(x):
 def check_against_oracle(eng, sds, fr, t, out_factory):
     """Stage-by-stage parity of GMFSSEngine against oracle/gmfss_oracle.py; shared with tests/test_gpu_gmfss.py.
 
-    With random GMFlow weights the matching is incoherent (flows of tens of pixels with no spatial structure), and the soft
+    This is the STRESS vector.  With random GMFlow weights the matching is incoherent (flows of tens of pixels with no spatial structure), and the soft
     splat divides by accumulated weights that are close to zero in the resulting holes: a 1e-3 px difference in the flow
     shows up as O(1e-2) in a few output pixels.  End-to-end agreement is therefore asserted statistically, and the 1e-3 gate
-    is applied where it is meaningful: to render() run on the oracle's own state (teacher forcing)."""
+    is applied to render() run on the oracle's own state (teacher forcing).  The hard end-to-end 1e-3 gate is ``end_to_end_gate``
+    below, on a checkpoint whose matching is coherent."""
     h, w = fr.shape[1:3]
     x = fr.permute(0, 3, 1, 2).contiguous()
     ph, pw = ((h - 1) // 64 + 1) * 64, ((w - 1) // 64 + 1) * 64
@@ -85,6 +86,38 @@ def test_prepare_and_render_match_oracle(setup, h, w, t):
     r = check_against_oracle(eng, sds, fr, t, lambda hh, ww: torch.zeros(hh, ww, 3))
     print(r)
     eng.release_workspace()
+
+
+def end_to_end_gate(eng, sds, fr, t, out):
+    """The north_star gate, per-pixel |d| <= 1e-3 END TO END (prepare + render vs the oracle's reuse + inference), on the
+    coherent test vector (synth.gmfss_coherent_state_dicts + synth.texture_frames); shared with tests/test_gpu_gmfss.py.
+    Also checks that the vector is what it claims to be: bounded flows, consistent forward/backward matching."""
+    h, w = fr.shape[1:3]
+    x = fr.permute(0, 3, 1, 2).contiguous()
+    with torch.inference_mode():
+        want = G.gmfss_forward(sds, x[0:1], x[1:2], t).permute(0, 2, 3, 1)[0]
+    dev = eng.device
+    P = eng.prepare(fr[0].contiguous().to(dev), fr[1].contiguous().to(dev))
+    flows = P["flows"].cpu()
+    assert flows.abs().mean().item() <= 0.5 and (flows.abs() > 8.0).float().mean().item() <= 0.01, \
+        f"coherent vector: flows max {flows.abs().max().item()} mean {flows.abs().mean().item()}"
+    eng.render(t, out)
+    d = (out.cpu() - want).abs()
+    assert d.max().item() <= 1e-3, f"GMFSS end to end {h}x{w} t={t}: max {d.max().item()} mean {d.mean().item()}"
+    return d.max().item(), d.mean().item()
+
+
+@pytest.mark.parametrize("variant,h,w,t", [("union", 128, 192, 0.5), ("base", 128, 128, 0.3), ("union", 256, 384, 0.25)])
+def test_end_to_end_gate_on_the_coherent_checkpoint(variant, h, w, t):
+    from cfi_amd.gmfss import GMFSSEngine
+
+    sds = synth.gmfss_coherent_state_dicts(1234, variant)
+    eng = GMFSSEngine(sds, _test_backend=EmuBackend())
+    try:
+        mx, mean = end_to_end_gate(eng, sds, synth.texture_frames(2, h, w, seed=h + 1), t, torch.zeros(h, w, 3))
+        print(f"GMFSS {variant} {h}x{w} coherent, CPU double: e2e max {mx:.2e} mean {mean:.2e}")
+    finally:
+        eng.close()
 
 
 def test_constant_tables_match_oracle():

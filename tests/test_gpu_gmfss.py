@@ -10,7 +10,7 @@ import torch
 from cfi_amd import synth
 from cfi_amd.schedule import InterpolationStateList
 from oracle import gmfss_oracle as G
-from test_gmfss_engine_cpu import check_against_oracle
+from test_gmfss_engine_cpu import check_against_oracle, end_to_end_gate
 
 pytestmark = pytest.mark.gpu
 
@@ -57,3 +57,59 @@ def test_node_against_oracle_loop(hip_lib, tmp_path, monkeypatch):
     assert d.mean().item() <= 3e-3 and (d > 2e-2).float().mean().item() <= 0.05, f"max {d.max().item()} mean {d.mean().item()}"
     with pytest.raises(KeyError):
         M.GMFSS_Fortuna_VFI().vfi("GMFSS_fortuna_v2", frames)
+
+
+# ---- the hard end-to-end gate on the coherent test vector -----------------------------------------------------------
+@pytest.fixture(scope="module", params=["union", "base"])
+def coherent(request, hip_lib):
+    from cfi_amd.gmfss import GMFSSEngine
+
+    torch.cuda.set_device(0)
+    sds = synth.gmfss_coherent_state_dicts(1234, request.param)
+    eng = GMFSSEngine(sds)
+    yield sds, eng
+    eng.close()
+
+
+@pytest.mark.parametrize("h,w,t", [(128, 192, 0.5), (320, 512, 0.5), (320, 512, 0.2), (448, 704, 0.7)])
+def test_end_to_end_gate(coherent, h, w, t):
+    sds, eng = coherent
+    mx, mean = end_to_end_gate(eng, sds, synth.texture_frames(2, h, w, seed=h + 1), t, torch.zeros(h, w, 3, device="cuda"))
+    print(f"GMFSS coherent {h}x{w} t={t}: e2e max {mx:.2e} mean {mean:.2e}")
+    eng.release_workspace()
+
+
+def test_node_end_to_end_gate(hip_lib, tmp_path, monkeypatch):
+    """GMFSS_Fortuna_VFI.vfi at 320x512 (>= 270x480, no padding), x3 with a skipped pair: every new frame within 1e-3 of the
+    oracle's node loop, pass-through frames bit-exact."""
+    import cfi_amd.ckpt as K
+    import cfi_amd.gmfss as M
+
+    sds = synth.gmfss_coherent_state_dicts(1234)
+    paths = {}
+    for part, (_, name) in M.CKPTS_PATH_CONFIG["GMFSS_fortuna_union"].items():
+        paths[name] = str(tmp_path / name)
+        torch.save(sds[part], paths[name])
+    monkeypatch.setattr(K, "load_file_from_github_release", lambda model_type, ckpt_name: paths[ckpt_name])
+    frames = synth.texture_frames(4, 320, 512, seed=21)
+    states = InterpolationStateList([1], True)
+    (out,) = M.GMFSS_Fortuna_VFI().vfi("GMFSS_fortuna_union", frames, multiplier=3, optional_interpolation_states=states)
+    want = G.gmfss_vfi(sds, frames, 3, states)
+    assert out.shape == want.shape == (8, 320, 512, 3) and out.dtype == torch.float32 and out.device.type == "cpu"
+    d = (out - want).abs()
+    assert d.max().item() <= 1e-3, f"GMFSS node end to end: max {d.max().item()} mean {d.mean().item()}"
+    for i, j in ((0, 0), (3, 1), (4, 2), (7, 3)):
+        assert torch.equal(out[i], frames[j])
+
+
+def test_end_to_end_gate_1080p(hip_lib):
+    """1080x1920 (zero-padded to 1088 rows like the reference, gmfss_fortuna/__init__.py:41-78) on the coherent vector."""
+    from cfi_amd.gmfss import GMFSSEngine
+
+    sds = synth.gmfss_coherent_state_dicts(1234)
+    eng = GMFSSEngine(sds)
+    try:
+        mx, mean = end_to_end_gate(eng, sds, synth.texture_frames(2, 1080, 1920, seed=9), 0.5, torch.zeros(1080, 1920, 3, device="cuda"))
+        print(f"GMFSS coherent 1080p: e2e max {mx:.2e} mean {mean:.2e}")
+    finally:
+        eng.close()

@@ -123,3 +123,73 @@ def test_hip_ops_vs_prebuilt_reference_kernels(lib):
         want = _nhwc(R.costvol_out(one, two))
         got = _hip_costvol(lib, one, two)
         assert torch.equal(got, want), describe_diff(got, want, f"costvol {shp} (bit-exact expected)")
+
+
+# ---- the list splat's side paths -------------------------------------------------------------------------------------
+def _smooth_flow(rng, n, h, w, amp, cells=6):
+    import torch.nn.functional as F
+
+    base = torch.from_numpy(rng.standard_normal((n, 2, cells, cells + 2)).astype(np.float32)) * amp
+    return F.interpolate(base, size=(h, w), mode="bicubic", align_corners=True).numpy()
+
+
+@pytest.mark.parametrize("kind", ["smooth", "zoom_in", "to_one_pixel", "rotation", "mixed_far"])
+@pytest.mark.parametrize("c", [4, 3, 9])
+def test_softsplat_flow_fields(lib, kind, c):
+    """coherent fields (the gather's common case), convergent fields (cells with more than SPLAT_K sources spill to the
+    global-atomic pass) and far sources, against the sequential oracle"""
+    rng = np.random.default_rng(len(kind) + c)
+    n, h, w = 2, 96, 160
+    a = rng.random((n, c, h, w), dtype=np.float32)
+    ys, xs = np.meshgrid(np.arange(h, dtype=np.float32), np.arange(w, dtype=np.float32), indexing="ij")
+    if kind == "smooth":
+        f = _smooth_flow(rng, n, h, w, 6.0)
+    elif kind == "zoom_in":            # everything contracts towards the centre by 4x: ~16 sources per target cell
+        f = np.stack([np.stack([(w / 2 - xs) * 0.75, (h / 2 - ys) * 0.75])] * n)
+    elif kind == "to_one_pixel":       # every source lands in the same 2x2 footprint
+        f = np.stack([np.stack([40.3 - xs, 50.6 - ys])] * n)
+        f = np.clip(f, -62.0, 62.0)
+    elif kind == "rotation":
+        th = 0.05
+        f = np.stack([np.stack([(np.cos(th) - 1) * (xs - w / 2) - np.sin(th) * (ys - h / 2),
+                                np.sin(th) * (xs - w / 2) + (np.cos(th) - 1) * (ys - h / 2)])] * n)
+    else:
+        f = _smooth_flow(rng, n, h, w, 3.0)
+        f[:, :, 10:20, 30:50] += 90.0      # a block of far sources (> 63 px)
+        f[0, 0, 5, 5] = np.nan
+    f = np.ascontiguousarray(f, np.float32)
+    want = _nhwc(M.softsplat_sum(a, f))
+    got = _hip_splat(lib, a, f)
+    tol = 1e-5 * max(1.0, want.abs().max().item())
+    assert (got - want).abs().max().item() <= tol, describe_diff(got, want, f"softsplat {kind} C={c}")
+
+
+def test_softsplat_is_deterministic_and_exact_for_translations(lib):
+    """the gather adds each pixel's contributions in a fixed order (sorted lists): bit-identical run to run; for a uniform
+    translation that order is the sequential restatement's (ascending source position) -> bit-exact; for a smooth field the
+    orders differ at a few pixels -> last-bit differences only"""
+    rng = np.random.default_rng(3)
+    a = rng.random((1, 4, 128, 192), dtype=np.float32)
+    f = np.ascontiguousarray(_smooth_flow(rng, 1, 128, 192, 4.0), np.float32)
+    want = _nhwc(M.softsplat_sum(a, f))
+    got, again = _hip_splat(lib, a, f), _hip_splat(lib, a, f)
+    assert torch.equal(got, again), "not deterministic run to run"
+    assert (got - want).abs().max().item() <= 4 * 2.4e-7 * want.abs().max().item(), describe_diff(got, want, "smooth field: more than 4 ulp")
+    f = np.empty((1, 2, 128, 192), np.float32)
+    f[:, 0], f[:, 1] = 5.3, -17.6
+    want = _nhwc(M.softsplat_sum(a, f))
+    got = _hip_splat(lib, a, f)
+    assert torch.equal(got, want), describe_diff(got, want, "uniform translation: bit-exact expected")
+
+
+@pytest.mark.parametrize("env", [{"VFI_SPLAT_SPILL_CAP": "64"}, {"VFI_SPLAT_MODE": "atomic"}])
+def test_softsplat_fallback_paths_in_a_fresh_process(env):
+    """the spill list overflowing (-> the LDS-atomic tile kernel redoes the launch) and the forced atomic mode: the settings are
+    read once per process, so the same tests run in a child process"""
+    import subprocess
+    import sys
+
+    e = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "flow_fields or vs_c_oracle or prebuilt"], env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -217,8 +217,9 @@ def test_node_rejects_unsupported(hip_lib, sd, tmp_path, monkeypatch):
 
 @pytest.mark.parametrize("dtype", ["float16", "bfloat16"])
 def test_node_dtype_widget(hip_lib, sd, tmp_path, monkeypatch, dtype):
-    """dtype widget (rife/__init__.py:120-134,195-198,210,227-230): the reference returns the IMAGE tensor in the
-    requested dtype.  Here: clip rounded to that dtype on the way in, fp32 compute, result returned in that dtype."""
+    """dtype widget (rife/__init__.py:120-134,195-198,210,227-230,237-238): the reference rounds every frame through the
+    requested dtype and ALWAYS returns float32.  Here: clip rounded to that dtype on the way in, fp32 compute, new frames
+    rounded once through it, float32 out."""
     import cfi_amd.rife as R
 
     pth = tmp_path / "rife47.pth"
@@ -229,9 +230,10 @@ def test_node_dtype_widget(hip_lib, sd, tmp_path, monkeypatch, dtype):
     with pytest.warns(UserWarning):
         (out,) = R.RIFE_VFI().vfi("rife47.pth", frames, multiplier=2, dtype=dtype)
     (ref,) = R.RIFE_VFI().vfi("rife47.pth", frames.to(td).to(torch.float32), multiplier=2)
-    assert out.dtype == td and out.device.type == "cpu" and out.shape == ref.shape == (5, 70, 90, 3)
-    assert torch.equal(out, ref.to(td))
-    assert torch.equal(out[0], frames[0].to(td)) and torch.equal(out[4], frames[2].to(td))   # pass-through frames
+    assert out.dtype == torch.float32 and out.device.type == "cpu" and out.shape == ref.shape == (5, 70, 90, 3)
+    out.numpy()                                                   # what SaveImage / Preview do next
+    assert torch.equal(out, ref.to(td).to(torch.float32))
+    assert torch.equal(out[0], frames[0].to(td).float()) and torch.equal(out[4], frames[2].to(td).float())   # pass-through frames
     with pytest.raises(KeyError):
         R.RIFE_VFI().vfi("rife47.pth", frames, dtype="float64")
 
