@@ -3,7 +3,8 @@
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+           --master-port P bench.py --gpus N --steps K --warmup W        (one process per GPU: the driver's launch)
+    python bench.py --gpus N --steps K --warmup W                          (ONE process, N device threads: multidev.py)
 
 One "step" = one pass of the hot path over one batch of a synthetic 1080p frame-pair stream that is
 already resident in HBM: for each of B new frames  clamp/pad/encode (vfi_rife_load_frame)  and for
@@ -193,6 +194,193 @@ def cpu_baseline(sd, H, W, budget_s=25.0):
     }
 
 
+def main_single_process(args):
+    """--gpus N without a torch.distributed launcher: ONE process drives N devices (multidev.py) — one host thread and stream
+    per device, weights packed on device 0 and broadcast as one flat buffer over RCCL (ncclCommInitAll clique), every device
+    runs its own B-pair stream (weak scaling) and the new frames are all-gathered in place by grouped per-root broadcasts on
+    per-device communication streams, overlapped with the next step.  Same timed region as the multi-process form: all devices
+    synchronised + a barrier on both sides, so the elapsed time is the slowest device's."""
+    import threading
+
+    import __graft_entry__ as ge
+
+    ge.build()
+    ge.load_package()
+    from cfi_amd import _lib, multidev, synth
+
+    N, B, H, W, K, Wm = args.gpus, args.batch, args.height, args.width, args.steps, args.warmup
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    if torch.cuda.device_count() < N:
+        raise SystemExit(f"--gpus {N}: only {torch.cuda.device_count()} device(s) visible")
+    devices = list(range(N))
+    sd = synth.rife47_synth_state_dict(1234)
+    torch.cuda.set_device(0)
+    group = multidev.RifeDeviceGroup(sd, "4.7", devices)
+    comm = group.comm if group.comm is not None else multidev.Comm(devices)      # N = 1: the degenerate clique, same calls
+    gather = not args.no_gather
+    n_clip = 2 * B + 1
+    raw, bufs = [None] * N, [None] * N
+    for r in devices:
+        torch.cuda.set_device(r)
+        group.engines[r].configure(H, W, B, B + 1, 1.0)
+        g = torch.Generator(device="cpu").manual_seed(r)
+        raw[r] = torch.rand((n_clip, H, W, 3), generator=g, dtype=torch.float32).to(f"cuda:{r}")
+        bufs[r] = [torch.empty((N * B, H, W, 3), dtype=torch.float32, device=f"cuda:{r}") for _ in range(2)]
+    torch.cuda.set_device(0)
+    slot0, slot1, ts = list(range(B)), list(range(1, B + 1)), [0.5] * B
+    barrier = threading.Barrier(N)
+    ev_done = [None] * N
+    ev_gath = [[None, None] for _ in range(N)]
+    per = B * H * W * 3
+    times = {}
+    errors = []
+
+    def step(r, i, main):
+        k = i & 1
+        eng = group.engines[r]
+        if ev_gath[r][k] is not None:
+            main.wait_event(ev_gath[r][k])           # this buffer's previous all-gather has finished
+        base = B * k
+        for j in range(B + 1):
+            eng.load_frame(j, raw[r][base + j])
+        eng.interpolate(slot0, slot1, ts, bufs[r][k][r * B:(r + 1) * B])
+        if gather:
+            e = torch.cuda.Event()
+            e.record(main)
+            ev_done[r] = e
+            barrier.wait()                           # every device has enqueued step i
+            if r == 0:                               # one thread issues the collective for all devices
+                for d in devices:
+                    with torch.cuda.device(d):
+                        comm.streams[d].wait_event(ev_done[d])
+                comm.all_gather_v([bufs[d][k].data_ptr() for d in devices], [per] * N)
+                for d in devices:
+                    with torch.cuda.device(d):
+                        g_ = torch.cuda.Event()
+                        g_.record(comm.streams[d])
+                        ev_gath[d][k] = g_
+            barrier.wait()                           # the collective of step i is enqueued before anyone reuses its events
+
+    def worker(r):
+        try:
+            torch.cuda.set_device(r)
+            main = torch.cuda.current_stream()
+            for i in range(Wm):
+                step(r, i, main)
+            torch.cuda.synchronize(r)
+            barrier.wait()
+            if r == 0:
+                times["t0"] = time.perf_counter()
+            for i in range(K):
+                step(r, i, main)
+            torch.cuda.synchronize(r)                # compute and communication streams of this device
+            barrier.wait()
+            if r == 0:
+                times["t1"] = time.perf_counter()
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+            barrier.abort()
+
+    threads = [threading.Thread(target=worker, args=(r,), daemon=True) for r in devices[1:]]
+    for t in threads:
+        t.start()
+    worker(0)
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    elapsed = times["t1"] - times["t0"]
+
+    # roofline leg: the dominant kernel's launch duration by HIP events on device 0's stream (the library's tracer is
+    # process-wide, so this pass runs device 0 alone: K steps, no collective)
+    torch.cuda.set_device(0)
+    lib = _lib.load()
+    lib.vfi_trace_reset()
+    lib.vfi_trace_enable(1)
+    eng0 = group.engines[0]
+    t0 = time.perf_counter()
+    for i in range(K):
+        for j in range(B + 1):
+            eng0.load_frame(j, raw[0][B * (i & 1) + j])
+        eng0.interpolate(slot0, slot1, ts, bufs[0][i & 1][:B])
+    torch.cuda.synchronize(0)
+    traced = time.perf_counter() - t0
+    lib.vfi_trace_enable(0)
+    rep = _lib.trace_report()
+    lib.vfi_trace_reset()
+    res = result_line(args, N, elapsed, traced, rep, eng0,
+                      "all_gather_v (RCCL grouped broadcasts, in place, comm streams), overlapped" if gather else "none")
+    res["config"]["launch"] = f"one process, {N} device thread(s) (multidev.py; weights broadcast over RCCL)"
+    group.close()
+    if N == 1 and group.comm is None:
+        comm.close()
+    print(json.dumps(res), flush=True)
+
+
+def result_line(args, world, elapsed, traced, rep, eng, collective):
+    """The JSON line's common part (metric, roofline of the dominant kernel, per-kernel table)."""
+    B, H, W, K, Wm = args.batch, args.height, args.width, args.steps, args.warmup
+    conv_flop, _ = eng.work_per_task()
+    hp, wp = -(-H // 64) * 64, -(-W // 64) * 64
+    dom = "resconv_c64"
+    calls, ms = rep.get(dom, (0, 0.0))
+    flop_per_launch = 2.0 * B * (hp // 4) * (wp // 4) * 64 * 64 * 9
+    avg_ms = ms / calls if calls else float("nan")
+    achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12 if calls else float("nan")
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            traffic = tj.get(dom)
+            if traffic is not None:   # measured per launch at the batch recorded in the file; linear in the batch
+                traffic = int(traffic * B / float(tj.get("_detail", {}).get("batch", B)))
+        except Exception:
+            traffic = None
+    total_ms = sum(v[1] for v in rep.values())
+    kernels = {k: {"calls": v[0], "ms": round(v[1], 3), "share": round(v[1] / total_ms, 4)} for k, v in rep.items()}
+    return {
+        # BASELINE.json's metric; `value` is the whole-job aggregate over n_gpus (== per GPU at N=1), the per-GPU rate is
+        # config.per_gpu_frames_per_s
+        "metric": "interpolated frames/sec/GPU @1080p RIFE4.7 2x",
+        "value": round(world * B * K / elapsed, 3),
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": Wm,
+        "ms_per_step": round(elapsed / K * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"RIFE 4.7 2x, {H}x{W} synthetic frame-pair stream, {B} pairs/step/GPU resident in HBM "
+                        f"(BASELINE.json configs[1]; SURVEY 8d config 2 clip: {2 * B + 1} frames torch.manual_seed(0) torch.rand); "
+                        f"seeded random-init weights",
+            "pairs_per_step_per_gpu": B,
+            "per_gpu_frames_per_s": round(B * K / elapsed, 3),
+            "new_frame_collective": collective,
+            "target_frames_per_s_per_gpu": 30,
+        },
+        "roofline": {
+            "kernel": "conv_mfma2_kernel<s1,3x3> as resconv_c64 (block3 ResConv 64->64 @%dx%d, batch %d)" % (hp // 4, wp // 4, B),
+            "bound": "mfma",
+            "achieved": round(achieved, 3),
+            "peak": PEAK_FP32_MFMA_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+            "traffic": traffic,
+            "launches": calls,
+            "avg_launch_ms": round(avg_ms, 4),
+            "flop_per_launch": flop_per_launch,
+            "traced_ms_per_step": round(traced / K * 1e3, 3),
+        },
+        "conv_tflops_whole_net": round(conv_flop * B * K / elapsed / 1e12, 3),
+        "kernels": kernels,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -206,7 +394,11 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the FILM / M2M device-resident numbers")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather of new frames")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) | gloo (plumbing test on one GPU)")
+    ap.add_argument("--device-threads", action="store_true",
+                    help="route --gpus 1 through the one-process / device-thread path too (what --gpus N > 1 uses without a launcher)")
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.device_threads):
+        return main_single_process(args)
 
     import __graft_entry__ as ge
 
@@ -315,66 +507,10 @@ def main():
     lib.vfi_trace_reset()
 
     if rank == 0:
-        conv_flop, _ = eng.work_per_task()
-        hp, wp = -(-H // 64) * 64, -(-W // 64) * 64
-        dom = "resconv_c64"
-        calls, ms = rep.get(dom, (0, 0.0))
-        flop_per_launch = 2.0 * B * (hp // 4) * (wp // 4) * 64 * 64 * 9
-        avg_ms = ms / calls if calls else float("nan")
-        achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12 if calls else float("nan")
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                traffic = tj.get(dom)
-                if traffic is not None:   # measured per launch at the batch recorded in the file; linear in the batch
-                    traffic = int(traffic * B / float(tj.get("_detail", {}).get("batch", B)))
-            except Exception:
-                traffic = None
-        total_ms = sum(v[1] for v in rep.values())
-        kernels = {k: {"calls": v[0], "ms": round(v[1], 3), "share": round(v[1] / total_ms, 4)} for k, v in rep.items()}
-        res = {
-            # BASELINE.json's metric; `value` is the whole-job aggregate over n_gpus (== per GPU at N=1), the per-GPU rate is
-            # config.per_gpu_frames_per_s
-            "metric": "interpolated frames/sec/GPU @1080p RIFE4.7 2x",
-            "value": round(world * B * K / elapsed, 3),
-            "unit": "frames/s",
-            "n_gpus": world,
-            "steps": K,
-            "warmup": Wm,
-            "ms_per_step": round(elapsed / K * 1e3, 3),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {
-                "workload": f"RIFE 4.7 2x, {H}x{W} synthetic frame-pair stream, {B} pairs/step/GPU resident in HBM "
-                            f"(BASELINE.json configs[1]; SURVEY 8d config 2 clip: {2 * B + 1} frames torch.manual_seed(0) torch.rand); "
-                            f"seeded random-init weights",
-                "pairs_per_step_per_gpu": B,
-                "per_gpu_frames_per_s": round(B * K / elapsed, 3),
-                "new_frame_collective": "none" if world == 1 or args.no_gather else
-                                        ("all_gather(RCCL), overlapped" if gathered is not None else "all_gather(gloo, host)"),
-                "target_frames_per_s_per_gpu": 30,
-            },
-            "roofline": {
-                "kernel": "conv_mfma_kernel<s1,3x3> as resconv_c64 (block3 ResConv 64->64 @%dx%d, batch %d)" % (hp // 4, wp // 4, B),
-                "bound": "mfma",
-                "achieved": round(achieved, 3),
-                "peak": PEAK_FP32_MFMA_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                "traffic": traffic,
-                "launches": calls,
-                "avg_launch_ms": round(avg_ms, 4),
-                "flop_per_launch": flop_per_launch,
-                "traced_ms_per_step": round(traced / K * 1e3, 3),
-            },
-            "conv_tflops_whole_net": round(conv_flop * B * K / elapsed / 1e12, 3),
-            "kernels": kernels,
-        }
+        res = result_line(args, world, elapsed, traced, rep, eng,
+                          "none" if world == 1 or args.no_gather else
+                          ("all_gather(RCCL), overlapped" if gathered is not None else "all_gather(gloo, host)"))
+        res["config"]["launch"] = "one process per GPU (torch.distributed)" if world > 1 else "one process, one GPU"
         if world == 1:
             eng.close()
             if not args.no_e2e:

@@ -50,7 +50,7 @@ def build_lib(force=False, verbose=True):
     for p, src in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]   # dl: comm.hip binds RCCL at first use
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

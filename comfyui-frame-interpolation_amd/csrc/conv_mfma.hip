@@ -18,6 +18,8 @@
 // ConvTranspose2d(4,2,1)+PixelShuffle(2) (rife_arch.py:215-218; index algebra SURVEY.md A7).
 #include "vfi_common.h"
 
+#include <atomic>
+
 #include <cstdlib>
 #include <map>
 #include <string>
@@ -335,13 +337,15 @@ static int launch_t(ConvArgs a, hipStream_t s, const char* name) {
 }
 
 static int n_cus_cached() {
-    static int n = 0;
+    static std::atomic<int> n_of[kMaxDevices];     // per device: one process may drive several
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 256;
+    int n = n_of[dev].load(std::memory_order_relaxed);
     if (!n) {
-        int dev = 0;
         hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
-            n = p.multiProcessorCount;
+        if (hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
         if (n <= 0) n = 256;
+        n_of[dev].store(n, std::memory_order_relaxed);
     }
     return n;
 }

@@ -16,6 +16,8 @@
 //   * epilogue fused as in the first generation (+bias, *beta + residual, LeakyReLU, NHWC store).
 #include "vfi_common.h"
 
+#include <atomic>
+
 namespace vfi {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -381,8 +383,14 @@ static int launch2_e(ConvArgs a, hipStream_t s, const char* name) {
     VFI_REQUIRE(a.Cout_p % G::BN == 0, "conv2 %s: Cout_p=%d not a multiple of the N tile %d", name, a.Cout_p, G::BN);
     VFI_REQUIRE((long)a.Hin * a.Win * a.in_cs * 4 < 0x7fffffffL, "conv2 %s: image larger than 2 GiB", name);
     VFI_REQUIRE(!a.in_plane || a.in_plane >= a.Hin * a.Win * 4, "conv2 %s: bad plane stride", name);
-    static int occ = 0;  // resident workgroups per CU for this instantiation
-    static int cus = 0;
+    // resident workgroups per CU of this instantiation and the CU count, PER DEVICE: one process may drive several
+    // devices from several threads (multidev.py), and hipFuncSetAttribute applies to the current device only
+    static std::atomic<int> occ_of[kMaxDevices];
+    static std::atomic<int> cus_of[kMaxDevices];
+    int dev = 0;
+    VFI_CHECK_HIP(hipGetDevice(&dev));
+    VFI_REQUIRE(dev >= 0 && dev < kMaxDevices, "conv2 %s: device index %d out of range", name, dev);
+    int occ = occ_of[dev].load(std::memory_order_acquire);
     if (!occ) {
         VFI_CHECK_HIP(hipFuncSetAttribute(
             reinterpret_cast<const void*>(&conv_mfma2_kernel<STRIDE, TAPS, MT, NT, WM, WN, CK, GROUPED, EXT>),
@@ -391,13 +399,13 @@ static int launch2_e(ConvArgs a, hipStream_t s, const char* name) {
         VFI_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(
             &o, reinterpret_cast<const void*>(&conv_mfma2_kernel<STRIDE, TAPS, MT, NT, WM, WN, CK, GROUPED, EXT>), 256,
             G::LDS_BYTES));
-        int dev = 0;
         hipDeviceProp_t p;
-        VFI_CHECK_HIP(hipGetDevice(&dev));
         VFI_CHECK_HIP(hipGetDeviceProperties(&p, dev));
-        cus = p.multiProcessorCount;
+        cus_of[dev].store(p.multiProcessorCount, std::memory_order_relaxed);
         occ = o < 1 ? 1 : o;
+        occ_of[dev].store(occ, std::memory_order_release);   // (two threads racing here compute the same values)
     }
+    const int cus = cus_of[dev].load(std::memory_order_relaxed);
     const int T = a.N * a.tiles_x * a.tiles_y;
     const int ny = a.Cout_p / G::BN;
     // Persistent (one resident wave of workgroups, each walks its share of tiles, DMA pipelined across tiles)

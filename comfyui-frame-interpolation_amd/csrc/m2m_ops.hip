@@ -450,12 +450,12 @@ struct SplatWs {
     float4* brange = nullptr;
     size_t brange_n = 0;
 };
-static SplatWs g_splat_ws[16];
+static SplatWs g_splat_ws[kMaxDevices];
 
 static int splat_ws(size_t n_blocks, SplatWs** out) {
     int dev = 0;
     VFI_CHECK_HIP(hipGetDevice(&dev));
-    VFI_REQUIRE(dev >= 0 && dev < 16, "splat: device index %d out of range", dev);
+    VFI_REQUIRE(dev >= 0 && dev < kMaxDevices, "splat: device index %d out of range", dev);
     SplatWs& w = g_splat_ws[dev];
     if (!w.ctl) {
         VFI_CHECK_HIP(hipMalloc((void**)&w.ctl, sizeof(SplatCtl)));

@@ -20,23 +20,47 @@ namespace {
 struct DevBuf {
     float* p = nullptr;
     size_t n = 0;
+    bool view = false;   // points into the network's weight arena (not owned)
     int ensure(size_t count) {
         if (count <= n) return 0;
-        if (p) (void)hipFree(p);
+        if (p && !view) (void)hipFree(p);
         p = nullptr;
         n = 0;
+        view = false;
         VFI_CHECK_HIP(hipMalloc((void**)&p, count * sizeof(float)));
         n = count;
         return 0;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p && !view) (void)hipFree(p);
         p = nullptr;
         n = 0;
+        view = false;
     }
 };
 
+// Weights live in ONE device allocation per network (the "arena"): vfi_rife_create stages every packed tensor into a host
+// image, uploads it with one copy and points the layers' DevBufs into it.  A second device gets the same network by
+// vfi_rife_clone_empty (same layout, empty arena) + one RCCL broadcast of the arena (comm.hip) — no per-tensor traffic.
+struct WeightView {
+    size_t delta;   // byte offset of the DevBuf inside struct vfi_rife
+    size_t off, count;
+};
+struct Staging {
+    void* net = nullptr;
+    std::vector<float> host;
+    std::vector<WeightView> views;
+};
+static thread_local Staging* g_stage = nullptr;
+
 int upload(DevBuf& b, const std::vector<float>& h) {
+    if (g_stage) {
+        const size_t off = (g_stage->host.size() + 63) & ~(size_t)63;     // 256-byte aligned pieces
+        g_stage->host.resize(off + h.size(), 0.f);
+        std::copy(h.begin(), h.end(), g_stage->host.begin() + off);
+        g_stage->views.push_back({(size_t)((char*)&b - (char*)g_stage->net), off, h.size()});
+        return 0;
+    }
     if (b.ensure(h.size())) return -1;
     VFI_CHECK_HIP(hipMemcpy(b.p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
     return 0;
@@ -80,8 +104,29 @@ struct vfi_rife {
     DevBuf Fdbg[kMaxBlocks], Xdbg[kMaxBlocks];
     bool keep = false;
     int last_B = 0;
+    // weight arena
+    float* arena = nullptr;
+    size_t arena_n = 0;
+    std::vector<WeightView> views;
+    int device = 0;
     size_t pack_stride() const { return (size_t)Hp * Wp * 4 * (1 + NF); }
 };
+
+// one device allocation for all weights; every recorded DevBuf becomes a view into it
+static int bind_arena(vfi_rife* net, const std::vector<WeightView>& views, size_t n, const float* host) {
+    VFI_CHECK_HIP(hipGetDevice(&net->device));
+    VFI_CHECK_HIP(hipMalloc((void**)&net->arena, n * sizeof(float)));
+    net->arena_n = n;
+    if (host) VFI_CHECK_HIP(hipMemcpy(net->arena, host, n * sizeof(float), hipMemcpyHostToDevice));
+    net->views = views;
+    for (const WeightView& v : views) {
+        DevBuf* b = (DevBuf*)((char*)net + v.delta);
+        b->p = net->arena + v.off;
+        b->n = v.count;
+        b->view = true;
+    }
+    return 0;
+}
 
 static int make_conv3x3(ConvLayer& L, const float* w, const float* b, const float* beta, int Cout, int Cin,
                         int Cin_p) {
@@ -131,6 +176,9 @@ vfi_rife_t* vfi_rife_create(int arch_ver_x10, const float* const* tensors, const
     }
     vfi_rife* net = new vfi_rife();
     net->arch = arch_ver_x10;
+    Staging stage;
+    stage.net = net;
+    g_stage = &stage;
     if (arch_ver_x10 == 417) {
         net->NF = 2;
         net->CM = 32;
@@ -210,11 +258,45 @@ vfi_rife_t* vfi_rife_create(int arch_ver_x10, const float* const* tensors, const
                  !upload(net->enc_b1, vb1);
         }
     }
+    g_stage = nullptr;
+    if (ok) ok = !bind_arena(net, stage.views, stage.host.size(), stage.host.data());
     if (!ok) {
         vfi_rife_destroy(net);
         return nullptr;
     }
     return net;
+}
+
+vfi_rife_t* vfi_rife_clone_empty(const vfi_rife_t* src) {
+    if (!src || !src->arena) {
+        set_error("vfi_rife_clone_empty: null / unfinished source network");
+        return nullptr;
+    }
+    vfi_rife* net = new vfi_rife();
+    net->arch = src->arch, net->NF = src->NF, net->CM = src->CM, net->CF = src->CF, net->n_mid = src->n_mid;
+    net->nblocks = src->nblocks, net->NX = src->NX, net->enc_act = src->enc_act;
+    auto meta = [](ConvLayer& d, const ConvLayer& s_) {
+        d.Cin = s_.Cin, d.Cin_p = s_.Cin_p, d.Cout = s_.Cout, d.Cout_p = s_.Cout_p, d.folded = s_.folded;
+    };
+    for (int b = 0; b < kMaxBlocks; ++b) {
+        meta(net->conv00[b], src->conv00[b]);
+        meta(net->conv01[b], src->conv01[b]);
+        meta(net->last[b], src->last[b]);
+        for (int i = 0; i < 8; ++i) meta(net->res[b][i], src->res[b][i]);
+    }
+    for (int m = 0; m < 2; ++m) meta(net->enc_mid[m], src->enc_mid[m]);
+    if (bind_arena(net, src->views, src->arena_n, nullptr)) {     // same layout on the CURRENT device; contents by broadcast
+        vfi_rife_destroy(net);
+        return nullptr;
+    }
+    return net;
+}
+
+int vfi_rife_weights(vfi_rife_t* net, float** arena_dev, int64_t* count) {
+    VFI_REQUIRE(net && net->arena && arena_dev && count, "vfi_rife_weights: null argument / no weights");
+    *arena_dev = net->arena;
+    *count = (int64_t)net->arena_n;
+    return 0;
 }
 
 void vfi_rife_destroy(vfi_rife_t* net) {
@@ -241,6 +323,7 @@ void vfi_rife_destroy(vfi_rife_t* net) {
     for (DevBuf* d : {&net->enc_w0, &net->enc_b0, &net->enc_w1, &net->enc_b1, &net->Ppool, &net->E, &net->F, &net->M,
                       &net->X, &net->A0, &net->A1, &net->A2, &net->T, &net->X1, &net->T1, &net->FEAT})
         d->release();
+    if (net->arena) (void)hipFree(net->arena);
     delete net;
 }
 
@@ -332,13 +415,14 @@ static void fill_args(ConvArgs& a, const ConvLayer& L, const float* in, int in_c
     a.Cout = L.Cout;
 }
 
-int vfi_rife_load_frame(vfi_rife_t* net, int slot, const float* frame_dev, int C, void* stream) {
+static int load_frame_impl(vfi_rife_t* net, int slot, const float* f32, const unsigned char* u8, int C, void* stream) {
     VFI_REQUIRE(net && net->Hp > 0, "vfi_rife_load_frame: network not configured");
     VFI_REQUIRE(slot >= 0 && slot < net->n_slots && C >= 3, "vfi_rife_load_frame: bad slot %d / channels %d", slot, C);
     hipStream_t st = (hipStream_t)stream;
     float* P = net->Ppool.p + (size_t)slot * net->pack_stride();
     const int Hp = net->Hp, Wp = net->Wp;
-    if (prep_frame_launch(frame_dev, P, net->H, net->W, C, Hp, Wp, st)) return -1;
+    if (u8 ? prep_frame_u8_launch(u8, P, net->H, net->W, C, Hp, Wp, st) : prep_frame_launch(f32, P, net->H, net->W, C, Hp, Wp, st))
+        return -1;
     if (encode_conv_launch(P, net->E.p, net->enc_w0.p, net->enc_b0.p, net->CM, net->enc_act, Hp, Wp, st)) return -1;
     float* cur = net->E.p;
     float* nxt = net->E2.p;
@@ -352,6 +436,22 @@ int vfi_rife_load_frame(vfi_rife_t* net, int slot, const float* frame_dev, int C
         std::swap(cur, nxt);
     }
     return encode_deconv_launch(cur, P, net->enc_w1.p, net->enc_b1.p, net->CM, net->CF, Hp, Wp, st);
+}
+
+int vfi_rife_load_frame(vfi_rife_t* net, int slot, const float* frame_dev, int C, void* stream) {
+    VFI_REQUIRE(frame_dev, "vfi_rife_load_frame: null frame");
+    return load_frame_impl(net, slot, frame_dev, nullptr, C, stream);
+}
+
+int vfi_rife_load_frame_u8(vfi_rife_t* net, int slot, const uint8_t* frame_dev, int C, void* stream) {
+    VFI_REQUIRE(frame_dev, "vfi_rife_load_frame_u8: null frame");
+    return load_frame_impl(net, slot, nullptr, frame_dev, C, stream);
+}
+
+int vfi_f32_to_u8(const float* in_dev, uint8_t* out_dev, int64_t n, void* stream) {
+    VFI_REQUIRE(in_dev && out_dev && n >= 0 && ((uintptr_t)in_dev & 15) == 0 && ((uintptr_t)out_dev & 3) == 0,
+                "vfi_f32_to_u8: bad arguments (in 16-byte, out 4-byte aligned)");
+    return n ? f32_to_u8_launch(in_dev, out_dev, (long)n, (hipStream_t)stream) : 0;
 }
 
 int vfi_rife_interpolate(vfi_rife_t* net, int B, const int* slot0, const int* slot1, const float* timestep,

@@ -13,6 +13,8 @@ struct RifeTasks {
 
 int warp_border_launch(const float* in, const float* flow, float* out, int N, int H, int W, int C, hipStream_t s);
 int prep_frame_launch(const float* src, float* P, int H, int W, int C, int Hp, int Wp, hipStream_t s);
+int prep_frame_u8_launch(const unsigned char* src, float* P, int H, int W, int C, int Hp, int Wp, hipStream_t s);
+int f32_to_u8_launch(const float* in, unsigned char* out, long n, hipStream_t s);
 // Head: first conv 3 -> CM (stride 2, optional LeakyReLU) into E [Hp/2][Wp/2][CM]; last layer CM -> CF transposed conv
 // into pack planes 1..CF/4.  (CM, CF, act) = (16, 4, false) for 4.7, (32, 8, true) for 4.17.
 int encode_conv_launch(const float* P, float* E, const float* w0, const float* b0, int CM, bool act, int Hp, int Wp,

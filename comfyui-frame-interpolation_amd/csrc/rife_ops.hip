@@ -88,19 +88,42 @@ int warp_border_launch(const float* in, const float* flow, float* out, int N, in
 // ---------------------------------------------------------------------------------------
 // frame preparation: clamp, drop alpha, zero-pad to x64            rife_arch.py:476-484
 // ---------------------------------------------------------------------------------------
-__global__ void prep_frame_kernel(const float* __restrict__ src, float* __restrict__ P, int H, int W, int C,
+template <typename SRC>   // float: IMAGE as ComfyUI hands it over; unsigned char: 8-bit frames converted here (x / 255)
+__global__ void prep_frame_kernel(const SRC* __restrict__ src, float* __restrict__ P, int H, int W, int C,
                                   int Hp, int Wp) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= Hp * Wp) return;
     const int X = idx % Wp, Y = idx / Wp;
     float4 v = {0.f, 0.f, 0.f, 0.f};
     if (Y < H && X < W) {
-        const float* s = src + ((size_t)Y * W + X) * C;
-        v.x = fminf(fmaxf(s[0], 0.f), 1.f);
-        v.y = fminf(fmaxf(s[1], 0.f), 1.f);
-        v.z = fminf(fmaxf(s[2], 0.f), 1.f);
+        const SRC* s = src + ((size_t)Y * W + X) * C;
+        if (sizeof(SRC) == 1) {     // torch's uint8 -> float32 image: x.float() / 255 (IEEE division, already in [0, 1])
+            v.x = __fdiv_rn((float)s[0], 255.0f);
+            v.y = __fdiv_rn((float)s[1], 255.0f);
+            v.z = __fdiv_rn((float)s[2], 255.0f);
+        } else {
+            v.x = fminf(fmaxf((float)s[0], 0.f), 1.f);
+            v.y = fminf(fmaxf((float)s[1], 0.f), 1.f);
+            v.z = fminf(fmaxf((float)s[2], 0.f), 1.f);
+        }
     }
     *(float4*)(P + (size_t)idx * 4) = v;
+}
+
+// float32 frames in [0,1] -> 8 bit: round(clamp(x) * 255), ties to even like torch.round; 4 values per thread
+__global__ void f32_to_u8_kernel(const float* __restrict__ in, unsigned char* __restrict__ out, long n) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const float4 v = *(const float4*)(in + i);
+        uchar4 o;
+        o.x = (unsigned char)rintf(fminf(fmaxf(v.x, 0.f), 1.f) * 255.0f);
+        o.y = (unsigned char)rintf(fminf(fmaxf(v.y, 0.f), 1.f) * 255.0f);
+        o.z = (unsigned char)rintf(fminf(fmaxf(v.z, 0.f), 1.f) * 255.0f);
+        o.w = (unsigned char)rintf(fminf(fmaxf(v.w, 0.f), 1.f) * 255.0f);
+        *(uchar4*)(out + i) = o;
+    } else {
+        for (long j = i; j < n; ++j) out[j] = (unsigned char)rintf(fminf(fmaxf(in[j], 0.f), 1.f) * 255.0f);
+    }
 }
 
 // Head, first layer: Conv2d(3,CM,3,stride 2,pad 1) (+ LeakyReLU(0.2) for the Head / Head_417 variants).
@@ -204,7 +227,21 @@ __global__ void encode_deconv_kernel(const float* __restrict__ E, const float* _
 
 int prep_frame_launch(const float* src, float* P, int H, int W, int C, int Hp, int Wp, hipStream_t s) {
     TraceScope ts("prep_frame", s);
-    hipLaunchKernelGGL(prep_frame_kernel, dim3(cdiv(Hp * Wp, 256)), dim3(256), 0, s, src, P, H, W, C, Hp, Wp);
+    hipLaunchKernelGGL(prep_frame_kernel<float>, dim3(cdiv(Hp * Wp, 256)), dim3(256), 0, s, src, P, H, W, C, Hp, Wp);
+    VFI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int prep_frame_u8_launch(const unsigned char* src, float* P, int H, int W, int C, int Hp, int Wp, hipStream_t s) {
+    TraceScope ts("prep_frame", s);
+    hipLaunchKernelGGL(prep_frame_kernel<unsigned char>, dim3(cdiv(Hp * Wp, 256)), dim3(256), 0, s, src, P, H, W, C, Hp, Wp);
+    VFI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int f32_to_u8_launch(const float* in, unsigned char* out, long n, hipStream_t s) {
+    TraceScope ts("f32_to_u8", s);
+    hipLaunchKernelGGL(f32_to_u8_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, s, in, out, n);
     VFI_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -44,6 +44,8 @@ struct TraceScope {
     }
 };
 
+constexpr int kMaxDevices = 16;   // devices one process may drive (per-device caches are indexed by the HIP device id)
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
 

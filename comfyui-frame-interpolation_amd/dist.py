@@ -49,16 +49,28 @@ def all_gather_frames(local, counts):
 
 
 def broadcast_state_dict(sd, keys, device):
-    """Rank 0 holds the checkpoint; broadcast each tensor once (21.3 MB for RIFE 4.7)."""
+    """Rank 0 holds the checkpoint; ONE broadcast of all tensors as a flat fp32 buffer (21.3 MB for RIFE 4.7), split by the
+    shape table every rank knows.  (The single-process path, multidev.py, broadcasts the PACKED device arena instead.)"""
     import torch.distributed as dist
 
     rank, ws = world()
     if ws == 1:
         return sd
-    out = {}
-    for k, shape in keys.items():
-        t = sd[k].to(device=device, dtype=torch.float32).contiguous() if rank == 0 else torch.empty(
-            shape, dtype=torch.float32, device=device)
-        dist.broadcast(t, src=0)
-        out[k] = t.cpu()
+    numels = []
+    for shape in keys.values():
+        n = 1
+        for d in shape:
+            n *= int(d)
+        numels.append(n)
+    if rank == 0:
+        flat = torch.cat([sd[k].detach().to(torch.float32).reshape(-1) for k in keys]).to(device)
+        assert flat.numel() == sum(numels)
+    else:
+        flat = torch.empty(sum(numels), dtype=torch.float32, device=device)
+    dist.broadcast(flat, src=0)
+    flat = flat.cpu()
+    out, off = {}, 0
+    for (k, shape), n in zip(keys.items(), numels):
+        out[k] = flat[off:off + n].view(tuple(shape)).clone()
+        off += n
     return out

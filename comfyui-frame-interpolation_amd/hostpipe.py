@@ -80,14 +80,36 @@ def _pool(name, n):
     return _pools[name]
 
 
-def _rings(device, shape, n_up, n_down):
-    """Pinned / device staging rings for this (device, frame shape); each ring only ever grows."""
-    r = _ring_cache.setdefault((str(device), tuple(shape)), {"up_host": [], "up_dev": [], "down_host": []})
+_ring_lock = threading.Lock()
+
+
+def _rings_acquire(device, shape, dtype=torch.float32):
+    """A set of pinned / device staging rings for this (device, frame shape), exclusively the caller's until
+    ``_rings_release``; sets are kept for the life of the process (pinning costs about as much as the copies it saves) and each
+    ring only ever grows.  Concurrent pipelines on one device (two host threads) get different sets."""
+    key = (str(device), tuple(shape), dtype)
+    with _ring_lock:
+        free = _ring_cache.setdefault(key, [])
+        r = free.pop() if free else {"key": key, "up_host": [], "up_dev": [], "down_host": []}
+    busy = r.pop("busy", None)
+    if busy is not None:
+        busy.synchronize()        # the previous owner's kernels may still be reading the device slots
+    return r
+
+
+def _rings_release(r):
+    if r is not None:
+        with _ring_lock:
+            _ring_cache.setdefault(r["key"], []).append(r)
+
+
+def _rings_grow(r, device, shape, n_up, n_down):
+    dtype = r["key"][2]
     while len(r["up_host"]) < n_up:
-        r["up_host"].append(torch.empty(shape, dtype=torch.float32, pin_memory=True))
-        r["up_dev"].append(torch.empty(shape, dtype=torch.float32, device=device))
+        r["up_host"].append(torch.empty(shape, dtype=dtype, pin_memory=True))
+        r["up_dev"].append(torch.empty(shape, dtype=dtype, device=device))
     while len(r["down_host"]) < n_down:
-        r["down_host"].append(torch.empty(shape, dtype=torch.float32, pin_memory=True))
+        r["down_host"].append(torch.empty(shape, dtype=dtype, pin_memory=True))
     return r
 
 
@@ -99,12 +121,12 @@ class Uploader:
         self.frames, self.order, self.device, self.main = frames, list(order), device, main
         H, W = frames.shape[1:3]
         self.depth = depth
-        r = _rings(device, (H, W, 3), depth, 0)
-        self.host, self.dev = r["up_host"][:depth], r["up_dev"][:depth]
+        self.rings = _rings_grow(_rings_acquire(device, (H, W, 3), frames.dtype), device, (H, W, 3), depth, 0)   # fp32 or uint8 clips
+        self.host, self.dev = self.rings["up_host"][:depth], self.rings["up_dev"][:depth]
         self.stream = torch.cuda.Stream(device)
         self.freed = [threading.Event() for _ in self.order]      # slot of item i may be overwritten
         self.consumed = [None] * len(self.order)                  # cuda event: main stream finished reading item i
-        pool = _pool("up", workers)
+        pool = _pool(f"up{device}", workers)
         self.futs = [pool.submit(self._stage, i) for i in range(len(self.order))]
 
     def _stage(self, i):
@@ -139,18 +161,27 @@ class Uploader:
                 self.consumed[i] = torch.cuda.Event()
                 self.consumed[i].record(self.main)
             self.freed[i].set()
-        for f in self.futs:
-            f.result()
+        try:
+            for f in self.futs:
+                f.result()
+        finally:
+            if self.rings is not None:
+                busy = torch.cuda.Event()
+                busy.record(self.main)
+                self.rings["busy"] = busy
+            _rings_release(self.rings)
+            self.rings = None
 
 
 class Downloader:
     """Moves device frames [H,W,3] into rows of a host tensor through pinned slots, off the critical path."""
 
-    def __init__(self, device, shape, main, depth=16, workers=WORKERS[1]):
+    def __init__(self, device, shape, main, depth=16, workers=WORKERS[1], dtype=torch.float32):
         self.device, self.main, self.depth = device, main, depth
-        self.host = _rings(device, shape, 0, depth)["down_host"][:depth]
+        self.rings = _rings_grow(_rings_acquire(device, shape, dtype), device, shape, 0, depth)
+        self.host = self.rings["down_host"][:depth]
         self.stream = torch.cuda.Stream(device)
-        self.pool = _pool("down", workers)
+        self.pool = _pool(f"down{device}", workers)
         self.slot_fut = [None] * depth
         self.n = 0
         self.futs = []
@@ -183,10 +214,14 @@ class Downloader:
         return evs[-1] if evs else ready_event
 
     def close(self):
-        with _T("main.wait_down_close"):
-            for f in self.futs:
-                f.result()
-        self.futs = []
+        try:
+            with _T("main.wait_down_close"):
+                for f in self.futs:
+                    f.result()
+        finally:
+            self.futs = []
+            _rings_release(self.rings)
+            self.rings = None
 
 
 def copy_rows_async(out, rows, frames, idx, workers=WORKERS[2]):

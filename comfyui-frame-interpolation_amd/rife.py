@@ -65,6 +65,27 @@ class RifeEngine:
             raise RuntimeError("vfi_rife_create failed: " + _lib.last_error())
         self.cfg = None
 
+    @classmethod
+    def clone_empty(cls, src, device):
+        """The same network for another device of this process (current device must be ``device``): weight arena allocated
+        but empty — multidev.RifeDeviceGroup fills it by one RCCL broadcast."""
+        self = cls.__new__(cls)
+        self.lib = src.lib
+        self.device = torch.device(device)
+        _lib.check(self.lib.vfi_init(self.device.index or 0), "vfi_init")
+        self.arch_ver = src.arch_ver
+        self.handle = self.lib.vfi_rife_clone_empty(src.handle)
+        if not self.handle:
+            raise RuntimeError("vfi_rife_clone_empty failed: " + _lib.last_error())
+        self.cfg = None
+        return self
+
+    def weights(self):
+        """(device pointer, float count) of the flat weight arena."""
+        p, n = C.c_void_p(), C.c_int64()
+        _lib.check(self.lib.vfi_rife_weights(self.handle, C.byref(p), C.byref(n)), "vfi_rife_weights")
+        return p.value, n.value
+
     def close(self):
         if getattr(self, "handle", None):
             self.lib.vfi_rife_destroy(self.handle)
@@ -85,11 +106,15 @@ class RifeEngine:
             self.cfg = cfg
 
     def load_frame(self, slot, frame_dev):
-        """frame_dev: [H,W,C] fp32 device tensor (C >= 3)."""
-        assert frame_dev.is_cuda and frame_dev.dtype == torch.float32 and frame_dev.is_contiguous()
+        """frame_dev: [H,W,C] device tensor (C >= 3), fp32 — or uint8, converted on the device (x / 255)."""
+        assert frame_dev.is_cuda and frame_dev.dtype in (torch.float32, torch.uint8) and frame_dev.is_contiguous()
         assert tuple(frame_dev.shape[:2]) == self.cfg[:2], (frame_dev.shape, self.cfg)
-        _lib.check(self.lib.vfi_rife_load_frame(self.handle, slot, frame_dev.data_ptr(), frame_dev.shape[2],
-                                                _lib.stream_ptr()), "vfi_rife_load_frame")
+        if frame_dev.dtype == torch.uint8:
+            _lib.check(self.lib.vfi_rife_load_frame_u8(self.handle, slot, frame_dev.data_ptr(), frame_dev.shape[2],
+                                                       _lib.stream_ptr()), "vfi_rife_load_frame_u8")
+        else:
+            _lib.check(self.lib.vfi_rife_load_frame(self.handle, slot, frame_dev.data_ptr(), frame_dev.shape[2],
+                                                    _lib.stream_ptr()), "vfi_rife_load_frame")
 
     def interpolate(self, slot0, slot1, timesteps, out_dev):
         """out_dev[b] = clamp(IFNet(frame[slot0[b]], frame[slot1[b]], t[b]), 0, 1);  out_dev [B,H,W,3]."""
@@ -171,6 +196,7 @@ def run_tasks(engine, frames_cpu, tasks, batch_size, scale_factor=1.0, out_devic
     n_slots = 2 * bs + 2
     engine.configure(H, W, bs, n_slots, scale_factor)
     dev = engine.device
+    u8 = out is not None and out.dtype == torch.uint8      # 8-bit output rows: converted on the device, a quarter of the D2H bytes
     if out_device:
         res = torch.empty((len(tasks), H, W, 3), dtype=torch.float32, device=dev)
     elif out is None:
@@ -183,8 +209,9 @@ def run_tasks(engine, frames_cpu, tasks, batch_size, scale_factor=1.0, out_devic
     order = [f for _, _, need in _batches(tasks, bs) for f, _ in sim.assign(need)]
     slots = _FrameSlots(n_slots)
     up = Uploader(frames_cpu, order, dev, main, depth=min(len(order), bs + 4) or 1)
-    down = None if out_device else Downloader(dev, (H, W, 3), main, depth=2 * bs)
+    down = None if out_device else Downloader(dev, (H, W, 3), main, depth=2 * bs, dtype=torch.uint8 if u8 else torch.float32)
     bufs = [torch.empty((bs, H, W, 3), dtype=torch.float32, device=dev) for _ in range(2)] if not out_device else None
+    bufs8 = [torch.empty((bs, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(2)] if u8 else None
     buf_free = [None, None]
     import os, time
     tl = [] if os.environ.get("VFI_HOST_TIMELINE") == "1" else None
@@ -222,6 +249,9 @@ def run_tasks(engine, frames_cpu, tasks, batch_size, scale_factor=1.0, out_devic
                 e1.record(main)
                 tl.append((t_a, t_b, time.perf_counter() - t_base, e0, e1))
             if not out_device:
+                if u8:
+                    _lib.check(engine.lib.vfi_f32_to_u8(buf.data_ptr(), bufs8[k].data_ptr(), buf.numel(), _lib.stream_ptr()), "vfi_f32_to_u8")
+                    buf = bufs8[k][:len(bt)]
                 done = torch.cuda.Event()
                 done.record(main)
                 with _T("main.push"):
@@ -265,6 +295,19 @@ class RIFE_VFI:
         del keep
         print(f"Comfy-VFI done! {len(plan)} frames generated")
         return out
+
+    @staticmethod
+    def _device_group(cache_key, engine, arch_ver):
+        """multidev.RifeDeviceGroup over the devices VFI_DEVICES / config.yaml select (None = just the engine's device)."""
+        from . import multidev
+
+        devices = multidev.selected_devices(engine.device)
+        if len(devices) <= 1 or arch_ver == "4.0":
+            return None
+        key = cache_key + ("devices",) + tuple(devices)
+        if key not in _model_cache:
+            _model_cache[key] = multidev.RifeDeviceGroup.around(engine, devices)
+        return _model_cache[key]
 
     @classmethod
     def INPUT_TYPES(s):
@@ -312,6 +355,8 @@ class RIFE_VFI:
         if dtype not in DTYPE_OPTIONS:
             raise KeyError(dtype)
         if dtype != "float32":
+            if frames.dtype == torch.uint8:
+                frames = frames.to(torch.float32) / 255.0
             # The reference casts model and inputs to the widget's dtype, rounds every output frame through it
             # (rife/__init__.py:120-134,195-198,210,227-230) and ALWAYS returns float32 (:237-238).  Here the hot path
             # computes in fp32: the clip is rounded to the requested dtype on the way in (so pass-through frames are
@@ -336,6 +381,8 @@ class RIFE_VFI:
             print(f"Comfy-VFI: Loaded and cached model {ckpt_name} (HIP, float32)")
         engine = _model_cache[cache_key]
         if arch_ver == "4.0":
+            if frames.dtype == torch.uint8:
+                frames = frames.to(torch.float32) / 255.0      # the op-by-op 4.0 engine takes float32 clips only
             return (self._vfi40(engine, frames, multiplier, fast_mode, ensemble, scale_factor, batch_size,
                                 optional_interpolation_states),)
 
@@ -343,7 +390,15 @@ class RIFE_VFI:
         n = len(frames)
         _, tasks = rife_task_list(n, multiplier, optional_interpolation_states)
         plan = rife_output_plan(n, tasks)
-        out = torch.empty((len(plan),) + tuple(frames.shape[1:]), dtype=torch.float32)
+        # Extension beyond the reference: a uint8 clip (what video load / save nodes hold) stays 8-bit
+        # on the host and over PCIe — x / 255 on the device on the way in, round(clamp(y) * 255) on the way out, uint8 IMAGE
+        # returned; the float32 contract of the reference is untouched for float32 clips.
+        u8 = frames.dtype == torch.uint8
+        if u8 and world()[1] > 1:
+            raise NotImplementedError("RIFE VFI (HIP): uint8 clips are not supported on the torch.distributed multi-process path")
+        if not u8 and frames.dtype != torch.float32:
+            frames = frames.to(torch.float32)
+        out = torch.empty((len(plan),) + tuple(frames.shape[1:]), dtype=torch.uint8 if u8 else torch.float32)
         src_rows = [i for i, (kind, _) in enumerate(plan) if kind == "src"]
         src_idx = [idx for kind, idx in plan if kind == "src"]
         new_rows = [0] * len(tasks)
@@ -358,7 +413,12 @@ class RIFE_VFI:
         passthrough += copy_rows_async(out, src_rows, frames, src_idx)
         batch_size = effective_batch(batch_size, frames.shape[1], frames.shape[2])
         rank, ws = world()
-        if ws > 1:
+        group = self._device_group(cache_key, engine, arch_ver) if ws == 1 else None
+        if group is not None:
+            # one process, several GPUs (multidev.py): every device interpolates its block of the task list and copies its own
+            # shard into `out` over its own PCIe link
+            group.run(frames, tasks, batch_size, scale_factor, out, new_rows)
+        elif ws > 1:
             lo, hi = shard_tasks(tasks, rank, ws)
             counts = [shard_tasks(tasks, r, ws)[1] - shard_tasks(tasks, r, ws)[0] for r in range(ws)]
             local = run_tasks(engine, frames, tasks[lo:hi], batch_size, scale_factor, out_device=True)

@@ -342,6 +342,12 @@ int vfi_rife_configure(vfi_rife_t* net, int H, int W, int max_batch, int n_slots
  * adjacent pairs and all timesteps. */
 int vfi_rife_load_frame(vfi_rife_t* net, int slot, const float* frame_dev, int C, void* stream);
 
+/* 8-bit frames (the callers either side of the node — video load / save — deal in uint8 images, a
+ * quarter of the PCIe bytes): the same as vfi_rife_load_frame on frame_dev[H,W,C] uint8 with x = u8 / 255 computed on the
+ * device (== torch's ``frames.float() / 255`` bit for bit), and the way back: out = round(clamp(in, 0, 1) * 255), ties to even. */
+int vfi_rife_load_frame_u8(vfi_rife_t* net, int slot, const uint8_t* frame_dev, int C, void* stream);
+int vfi_f32_to_u8(const float* in_dev, uint8_t* out_dev, int64_t n, void* stream);
+
 /* The per-task hot loop: out[b] = clamp(IFNet(frame[slot0[b]], frame[slot1[b]], t[b]), 0, 1)
  * for b < B.  Replaces the model call + clamp at vfi_models/rife/__init__.py:200-207 and
  * IFNet.forward (rife_arch.py:465-732, arch "4.7").   out_dev: [B,H,W,3]. */
@@ -357,6 +363,31 @@ int vfi_rife_debug_keep(vfi_rife_t* net, int on);
 
 /* Work done by one interpolate call for roofline accounting (algorithmic, per task). */
 int vfi_rife_work(vfi_rife_t* net, double* conv_flop_per_task, double* hbm_bytes_per_task);
+
+/* ---- one process, several GPUs ------------------------------------------------------------
+ * The reference's node contract is ONE vfi() call in ONE ComfyUI process (__init__.py:24-48,
+ * vfi_models/rife/__init__.py:77-91), so the multi-GPU form that is a drop-in is single-process: one host thread + one
+ * stream per visible device (each thread calls vfi_init(device) once), tasks block-partitioned over the devices, every
+ * device copying its own shard of new frames into the shared host output tensor.  RCCL (ncclCommInitAll, bound at first
+ * use by dlopen) carries the two exchanges north_star names: the weights, once, as one flat buffer, and the all-gather of new
+ * frames for device-side consumers.  All vfi_comm_* calls are made by ONE thread for all devices. */
+
+/* A second copy of `src` for the CURRENT device: same architecture and weight layout, weight arena allocated but EMPTY —
+ * fill it with vfi_comm_broadcast over the arenas (vfi_rife_weights).  Configure / load_frame / interpolate as usual. */
+vfi_rife_t* vfi_rife_clone_empty(const vfi_rife_t* src);
+/* The network's weights as one flat device buffer (every packed tensor of vfi_rife_create, 256-byte aligned pieces). */
+int vfi_rife_weights(vfi_rife_t* net, float** arena_dev, int64_t* count);
+
+typedef struct vfi_comm vfi_comm_t;
+/* ncclCommInitAll over `devices` (HIP device ids, distinct); NULL + vfi_last_error() when RCCL is unavailable. */
+vfi_comm_t* vfi_comm_create(int n_devices, const int* devices);
+void vfi_comm_destroy(vfi_comm_t* comm);
+int vfi_comm_size(const vfi_comm_t* comm);
+/* bufs_dev[i] (on devices[i], `count` floats) <- bufs_dev[root]; streams[i] = a hipStream_t created on devices[i]. */
+int vfi_comm_broadcast(vfi_comm_t* comm, float* const* bufs_dev, int64_t count, int root, void* const* streams);
+/* In-place all-gather-v: bufs_dev[i] holds sum(counts) floats, rank r's own block already in place at offset
+ * counts[0] + ... + counts[r-1]; afterwards every buffer holds every block (grouped per-root broadcasts, so counts may differ). */
+int vfi_comm_all_gather_v(vfi_comm_t* comm, float* const* bufs_dev, const int64_t* counts, void* const* streams);
 
 #ifdef __cplusplus
 }

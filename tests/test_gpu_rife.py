@@ -664,3 +664,23 @@ def test_quad_transition_matches_cell_kernel(hip_lib, tmp_path):
         res[mask] = torch.load(out)
     for a, b in zip(res["0"], res["6"]):
         assert (a - b).abs().max().item() <= 5e-5, describe_diff(a, b, "quad vs cell transition")
+
+
+def test_node_uint8_clip(hip_lib, sd, tmp_path, monkeypatch):
+    """an 8-bit clip stays 8-bit on the host and over PCIe; conversion on the device both ways.  Equal, value
+    for value, to the float32 node on frames / 255 followed by round(y * 255) — and 4x fewer bytes each way."""
+    import cfi_amd.rife as R
+
+    pth = tmp_path / "rife47.pth"
+    torch.save(sd, pth)
+    monkeypatch.setattr(R, "load_file_from_github_release", lambda model_type, ckpt: str(pth))
+    f32 = synth.smooth_frames(6, 90, 134, seed=8, shift=2.0, c=4)
+    u8 = (f32 * 255).round().to(torch.uint8)                                 # RGBA, 6 frames
+    before = u8.clone()
+    (out,) = R.RIFE_VFI().vfi("rife47.pth", u8, multiplier=3, batch_size=4)
+    (ref,) = R.RIFE_VFI().vfi("rife47.pth", u8.to(torch.float32) / 255.0, multiplier=3, batch_size=4)
+    assert torch.equal(u8, before) and out.dtype == torch.uint8 and out.device.type == "cpu" and out.shape == (16, 90, 134, 3)
+    want = (ref.clamp(0, 1) * 255).round().to(torch.uint8)
+    assert torch.equal(out, want), f"{(out.int() - want.int()).abs().max().item()} levels"
+    for i in range(6):
+        assert torch.equal(out[3 * i], u8[i, ..., :3])
