@@ -117,6 +117,8 @@ PROTOTYPES = {
     "vfi_rife_debug_keep": (C.c_int, [C.c_void_p, C.c_int]),
     "vfi_rife_debug_read": (C.c_int64, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64]),
     "vfi_rife_work": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "vfi_attention": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
     "vfi_rife_load_frame_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "vfi_f32_to_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "vfi_rife_clone_empty": (C.c_void_p, [C.c_void_p]),

@@ -1,0 +1,267 @@
+// Flash-style single-head attention on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32 products) for GMFSS's
+// GMFlow: the 12 + 12 window attentions of FeatureTransformer, the global matching softmax (8640 x 8640 at 1080p) and the
+// global flow propagation.  Replaces the three-kernel form  scores = q k^T (bmm_nt)  ->  row softmax  ->  P v (bmm_nn)  of
+// round 1, whose score matrices round-tripped HBM (11 GiB of workspace at 1080p, 215 of the 275 ms per pair):
+//   GMFSS_Fortuna_union_arch.py:367-436 (single_head_split_window_attention), :806-843 (global_correlation_softmax),
+//   :708-745 (FeatureFlowAttention.forward, global branch).
+//
+// out[b][m][0:DV] = sum_n softmax_n(alpha * q[b][m] . k[b][n] + mask(b, m, n)) * v[b][n][0:DV]
+//   mask(b, m, n) = -100 where label[b % period][m] != label[b % period][n]  (the shifted-window mask, :326-364), else 0.
+//
+// One wave = 32 queries, one workgroup = 4 waves = 128 queries of one batch entry; keys / values stream through LDS in blocks
+// of 32 (double-buffered).  The transposed products are computed, S^T = K Q^T and O^T = V^T P^T, so that a lane's MFMA
+// column is ONE query: the online-softmax row statistics are per-lane scalars (plus one exchange with lane ^ 32), the
+// rescaling of the output accumulator is a per-lane multiply, and the probabilities never leave registers — the S^T
+// accumulator layout (register r of half h = key 8(r/4) + 4h + r%4) is exactly the B-operand order of the second product when
+// V^T is read from LDS four keys at a time.
+#include "vfi_common.h"
+
+#include "../../include/vfi_hip.h"
+
+namespace vfi {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int ATT_C = 128;            // head dimension of GMFlow's transformer
+constexpr int ATT_KB = 32;            // keys per block
+constexpr int ATT_KS = ATT_C + 4;     // LDS row stride of the K tile (floats)
+constexpr int ATT_VS = ATT_KB + 4;    // LDS row stride of the V^T tile
+
+struct AttArgs {
+    const float* q;
+    const float* k;
+    const float* v;
+    float* out;
+    const int* labels;   // [period][L] or nullptr
+    int q_cs, k_cs, v_cs, out_cs;
+    int nb, Lq, Lk, DV, period;
+    float alpha;
+};
+
+template <int DVT>   // output tiles of 32 value channels: 4 (DV = 128) or 1 (DV <= 32, e.g. the 2-channel grid / flow)
+__global__ __launch_bounds__(256) void attention_kernel(const AttArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int DVP = DVT * 32;
+    constexpr int KT = ATT_KB * ATT_KS, VT = DVP * ATT_VS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 x (K tile | V^T tile | labels)
+    constexpr int BUF = KT + VT + ATT_KB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int b = blockIdx.y;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int query = q0 + l31;
+    const bool qok = query < a.Lq;
+    const float* kb_ = a.k + (size_t)b * a.Lk * a.k_cs;
+    const float* vb_ = a.v + (size_t)b * a.Lk * a.v_cs;
+    const int* lab = a.labels ? a.labels + (size_t)(b % a.period) * a.Lk : nullptr;     // (labels index tokens: Lq == Lk when used)
+
+    // this lane's query row, the channels of its half: qreg[4g + j] = Q[query][8g + 4 half + j]
+    float qreg[64];
+    {
+        const float* qp = a.q + ((size_t)b * a.Lq + (qok ? query : 0)) * a.q_cs + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            f32x4 t = *(const f32x4*)(qp + 8 * g);
+            if (!qok) t = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) qreg[4 * g + j] = t[j];
+        }
+    }
+    const int qlab = lab && qok ? lab[query] : 0;
+
+    f32x16 o[DVT];
+#pragma unroll
+    for (int t = 0; t < DVT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int nblk = (a.Lk + ATT_KB - 1) / ATT_KB;
+    // loader, split in two so that the global latency hides under the MFMAs: fetch() block k+1 into registers before block k is
+    // multiplied, commit() them to the other LDS buffer afterwards.  K tile 32 x 128 floats = 1024 float4 (4 per thread),
+    // V tile 32 keys x DV (DV = 128: 4 float4 per thread, transposed on the way into LDS).
+    f32x4 kreg[4], vreg[4];
+    int lreg = 0;
+    auto fetch = [&](int kblk) {
+        const int key0 = kblk * ATT_KB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            const int key = idx >> 5, d4 = idx & 31;
+            kreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (key0 + key < a.Lk) kreg[i] = *(const f32x4*)(kb_ + (size_t)(key0 + key) * a.k_cs + 4 * d4);
+        }
+        if (DVT == 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = tid + 256 * i;
+                const int key = idx & 31, d4 = idx >> 5;     // consecutive lanes = consecutive keys: conflict-free transposed store
+                vreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (key0 + key < a.Lk) vreg[i] = *(const f32x4*)(vb_ + (size_t)(key0 + key) * a.v_cs + 4 * d4);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = tid + 256 * i;
+                const int key = idx & 31, d = idx >> 5;
+                vreg[0][i] = (d < a.DV && key0 + key < a.Lk) ? vb_[(size_t)(key0 + key) * a.v_cs + d] : 0.f;
+            }
+        }
+        if (tid < ATT_KB) lreg = (lab && key0 + tid < a.Lk) ? lab[key0 + tid] : 0;
+    };
+    auto commit = [&](int buf) {
+        float* kt = smem + buf * BUF;
+        float* vt = kt + KT;
+        int* lt = (int*)(vt + VT);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            const int key = idx >> 5, d4 = idx & 31;
+            *(f32x4*)(kt + key * ATT_KS + 4 * d4) = kreg[i];
+        }
+        if (DVT == 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = tid + 256 * i;
+                const int key = idx & 31, d4 = idx >> 5;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) vt[(4 * d4 + j) * ATT_VS + key] = vreg[i][j];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = tid + 256 * i;
+                vt[(idx >> 5) * ATT_VS + (idx & 31)] = vreg[0][i];
+            }
+        }
+        if (tid < ATT_KB) lt[tid] = lreg;
+    };
+
+    fetch(0);
+    commit(0);
+    __syncthreads();
+    for (int kblk = 0; kblk < nblk; ++kblk) {
+        const int buf = kblk & 1;
+        if (kblk + 1 < nblk) fetch(kblk + 1);
+        const float* kt = smem + buf * BUF;
+        const float* vt = kt + KT;
+        const int* lt = (const int*)(vt + VT);
+
+        // ---- S^T = K Q^T : rows = keys, this lane's column = its query
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        const float* krow = kt + l31 * ATT_KS + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const f32x4 kf = *(const f32x4*)(krow + 8 * g);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qreg[4 * g + j], s, 0, 0, 0);
+        }
+        // ---- scale, mask, online softmax (per-lane: every register of `s` belongs to this lane's query)
+        const int key0 = kblk * ATT_KB;
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kk = 8 * (r >> 2) + 4 * half + (r & 3);
+            float x = s[r] * a.alpha;
+            if (lab && lt[kk] != qlab) x += -100.0f;
+            if (key0 + kk >= a.Lk) x = -INFINITY;
+            s[r] = x;
+            mloc = fmaxf(mloc, x);
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+        const float m_new = fmaxf(m_run, mloc);          // finite: every block holds at least one real key
+        const float corr = __expf(m_run - m_new);        // 0 on the first block (m_run = -inf)
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = __expf(s[r] - m_new);
+            s[r] = p;
+            psum += p;
+        }
+        psum += __shfl_xor(psum, 32);
+        l_run = l_run * corr + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int t = 0; t < DVT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t][r] *= corr;
+        // ---- O^T += V^T P^T : A = V^T[channel l31 of tile t][4 keys of this half], B = the S^T registers as they are
+#pragma unroll
+        for (int t = 0; t < DVT; ++t) {
+            const float* vrow = vt + (32 * t + l31) * ATT_VS + 4 * half;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 vf = *(const f32x4*)(vrow + 8 * j);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[i], s[4 * j + i], o[t], 0, 0, 0);
+            }
+        }
+        if (kblk + 1 < nblk) commit(buf ^ 1);     // that buffer was released by the barrier that ended block kblk-1
+        __syncthreads();                          // block consumed; the next one has been written
+    }
+    // ---- normalise and store: register r of tile t = channel 32t + 8(r/4) + 4 half + r%4 of this lane's query
+    if (qok) {
+        const float inv = 1.0f / l_run;
+        float* op = a.out + ((size_t)b * a.Lq + query) * a.out_cs;
+#pragma unroll
+        for (int t = 0; t < DVT; ++t)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int ch = 32 * t + 8 * r4 + 4 * half;
+                if (DVT == 4) {
+                    *(f32x4*)(op + ch) = f32x4{o[t][4 * r4] * inv, o[t][4 * r4 + 1] * inv, o[t][4 * r4 + 2] * inv, o[t][4 * r4 + 3] * inv};
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (ch + i < a.DV) op[ch + i] = o[t][4 * r4 + i] * inv;
+                }
+            }
+    }
+#endif
+}
+
+template <int DVT>
+static int attention_launch_t(const AttArgs& a, hipStream_t s) {
+    constexpr int LDS = 2 * (ATT_KB * ATT_KS + DVT * 32 * ATT_VS + ATT_KB) * 4;
+    static bool attr_set[kMaxDevices] = {};
+    int dev = 0;
+    VFI_CHECK_HIP(hipGetDevice(&dev));
+    VFI_REQUIRE(dev >= 0 && dev < kMaxDevices, "attention: device index %d out of range", dev);
+    if (!attr_set[dev]) {
+        VFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<DVT>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set[dev] = true;
+    }
+    TraceScope ts(DVT == 4 ? "attention_c128" : "attention_c2", s);
+    hipLaunchKernelGGL(attention_kernel<DVT>, dim3(cdiv(a.Lq, 128), a.nb), dim3(256), LDS, s, a);
+    VFI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace vfi
+
+using namespace vfi;
+
+extern "C" int vfi_attention(const float* q_dev, int q_cs, const float* k_dev, int k_cs, const float* v_dev, int v_cs, float* out_dev,
+                             int out_cs, int nb, int Lq, int Lk, int C, int DV, float alpha, const int* labels_dev, int label_period,
+                             void* stream) {
+    VFI_REQUIRE(q_dev && k_dev && v_dev && out_dev && nb > 0 && Lq > 0 && Lk > 0, "vfi_attention: bad arguments");
+    VFI_REQUIRE(C == ATT_C, "vfi_attention: head dimension %d (only %d, GMFlow's)", C, ATT_C);
+    VFI_REQUIRE(DV == 128 || (DV >= 1 && DV <= 32), "vfi_attention: %d value channels (128, or 1..32)", DV);
+    VFI_REQUIRE(q_cs >= C && k_cs >= C && q_cs % 4 == 0 && k_cs % 4 == 0 && v_cs >= DV && out_cs >= DV &&
+                    (DV != 128 || (v_cs % 4 == 0 && out_cs % 4 == 0)),
+                "vfi_attention: bad strides (q %d, k %d, v %d, out %d)", q_cs, k_cs, v_cs, out_cs);
+    VFI_REQUIRE((((uintptr_t)q_dev | (uintptr_t)k_dev) & 15) == 0 && (DV != 128 || (((uintptr_t)v_dev | (uintptr_t)out_dev) & 15) == 0),
+                "vfi_attention: unaligned pointers");
+    VFI_REQUIRE(!labels_dev || (label_period > 0 && Lq == Lk), "vfi_attention: labels need Lq == Lk and a period");
+    AttArgs a;
+    a.q = q_dev, a.k = k_dev, a.v = v_dev, a.out = out_dev, a.labels = labels_dev;
+    a.q_cs = q_cs, a.k_cs = k_cs, a.v_cs = v_cs, a.out_cs = out_cs;
+    a.nb = nb, a.Lq = Lq, a.Lk = Lk, a.DV = DV, a.period = labels_dev ? label_period : 1;
+    a.alpha = alpha;
+    return DV == 128 ? attention_launch_t<4>(a, (hipStream_t)stream) : attention_launch_t<1>(a, (hipStream_t)stream);
+}

@@ -74,6 +74,21 @@ def shift_mask(h, w, k):
     return torch.where(diff != 0, torch.tensor(-100.0), torch.tensor(0.0)).contiguous()
 
 
+def shift_labels(h, w, k):
+    """The same mask as region labels per token in window order, int32 [k*k, lw]: two tokens of a (shifted) window may attend
+    to each other iff their labels are equal — what vfi_attention takes instead of the [k*k, lw, lw] float mask."""
+    wh, ww = h // k, w // k
+
+    def region(n, win):
+        r = torch.zeros(n, dtype=torch.int32)
+        r[n - win:n - win // 2] = 1
+        r[n - win // 2:] = 2
+        return r
+
+    label = region(h, wh)[:, None] * 3 + region(w, ww)[None, :]
+    return label.view(k, wh, k, ww).permute(0, 2, 1, 3).reshape(k * k, wh * ww).contiguous()
+
+
 class GMFSSEngine(OpsEngine):
     def __init__(self, state_dicts, device=None, _test_backend=None):
         super().__init__(device, _test_backend)
@@ -221,11 +236,10 @@ class GMFSSEngine(OpsEngine):
         qw, kw, vw, ow = (self._t("att_" + n, nb, lw, c) for n in ("q", "k", "v", "o"))
         for src, dst in ((q, qw), (k, kw), (v, vw)):
             self._c("vfi_window_partition", _p(src), src.shape[-1], _p(dst), c, B, h, w, c, splits, sh, sw, 0)
-        sc = self._t("att_s", nb, lw, lw)
-        self._c("vfi_bmm_nt", _p(qw), c, _p(kw), c, _p(sc), nb, lw, lw, c, 1.0 / c ** 0.5)
-        mask = self._const(("mask", h, w, splits), lambda: shift_mask(h, w, splits)) if shifted else None
-        self._c("vfi_softmax_rows", _p(sc), nb, lw, lw, _p(mask) if shifted else None, splits * splits)
-        self._c("vfi_bmm_nn", _p(sc), _p(vw), c, _p(ow), c, nb, lw, lw, c)
+        # softmax(q k^T / sqrt(c) + mask) v as one flash-style MFMA kernel (csrc/attention.hip): no score matrix in HBM
+        labels = self._const(("labels", h, w, splits), lambda: shift_labels(h, w, splits)) if shifted else None
+        self._c("vfi_attention", _p(qw), c, _p(kw), c, _p(vw), c, _p(ow), c, nb, lw, lw, c, c, 1.0 / c ** 0.5,
+                _p(labels) if shifted else None, splits * splits)
         self._c("vfi_window_partition", _p(ow), c, _p(out), out.shape[-1], B, h, w, c, splits, sh, sw, 1)
 
     def _pair_swap(self, a, o):
@@ -339,22 +353,18 @@ class GMFSSEngine(OpsEngine):
         self._transformer(a, 2)
         o = self._t("s0_o", 2, h8, w8, 128)
         self._pair_swap(a, o)
-        sc = self._t("s0_scores", 2, L, L)
-        self._c("vfi_bmm_nt", _p(a), 128, _p(o), 128, _p(sc), 2, L, L, 128, 1.0 / 128 ** 0.5)
-        self._c("vfi_softmax_rows", _p(sc), 2, L, L, None, 0)
         grid = self._const(("grid", h8, w8), lambda: torch.stack(torch.meshgrid(torch.arange(h8), torch.arange(w8), indexing="ij")[::-1], -1)
                            .float()[None].repeat(2, 1, 1, 1))
         flow8 = self._t("s0_flow", 2, h8, w8, 2)
-        self._c("vfi_bmm_nn", _p(sc), _p(grid), 2, _p(flow8), 2, 2, L, L, 2)
+        # global matching: softmax over ALL target pixels, expected coordinate (v = the pixel grid, 2 channels)
+        self._c("vfi_attention", _p(a), 128, _p(o), 128, _p(grid), 2, _p(flow8), 2, 2, L, L, 128, 2, 1.0 / 128 ** 0.5, None, 0)
         self._ax(flow8, 0, grid, 0, flow8, 0, 2, 1.0, -1.0)
         # propagation: key projected from the PROJECTED query (:728-735)
         q, k = self._t("s0_q", 2, h8, w8, 128), self._t("s0_k", 2, h8, w8, 128)
         self._conv(self.prop_q, a, 0, q, 0)
         self._conv(self.prop_k, q, 0, k, 0)
-        self._c("vfi_bmm_nt", _p(q), 128, _p(k), 128, _p(sc), 2, L, L, 128, 1.0 / 128 ** 0.5)
-        self._c("vfi_softmax_rows", _p(sc), 2, L, L, None, 0)
         flow8p = self._t("s0_flowp", 2, h8, w8, 2)
-        self._c("vfi_bmm_nn", _p(sc), _p(flow8), 2, _p(flow8p), 2, 2, L, L, 2)
+        self._c("vfi_attention", _p(q), 128, _p(k), 128, _p(flow8), 2, _p(flow8p), 2, 2, L, L, 128, 2, 1.0 / 128 ** 0.5, None, 0)
         # ---- scale 1: local refinement at 1/4, one batch entry pair per direction
         flow4 = self._t("s1_flow", 2, h4, w4, 2)
         self._c("vfi_resize_bilinear_ac", _p(flow8p), 2, _p(flow4), 2, 2, h8, w8, h4, w4, 2, 2.0)

@@ -56,7 +56,8 @@ class OpsEngine:
 
     def _const(self, key, make):
         if key not in self.consts:
-            self.consts[key] = make().to(self.device, torch.float32).contiguous()
+            t = make()
+            self.consts[key] = t.to(self.device, torch.int32 if not t.is_floating_point() else torch.float32).contiguous()
         return self.consts[key]
 
     def _layer(self, w, b=None, slopes=None, kind=0, stride=1, chan_map=None, cin_phys=None, scale_out=None, shift_out=None):

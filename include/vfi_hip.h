@@ -251,6 +251,15 @@ int vfi_bmm_nn(const float* p_dev, const float* v_dev, int v_cs, float* out_dev,
 /* softmax over the rows of x [nb][rows][cols] in place; mask [period][rows][cols] (nullable) is added first, batch b taking
  * mask[b % period] (scores += attn_mask.repeat(b, 1, 1), :422-425) */
 int vfi_softmax_rows(float* x_dev, int nb, int rows, int cols, const float* mask_dev, int mask_period, void* stream);
+/* The three calls above as ONE flash-style kernel on the fp32 matrix cores, the score matrix never touching HBM:
+ *   out[b][m][0:DV] = sum_n softmax_n(alpha * q[b][m] . k[b][n] + mask) * v[b][n][0:DV],   q, k: [nb][L][C = 128]
+ * mask = -100 where labels[b % period][m] != labels[b % period][n] (labels nullable, int32 [period][Lk]: the shifted-window
+ * attention mask of generate_shift_window_attn_mask, :326-364, as region labels).  DV = 128 (attention) or 1..32 (global
+ * matching / flow propagation: v = pixel grid / flow).  Replaces single_head_split_window_attention (:367-436),
+ * global_correlation_softmax (:806-843), FeatureFlowAttention.forward's global branch (:708-745). */
+int vfi_attention(const float* q_dev, int q_cs, const float* k_dev, int k_cs, const float* v_dev, int v_cs, float* out_dev,
+                  int out_cs, int nb, int Lq, int Lk, int C, int DV, float alpha, const int* labels_dev, int label_period,
+                  void* stream);
 /* flow_warp / bilinear_sample: grid_sample(zeros, align_corners=True) at pixel + flow (:955-991) */
 int vfi_flow_sample(const float* in_dev, int in_cs, const float* flow_dev, int flow_cs, float* out_dev, int out_cs, int N, int H, int W,
                     int C, void* stream);

@@ -98,6 +98,22 @@ class EmuLib:
 
         return counted
 
+    # ---- flash attention (csrc/attention.hip is an MFMA kernel without a host body): torch restatement of its contract ---
+    def vfi_attention(self, q_ptr, q_cs, k_ptr, k_cs, v_ptr, v_cs, out_ptr, out_cs, nb, lq, lk, c, dv, alpha, labels_ptr, period, stream=None):
+        assert c == 128 and (dv == 128 or 1 <= dv <= 32) and q_cs >= c and k_cs >= c and v_cs >= dv and out_cs >= dv
+        assert int(q_ptr) % 16 == 0 and int(k_ptr) % 16 == 0 and (not labels_ptr or (lq == lk and period > 0))
+        q = view(q_ptr, nb, 1, lq, q_cs, c)[:, 0]
+        k = view(k_ptr, nb, 1, lk, k_cs, c)[:, 0]
+        v = view(v_ptr, nb, 1, lk, v_cs, dv)[:, 0]
+        sc = torch.matmul(q, k.transpose(1, 2)) * alpha
+        if labels_ptr:
+            lab = host_array(labels_ptr, period * lk, C.c_int).view(period, lk)
+            m = torch.where(lab[:, :, None] != lab[:, None, :], torch.tensor(-100.0), torch.tensor(0.0))
+            sc = sc + m.repeat(nb // period, 1, 1)
+        view(out_ptr, nb, 1, lq, out_cs, dv)[:, 0] = torch.matmul(torch.softmax(sc, dim=-1), v)
+        self.calls["vfi_attention"] = self.calls.get("vfi_attention", 0) + 1
+        return 0
+
     # ---- layer objects (vfi_conv_create_ex / vfi_conv_forward_ex) -----------------------------------------------------
     def vfi_conv_create_ex(self, kind, w_ptr, b_ptr, cout, cin, k, stride, pad_mode, chan_map, cin_phys, prelu_ptr):
         assert pad_mode == 0 and cin_phys % 8 == 0 and cin_phys >= cin
