@@ -376,7 +376,16 @@ int conv_pick_variant(const ConvArgs& a, int stride, bool grouped) {
         if (n3) return 9;                // s2_m1n3
         return 10;                       // s2_m1n1
     }
-    if (n2) return a.Cout_p == 64 ? kConv2Base + 0 : kConv2Base + 2;  // d1_m2n2 / d1_m1n2
+    if (n2) {   // d1_m2n2 (16x16 px tile) / d1_m1n2 (16x8): the larger M tile re-uses each weight fragment twice as often
+        static const long big_px = [] {
+            // pixel count from which wide layers take m2n2: measured on FILM / M2M at 1080p (profiles/r02_film_tile_experiment.txt)
+            // 100k is the best of {never, 1.5M, 400k, 100k, 20k} — by 0.6 % only; VFI_CONV_M2N2_PX overrides (-1 = never)
+            const char* e = getenv("VFI_CONV_M2N2_PX");
+            return e && *e ? atol(e) : 100000L;
+        }();
+        if (a.Cout_p == 64 || (big_px >= 0 && px >= big_px)) return kConv2Base + 0;
+        return kConv2Base + 2;
+    }
     if (n3) return px >= 100000 || a.Cin_p % 16 ? kConv2Base + 3 : 4;  // d1_m1n3 / s1_m1n1 (K chunk 16)
     return a.Cin_p % 16 == 0 && px < 20000 ? 4 : kConv2Base + 13;      // 32-channel N tile: s1_m1n1 / d1_m2n1
 }

@@ -6,7 +6,7 @@ OUT=gpurun_out/variant_sweep.log
 : > $OUT
 run() {
   echo "=== override: $1" >> $OUT
-  VFI_VARIANT_OVERRIDE="$1" timeout 120 python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
+  VFI_VARIANT_OVERRIDE="$1" timeout 120 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-extras 2>/dev/null | python -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):
