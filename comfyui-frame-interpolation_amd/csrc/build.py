@@ -26,6 +26,7 @@ def _digest():
     h = hashlib.sha256()
     files = _sources() + sorted(glob.glob(os.path.join(CSRC, "*.h")))
     files.append(os.path.join(PKG, "..", "include", "vfi_hip.h"))
+    files.append(os.path.join(PKG, "..", "include", "vfi_hip_test.h"))
     for f in files:
         with open(f, "rb") as fh:
             h.update(os.path.basename(f).encode())  # names only: the checkout path differs on the GPU box

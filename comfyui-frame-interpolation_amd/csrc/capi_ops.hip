@@ -4,6 +4,7 @@
 #include <cstring>
 
 #include "../../include/vfi_hip.h"
+#include "../../include/vfi_hip_test.h"
 #include "rife_ops.h"
 
 using namespace vfi;

@@ -11,6 +11,7 @@
 #include <cstring>
 
 #include "../../include/vfi_hip.h"
+#include "../../include/vfi_hip_test.h"
 #include "rife_ops.h"
 
 using namespace vfi;
@@ -99,7 +100,7 @@ struct vfi_rife {
     int scales[kMaxBlocks] = {8, 4, 2, 1, 1};  // integer block scales (1 where the block scale is fractional)
     int up[kMaxBlocks] = {1, 1, 1, 1, 1};      // 1/scale for fractional block scales 0.5 / 0.25 (scale_factor 2 / 4)
     // workspace
-    DevBuf Ppool, E, F, M, X, A0, A1, A2, T;
+    DevBuf Ppool, E, F, F2, M, X, A0, A1, A2, T;   // F2: the flow's second buffer for the fused last transition
     DevBuf X1, T1;  // frame-resolution staging around blocks that run above the frame resolution
     DevBuf Fdbg[kMaxBlocks], Xdbg[kMaxBlocks];
     bool keep = false;
@@ -320,7 +321,7 @@ void vfi_rife_destroy(vfi_rife_t* net) {
         L.bias.release();
     }
     net->E2.release();
-    for (DevBuf* d : {&net->enc_w0, &net->enc_b0, &net->enc_w1, &net->enc_b1, &net->Ppool, &net->E, &net->F, &net->M,
+    for (DevBuf* d : {&net->enc_w0, &net->enc_b0, &net->enc_w1, &net->enc_b1, &net->Ppool, &net->E, &net->F, &net->F2, &net->M,
                       &net->X, &net->A0, &net->A1, &net->A2, &net->T, &net->X1, &net->T1, &net->FEAT})
         d->release();
     if (net->arena) (void)hipFree(net->arena);
@@ -387,7 +388,7 @@ int vfi_rife_configure(vfi_rife_t* net, int H, int W, int max_batch, int n_slots
     }
     // T plane 1 holds only the mask (+1 unused channel): components 2,3 are never written; keep them defined
     if (net->Ppool.ensure(net->pack_stride() * n_slots) || net->E.ensure(full / 4 * net->CM) ||
-        (net->n_mid && net->E2.ensure(full / 4 * net->CM)) || net->F.ensure(B * full * 4) ||
+        (net->n_mid && net->E2.ensure(full / 4 * net->CM)) || net->F.ensure(B * full * 4) || net->F2.ensure(B * full * 4) ||
         net->M.ensure(B * full) || net->X.ensure(B * x) || net->A0.ensure(B * a0) || net->A1.ensure(B * a1) ||
         net->A2.ensure(B * a1) || net->T.ensure(B * t))
         return -1;
@@ -477,6 +478,16 @@ int vfi_rife_interpolate(vfi_rife_t* net, int B, const int* slot0, const int* sl
     const int NB = net->nblocks, TP = net->tplanes();
     const float* feat = net->NX ? net->FEAT.p : nullptr;
     bool fused_prev = false;
+    // The last transition of the standard scale list (block scales 2 -> 1) can run fused into the next block's conv0.0
+    // (trans1_conv0a_launch: X never goes to HBM; the flow then lives in the other of two buffers).  VFI_RIFE_FUSE0A=0 turns it
+    // off (A/B measurements); the debug taps need X and keep the un-fused path.
+    static const bool fuse0a_enabled = [] {
+        const char* e = getenv("VFI_RIFE_FUSE0A");
+        return !(e && e[0] == '0');
+    }();
+    float* Fcur = net->F.p;
+    float* Falt = net->F2.p;
+    bool a0_ready = false;   // conv0.0 of this block has already been computed by the fused transition
     for (int i = 0; i < NB; ++i) {
         const int s = net->scales[i], u = net->up[i];
         const int Hs = Hp / s * u, Ws = Wp / s * u;
@@ -484,9 +495,9 @@ int vfi_rife_interpolate(vfi_rife_t* net, int B, const int* slot0, const int* sl
         const int CX = net->CX(i), NF = net->NF;
         // X of this block: block 0 has no flow yet; later blocks get X from the fused transition kernel of the
         // previous iteration when the scale list allows it (standard [8,4,2,1]), else from stage_in.
-        const bool x_ready = i > 0 && fused_prev;
+        const bool x_ready = i > 0 && (fused_prev || a0_ready);
         if (!x_ready &&
-            stage_in_launch(net->Ppool.p, net->pack_stride(), tasks, B, net->F.p, net->M.p, i > 0 ? feat : nullptr,
+            stage_in_launch(net->Ppool.p, net->pack_stride(), tasks, B, Fcur, net->M.p, i > 0 ? feat : nullptr,
                             u > 1 ? net->X1.p : net->X.p, Hp, Wp, s, CX, NF, i > 0, st))
             return -1;
         if (u > 1 && planar4_up_launch(net->X1.p, net->X.p, B, Hp, Wp, u, CX, /*flow plane*/ 2 + 2 * NF + net->NX / 4, st)) return -1;
@@ -497,12 +508,15 @@ int vfi_rife_interpolate(vfi_rife_t* net, int B, const int* slot0, const int* sl
         }
         ConvArgs a;
         // conv0.0: 3x3 stride 2 + LeakyReLU(0.2)
-        fill_args(a, net->conv00[i], net->X.p, CX, net->A0.p, c / 2, B, Hs, Ws, 2);
-        a.in_plane = Hs * Ws * 4;  // X is planar4
-        conv3x3_taps(a);
-        a.act = 1;
-        a.slope = 0.2f;
-        if (conv_launch(a, 2, false, -1, st, kC00Name[i])) return -1;
+        if (!a0_ready) {
+            fill_args(a, net->conv00[i], net->X.p, CX, net->A0.p, c / 2, B, Hs, Ws, 2);
+            a.in_plane = Hs * Ws * 4;  // X is planar4
+            conv3x3_taps(a);
+            a.act = 1;
+            a.slope = 0.2f;
+            if (conv_launch(a, 2, false, -1, st, kC00Name[i])) return -1;
+        }
+        a0_ready = false;
         // conv0.1
         fill_args(a, net->conv01[i], net->A0.p, c / 2, net->A1.p, c, B, Hs / 2, Ws / 2, 2);
         conv3x3_taps(a);
@@ -538,20 +552,29 @@ int vfi_rife_interpolate(vfi_rife_t* net, int B, const int* slot0, const int* sl
             const int sn = net->scales[i + 1];
             const bool on_grid = u == 1 && net->up[i + 1] == 1 && s == 2 * sn;
             fused_prev = on_grid && (sn == 4 || sn == 2 || sn == 1 || (net->NX && sn == 8));
-            if (fused_prev) {
-                if (net->NX ? stage_trans_x_launch(net->Ppool.p, net->pack_stride(), tasks, B, Tsrc, net->F.p, net->X.p, Hp, Wp, s, sn,
+            const bool fuse0a = fuse0a_enabled && fused_prev && sn == 1 && net->NF == 1 && !net->NX && !net->keep && i > 0 &&
+                                net->CX(i + 1) == 24 && kBlockC[i + 1] == 64 && net->conv00[i + 1].Cout_p == 32;
+            if (fuse0a) {
+                if (trans1_conv0a_launch(net->Ppool.p, net->pack_stride(), tasks, B, Tsrc, Fcur, Falt, net->conv00[i + 1].w.p,
+                                         net->conv00[i + 1].bias.p, net->A0.p, Hp, Wp, 0.2f, st))
+                    return -1;
+                std::swap(Fcur, Falt);
+                fused_prev = false;
+                a0_ready = true;
+            } else if (fused_prev) {
+                if (net->NX ? stage_trans_x_launch(net->Ppool.p, net->pack_stride(), tasks, B, Tsrc, Fcur, net->X.p, Hp, Wp, s, sn,
                                                    i > 0, st)
-                            : stage_trans_launch(net->Ppool.p, net->pack_stride(), tasks, B, Tsrc, net->F.p, net->X.p, Hp, Wp,
+                            : stage_trans_launch(net->Ppool.p, net->pack_stride(), tasks, B, Tsrc, Fcur, net->X.p, Hp, Wp,
                                                  s, sn, NF, i > 0, st))
                     return -1;
             } else {
-                if (flow_up_launch(Tsrc, net->F.p, net->M.p, B, Hp, Wp, s, TP, i > 0, st)) return -1;
+                if (flow_up_launch(Tsrc, Fcur, net->M.p, B, Hp, Wp, s, TP, i > 0, st)) return -1;
                 if (net->NX && feat_up_launch(Tsrc, net->FEAT.p, B, Hp, Wp, s, st)) return -1;
             }
             if (net->keep) {
                 const size_t n = (size_t)B * Hp * Wp * 4;
                 if (net->Fdbg[i].ensure(n)) return -1;
-                VFI_CHECK_HIP(hipMemcpyAsync(net->Fdbg[i].p, net->F.p, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+                VFI_CHECK_HIP(hipMemcpyAsync(net->Fdbg[i].p, Fcur, n * sizeof(float), hipMemcpyDeviceToDevice, st));
             }
         } else {
             float* fd = nullptr;
@@ -561,7 +584,7 @@ int vfi_rife_interpolate(vfi_rife_t* net, int B, const int* slot0, const int* sl
                 VFI_CHECK_HIP(hipMemsetAsync(net->Fdbg[i].p, 0, n * sizeof(float), st));
                 fd = net->Fdbg[i].p;
             }
-            if (final_blend_launch(net->Ppool.p, net->pack_stride(), tasks, B, Tsrc, net->F.p, out_dev, fd, net->H,
+            if (final_blend_launch(net->Ppool.p, net->pack_stride(), tasks, B, Tsrc, Fcur, out_dev, fd, net->H,
                                    net->W, Hp, Wp, s, TP, st))
                 return -1;
         }

@@ -31,6 +31,10 @@ int flow_up_launch(const float* T, float* F, float* M, int B, int Hp, int Wp, in
 int feat_up_launch(const float* T, float* FEAT, int B, int Hp, int Wp, int s, hipStream_t st);
 int stage_trans_launch(const float* Ppool, size_t pack_stride, const RifeTasks& tasks, int B, const float* T, float* F,
                        float* X, int Hp, int Wp, int s_prev, int s_next, int NF, bool has_prev, hipStream_t st);
+// last transition (scales 2 -> 1, NF = 1) fused into the next block's conv0.0 (24 -> 32 channels, stride 2, LeakyReLU):
+// reads Fin, writes the updated flow to Fout (a different buffer) and conv0.0's output A0 [B][Hp/2][Wp/2][32]; X is never stored
+int trans1_conv0a_launch(const float* Ppool, size_t pack_stride, const RifeTasks& tasks, int B, const float* T, const float* Fin,
+                         float* Fout, const float* wpk, const float* bias, float* A0, int Hp, int Wp, float slope, hipStream_t st);
 // arch 4.26 (T with 4 planes, 8 carried feature channels, NF = 1); block scales 2*s_next -> s_next, s_next in {8,4,2,1}
 int stage_trans_x_launch(const float* Ppool, size_t pack_stride, const RifeTasks& tasks, int B, const float* T, float* F,
                          float* X, int Hp, int Wp, int s_prev, int s_next, bool has_prev, hipStream_t st);

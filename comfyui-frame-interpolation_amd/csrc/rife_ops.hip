@@ -15,6 +15,9 @@
 // F.interpolate calls :238-248,263-266; input torch.cat :543-548,629-644; flow/mask update
 // :645,698-699; final blend :721-723,732; encode :414-416.
 #include "rife_ops.h"
+
+#include <algorithm>
+#include <atomic>
 #include "rife_warp.h"
 #include <cstdlib>
 
@@ -791,6 +794,146 @@ int stage_trans_launch(const float* Ppool, size_t pack_stride, const RifeTasks& 
     }
 #undef VFI_ST2
 #undef VFI_ST
+    VFI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// Last block transition (block scales 2 -> 1) FUSED INTO the next block's first convolution (conv0.0: 3x3, stride 2,
+// 20 -> 32 channels, LeakyReLU 0.2; rife_arch.py:237-249 on the input of :631-645).  The un-fused pair moves the
+// full-resolution block input X through HBM twice — stage_trans<1> writes 24 channels x 1088x1920 x 4 B = 200 MB per frame
+// and the convolution reads them back with its halo (profiles/r02_pmc_*: 3.66 GB written + 4.1 GB fetched per 16 frames,
+// 1.67 + 1.36 ms, both at HBM speed).  Here a workgroup owns a 16x8 tile of the convolution's OUTPUT: it computes the
+// 33x17-pixel patch of X that the tile needs straight into LDS — the same arithmetic as stage_trans_kernel<1> (flow update,
+// both warps of image + features, timestep / mask / flow channels), pixels outside the image = the convolution's zero
+// padding — and multiplies it on the fp32 matrix cores against the layer's weights, which stay in registers (27 K-steps x 4
+// floats per lane) for all the tiles the persistent workgroup walks.  X never exists in HBM.
+// The flow update cannot be in place any more (a tile's halo pixels belong to its neighbours, which may already have
+// updated them): the new flow goes to a second buffer and the caller swaps.
+// ---------------------------------------------------------------------------------------
+constexpr int F0_TWO = 16, F0_THO = 8;                    // output tile (pixels of the stride-2 convolution)
+constexpr int F0_TWI = 2 * F0_TWO + 1, F0_THI = 2 * F0_THO + 1;   // 33 x 17 input patch incl. the 1-pixel halo (top / left)
+constexpr int F0_NPIX = F0_TWI * F0_THI;                  // 561
+constexpr int F0_S = 24 + 4;                              // LDS pixel stride in floats (S/4 odd: conflict-free b128 reads)
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void trans1_conv0a_kernel(const float* __restrict__ Ppool, size_t pack_stride, RifeTasks tasks,
+                                                            const float* __restrict__ T, const float* __restrict__ Fin,
+                                                            float* __restrict__ Fout, const float* __restrict__ wpk,
+                                                            const float* __restrict__ bias, float* __restrict__ A0, int Hp,
+                                                            int Wp, int n_tiles, int tiles_x, int tiles_y, float slope) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(16))) float lds[F0_NPIX * F0_S];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int Ho = Hp / 2, Wo = Wp / 2;
+    const int Hi = Hp / 2, Wi = Wp / 2;          // resolution of the pixel-shuffled T of the scale-2 block
+    // ---- this lane's B fragments: weights packed [tap][Cin/8][32][8]; lanes 0-31 take channels c..c+3, 32-63 c+4..c+7
+    f32x4_t wreg[27];
+#pragma unroll
+    for (int st = 0; st < 27; ++st) wreg[st] = *(const f32x4_t*)(wpk + ((size_t)st * 32 + l31) * 8 + half * 4);
+    const float bs = bias[l31];
+    // A fragment base: sub-tile s = wave (2 x 2 sub-tiles of 8 x 4 pixels), tap origin (-1, -1) folded in
+    const int sx = wave & 1, sy = wave >> 1;
+    const int oyl = sy * 4 + (l31 >> 3), oxl = sx * 8 + (l31 & 7);
+    const int abase = ((2 * oyl) * F0_TWI + 2 * oxl) * F0_S + half * 4;
+    const size_t hi_off = (size_t)Hp * Wp * 4;
+    const WarpGeo g = make_warp_geo(Wp, Hp);
+    const int tiles_per_img = tiles_x * tiles_y;
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int b = tile / tiles_per_img;
+        const int trem = tile - b * tiles_per_img;
+        const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+        const int Y0 = ty * F0_THO, X0 = tx * F0_TWO;
+        const int iy0 = 2 * Y0 - 1, ix0 = 2 * X0 - 1;
+        const float* Tb = T + (size_t)b * Hi * Wi * 8;
+        const float* P0 = Ppool + (size_t)tasks.slot0[b] * pack_stride;
+        const float* P1 = Ppool + (size_t)tasks.slot1[b] * pack_stride;
+        const float tstep = tasks.t[b];
+        // ---- phase A: the X patch (stage_trans_kernel<1, true, 1> per pixel)
+#pragma unroll
+        for (int it = 0; it < (F0_NPIX + 255) / 256; ++it) {      // 3 pixels per thread, unrolled: their gathers overlap
+            const int p = tid + 256 * it;
+            if (p >= F0_NPIX) break;
+            const int py = p / F0_TWI, px = p - py * F0_TWI;
+            const int Y = iy0 + py, X = ix0 + px;
+            float r[24];
+#pragma unroll
+            for (int c = 0; c < 24; ++c) r[c] = 0.f;
+            if (Y >= 0 && X >= 0 && Y < Hp && X < Wp) {
+                const Bil by = bil_index(Y, 0.5f, Hi), bx = bil_index(X, 0.5f, Wi);
+                const TVal v = t_bilerp(t_read(Tb, Hi, Wi, by.i0, bx.i0), t_read(Tb, Hi, Wi, by.i0, bx.i1), t_read(Tb, Hi, Wi, by.i1, bx.i0),
+                                        t_read(Tb, Hi, Wi, by.i1, bx.i1), by.w0, by.w1, bx.w0, bx.w1);
+                const size_t pb = (size_t)b * Hp * Wp + (size_t)Y * Wp + X;
+                const float4 o4 = ((const float4*)Fin)[pb];
+                const float4 f = make_float4(o4.x + v.f.x * 2.0f, o4.y + v.f.y * 2.0f, o4.z + v.f.z * 2.0f, o4.w + v.f.w * 2.0f);
+                if (py >= 1 && px >= 1) ((float4*)Fout)[pb] = f;        // this tile owns rows 2*Y0.. and columns 2*X0..
+                const Tap4 t0 = warp_taps(g, X, Y, f.x, f.y);
+                const Tap4 t1 = warp_taps(g, X, Y, f.z, f.w);
+                float4 a_lo, b_lo, a_hi[1], b_hi[1];
+                sample_pack<1>(P0, hi_off, t0, a_lo, a_hi);
+                sample_pack<1>(P1, hi_off, t1, b_lo, b_hi);
+                cat_inputs<1>(r, a_lo, b_lo, a_hi, b_hi, tstep);   // channels 0..14: img0, img1, feat0, feat1, timestep
+                r[15] = v.m;
+                r[16] = f.x, r[17] = f.y, r[18] = f.z, r[19] = f.w;     // interpolate(flow, 1/1) * 1/1
+            }
+            float* d = &lds[p * F0_S];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) *(float4*)(d + 4 * q) = make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
+        }
+        __syncthreads();
+        // ---- phase B: 128 output pixels x 32 channels, K = 9 taps x 24 channels
+        f32x16_t acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int toff = ((t / 3) * F0_TWI + (t % 3)) * F0_S;
+#pragma unroll
+            for (int c8 = 0; c8 < 3; ++c8) {
+                const f32x4_t av = *(const f32x4_t*)&lds[abase + toff + c8 * 8];
+                const f32x4_t bv = wreg[t * 3 + c8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
+            }
+        }
+        // ---- epilogue: + bias, LeakyReLU, NHWC store (32 lanes = 128 contiguous bytes per pixel)
+        {
+            const int oy0 = Y0 + sy * 4, ox0 = X0 + sx * 8 + 4 * half;
+            float* ob = A0 + ((size_t)(b * Ho + oy0) * Wo + ox0) * 32 + l31;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float v = acc[i] + bs;
+                ob[((size_t)(i >> 2) * Wo + (i & 3)) * 32] = fmaxf(v, v * slope);
+            }
+        }
+        __syncthreads();   // the patch is consumed; the next tile may overwrite it
+    }
+#endif
+}
+
+int trans1_conv0a_launch(const float* Ppool, size_t pack_stride, const RifeTasks& tasks, int B, const float* T, const float* Fin,
+                         float* Fout, const float* wpk, const float* bias, float* A0, int Hp, int Wp, float slope, hipStream_t st) {
+    VFI_REQUIRE(Hp % 32 == 0 && Wp % 32 == 0 && slope >= 0.f && slope <= 1.f, "trans1_conv0a: bad geometry %dx%d / slope %g", Hp, Wp, slope);
+    const int tiles_x = (Wp / 2) / F0_TWO, tiles_y = (Hp / 2) / F0_THO;
+    const int n_tiles = B * tiles_x * tiles_y;
+    static std::atomic<int> cus_of[kMaxDevices];
+    int dev = 0;
+    VFI_CHECK_HIP(hipGetDevice(&dev));
+    VFI_REQUIRE(dev >= 0 && dev < kMaxDevices, "trans1_conv0a: device index %d out of range", dev);
+    int cus = cus_of[dev].load(std::memory_order_relaxed);
+    if (!cus) {
+        hipDeviceProp_t p;
+        VFI_CHECK_HIP(hipGetDeviceProperties(&p, dev));
+        cus = p.multiProcessorCount;
+        cus_of[dev].store(cus, std::memory_order_relaxed);
+    }
+    const int grid = std::min(n_tiles, 2 * cus);      // 62.8 KB of LDS: two workgroups per CU, each walks its share of the tiles
+    TraceScope ts("trans1_conv0a", st);
+    hipLaunchKernelGGL(trans1_conv0a_kernel, dim3(grid), dim3(256), 0, st, Ppool, pack_stride, tasks, T, Fin, Fout, wpk, bias, A0, Hp, Wp,
+                       n_tiles, tiles_x, tiles_y, slope);
     VFI_CHECK_HIP(hipGetLastError());
     return 0;
 }

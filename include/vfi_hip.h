@@ -62,11 +62,6 @@ int vfi_conv3x3(const float* in_dev, const float* weight_host, const float* bias
                 const float* beta_host, float* out_dev, int N, int H, int W, int Cin, int Cout,
                 int stride, int act, float slope, int variant, void* stream);
 
-/* Same contract, straightforward one-thread-per-output FMA kernel (cross-check of the MFMA path). */
-int vfi_conv3x3_naive(const float* in_dev, const float* weight_host, const float* bias_host,
-                      const float* beta_host, float* out_dev, int N, int H, int W, int Cin,
-                      int Cout, int stride, int act, float slope, void* stream);
-
 /* ConvTranspose2d(Cin, Cout, 4, stride 2, pad 1) followed by PixelShuffle(2), output NHWC
  * [N,4H,4W,Cout/4].  Replaces IFBlock.lastconv, vfi_models/rife/rife_arch.py:215-218.
  *   weight: reference layout [Cin,Cout,4,4] (host). */
@@ -363,12 +358,14 @@ int vfi_f32_to_u8(const float* in_dev, uint8_t* out_dev, int64_t n, void* stream
 int vfi_rife_interpolate(vfi_rife_t* net, int B, const int* slot0, const int* slot1,
                          const float* timestep, float* out_dev, void* stream);
 
-/* Debug taps for parity tests: copy internal tensors of the LAST interpolate call to host.
- * what: 0 = flow after stage `stage` [B,Hp,Wp,4];  1 = stage input X of `stage`, planar4 [B,Cx/4,Hs,Ws,4];
- *       2 = frame slot pack, planar4 [2,Hp,Wp,4] = (rgb0 | encode features) (stage = slot).
- * Returns number of floats written or <0. */
-int64_t vfi_rife_debug_read(vfi_rife_t* net, int what, int stage, float* host_buf, int64_t cap);
-int vfi_rife_debug_keep(vfi_rife_t* net, int on);
+/* The whole node call for a HOST clip, for hosts that do not want to re-implement the node loop:
+ * frames_host [N,H,W,C] fp32 (C >= 3; alpha dropped) -> out_host [*n_out,H,W,3]: frame_0, its new frames, frame_1, ...,
+ * frame_last (rife/__init__.py:225-230).  multipliers [N-1] (NULL = 2 everywhere; m <= 1 keeps the frame), skip [N-1] flags
+ * (NULL = none; a skipped pair keeps the frame) as rife/__init__.py:149-174; scale_factor as the widget; `batch` tasks per
+ * launch (1..16).  out_host == NULL only computes *n_out.  Synchronous; configures `net` itself; uses its own streams and
+ * pinned staging.  Replaces RIFE_VFI.vfi's body, vfi_models/rife/__init__.py:149-239. */
+int vfi_rife_run(vfi_rife_t* net, const float* frames_host, int N, int H, int W, int C, const int* multipliers,
+                 const uint8_t* skip, float scale_factor, int batch, float* out_host, int64_t* n_out);
 
 /* Work done by one interpolate call for roofline accounting (algorithmic, per task). */
 int vfi_rife_work(vfi_rife_t* net, double* conv_flop_per_task, double* hbm_bytes_per_task);

@@ -1,0 +1,34 @@
+/*
+ * vfi_hip_test.h — TEST TAPS of libvfi_hip.so: entry points that exist for the parity tests only (a naive cross-check
+ * convolution, read-back of internal tensors of the RIFE network).  Not part of the drop-in boundary: nothing in the node
+ * classes' product path calls them; they are declared apart from include/vfi_hip.h so that the boundary header lists only
+ * what a host application binds.  (Per-kernel tracing, vfi_trace_*, and vfi_rife_work stay in vfi_hip.h: bench.py's
+ * roofline figures are part of the deliverable.)
+ */
+#ifndef VFI_HIP_TEST_H
+#define VFI_HIP_TEST_H
+
+#include "vfi_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Same contract as vfi_conv3x3, straightforward one-thread-per-output FMA kernel (cross-check of the MFMA path). */
+int vfi_conv3x3_naive(const float* in_dev, const float* weight_host, const float* bias_host,
+                      const float* beta_host, float* out_dev, int N, int H, int W, int Cin,
+                      int Cout, int stride, int act, float slope, void* stream);
+
+
+/* Debug taps for parity tests: copy internal tensors of the LAST interpolate call to host.
+ * what: 0 = flow after stage `stage` [B,Hp,Wp,4];  1 = stage input X of `stage`, planar4 [B,Cx/4,Hs,Ws,4];
+ *       2 = frame slot pack, planar4 [2,Hp,Wp,4] = (rgb0 | encode features) (stage = slot).
+ * Returns number of floats written or <0. */
+int64_t vfi_rife_debug_read(vfi_rife_t* net, int what, int stage, float* host_buf, int64_t cap);
+int vfi_rife_debug_keep(vfi_rife_t* net, int on);
+
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VFI_HIP_TEST_H */

@@ -8,15 +8,16 @@ from cfi_amd import _lib, rife_spec
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_functions():
-    src = open(os.path.join(ROOT, "include", "vfi_hip.h")).read()
+def header_functions(name="vfi_hip.h"):
+    src = open(os.path.join(ROOT, "include", name)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(vfi_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_header_and_binding_agree(hip_lib):
-    names = header_functions()
-    assert len(names) >= 15
+    product, taps = header_functions(), header_functions("vfi_hip_test.h")
+    names = sorted(product + taps)
+    assert len(product) >= 15 and taps == ["vfi_conv3x3_naive", "vfi_rife_debug_keep", "vfi_rife_debug_read"]   # test taps live apart
     assert sorted(_lib.PROTOTYPES) == names
     for n in names:
         assert getattr(hip_lib, n) is not None

@@ -684,3 +684,64 @@ def test_node_uint8_clip(hip_lib, sd, tmp_path, monkeypatch):
     assert torch.equal(out, want), f"{(out.int() - want.int()).abs().max().item()} levels"
     for i in range(6):
         assert torch.equal(out[3 * i], u8[i, ..., :3])
+
+
+def test_whole_clip_c_entry_point(hip_lib, sd, tmp_path, monkeypatch):
+    """vfi_rife_run: the node call behind ONE C entry point (host clip in, host clip out) against the Python node — list
+    multipliers incl. 1 and 4, a skipped pair, RGBA input, more frames than the staging ring has slots."""
+    import ctypes as C
+
+    import cfi_amd.rife as R
+    from cfi_amd import _lib
+
+    pth = tmp_path / "rife47.pth"
+    torch.save(sd, pth)
+    monkeypatch.setattr(R, "load_file_from_github_release", lambda model_type, ckpt: str(pth))
+    frames = torch.cat([synth.smooth_frames(4, 100, 150, seed=s_, shift=2.0, c=4) for s_ in (1, 2, 3)]).contiguous()   # 12 RGBA frames
+    mult = [2, 3, 1, 4, 2, 2, 2, 3, 2, 2, 2]
+    states = InterpolationStateList([4], True)
+    (want,) = R.RIFE_VFI().vfi("rife47.pth", frames, multiplier=mult, batch_size=8, optional_interpolation_states=states)
+    eng = R.RifeEngine(sd, "4.7")
+    try:
+        m = (C.c_int * 11)(*mult)
+        skip = (C.c_uint8 * 11)(*[1 if i == 4 else 0 for i in range(11)])
+        n_out = C.c_int64(0)
+        _lib.check(hip_lib.vfi_rife_run(eng.handle, None, 12, 100, 150, 4, m, skip, 1.0, 8, None, C.byref(n_out)), "vfi_rife_run (size)")
+        assert n_out.value == want.shape[0]
+        out = torch.full((n_out.value, 100, 150, 3), float("nan"))
+        _lib.check(hip_lib.vfi_rife_run(eng.handle, frames.data_ptr(), 12, 100, 150, 4, m, skip, 1.0, 8, out.data_ptr(), C.byref(n_out)),
+                   "vfi_rife_run")
+    finally:
+        eng.close()
+    assert not torch.isnan(out).any()
+    assert (out - want).abs().max().item() <= 2e-5, describe_diff(out, want, "vfi_rife_run vs the node")
+    src = [i for i in range(want.shape[0]) if any(torch.equal(want[i], frames[j, ..., :3]) for j in range(12))]
+    assert len(src) == 12 and all(torch.equal(out[i], want[i]) for i in src)
+
+
+@pytest.mark.parametrize("h,w,bs", [(128, 192, 1), (270, 480, 3), (1080, 1920, 2)])
+def test_fused_last_transition_matches_unfused(hip_lib, sd, h, w, bs):
+    """trans1_conv0a (block transition 2 -> 1 fused into block 3's conv0.0, X never in HBM, flow ping-pong) against the
+    un-fused kernels — which the debug taps force (they need X) — and against the oracle."""
+    from cfi_amd.rife import RifeEngine, run_tasks
+
+    eng = RifeEngine(sd, "4.7")
+    try:
+        frames = synth.smooth_frames(bs + 1, h, w, seed=h + bs, shift=3.0)
+        tasks = [(p, 0.5 if p % 2 == 0 else 0.3) for p in range(bs)]
+        fused = run_tasks(eng, frames, tasks, batch_size=bs)
+        eng.debug_keep(True)
+        unfused = run_tasks(eng, frames, tasks, batch_size=bs)
+        eng.debug_keep(False)
+        again = run_tasks(eng, frames, tasks, batch_size=bs)
+    finally:
+        eng.close()
+    assert torch.equal(fused, again), "fused path not deterministic / state left behind by the un-fused run"
+    # (different summation order in conv0.0; the later blocks amplify rounding noise a little: 5e-5 at 1080p)
+    assert (fused - unfused).abs().max().item() <= 2e-4, describe_diff(fused, unfused, "fused vs un-fused last transition")
+    if h <= 270:
+        x = frames.permute(0, 3, 1, 2)
+        with torch.inference_mode():
+            want = torch.cat([rife_oracle.ifnet47_forward(sd, x[p:p + 1], x[p + 1:p + 2], torch.tensor([t]).view(1, 1, 1, 1)) for p, t in tasks])
+        want = want.permute(0, 2, 3, 1).clamp(0, 1)
+        assert (fused - want).abs().max().item() <= 1e-3, describe_diff(fused, want, "fused path vs oracle")
