@@ -814,30 +814,38 @@ int stage_trans_launch(const float* Ppool, size_t pack_stride, const RifeTasks& 
 constexpr int F0_TWO = 16, F0_THO = 8;                    // output tile (pixels of the stride-2 convolution)
 constexpr int F0_TWI = 2 * F0_TWO + 1, F0_THI = 2 * F0_THO + 1;   // 33 x 17 input patch incl. the 1-pixel halo (top / left)
 constexpr int F0_NPIX = F0_TWI * F0_THI;                  // 561
-constexpr int F0_S = 24 + 4;                              // LDS pixel stride in floats (S/4 odd: conflict-free b128 reads)
+// LDS pixel stride = the 20 real channels (S/4 odd: conflict-free b128 reads).  The third 8-channel K chunk reads channels
+// 16..23 of a pixel, i.e. 4 floats of the NEXT pixel for lanes 32-63: finite values that meet the zero weights of the padded
+// input channels 20..23 (the last pixel's over-read lands in the weight image that follows the patch in LDS).
+constexpr int F0_S = 20;
+constexpr int F0_XF = F0_NPIX * F0_S;                     // floats of the patch
+constexpr int F0_WF = 27 * 32 * 8;                        // floats of the layer's packed weights [tap][Cin/8][32][8]
+constexpr int F0_THREADS = 512;
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void trans1_conv0a_kernel(const float* __restrict__ Ppool, size_t pack_stride, RifeTasks tasks,
-                                                            const float* __restrict__ T, const float* __restrict__ Fin,
-                                                            float* __restrict__ Fout, const float* __restrict__ wpk,
-                                                            const float* __restrict__ bias, float* __restrict__ A0, int Hp,
-                                                            int Wp, int n_tiles, int tiles_x, int tiles_y, float slope) {
+// 8 waves: phase A has one patch pixel per thread (+ the 49 halo pixels on a second, overlapped round); in phase B wave w
+// multiplies sub-tile (w & 3) over one half of the 27 K-steps (w >> 2), the halves are added through LDS.
+__global__ __launch_bounds__(F0_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void trans1_conv0a_kernel(const float* __restrict__ Ppool, size_t pack_stride, RifeTasks tasks,
+                                                                   const float* __restrict__ T, const float* __restrict__ Fin,
+                                                                   float* __restrict__ Fout, const float* __restrict__ wpk,
+                                                                   const float* __restrict__ bias, float* __restrict__ A0, int Hp,
+                                                                   int Wp, int n_tiles, int tiles_x, int tiles_y, float slope) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ __attribute__((aligned(16))) float lds[F0_NPIX * F0_S];
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // F0_XF floats of patch, then F0_WF floats of weights
+    float* wl = lds + F0_XF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int Ho = Hp / 2, Wo = Wp / 2;
     const int Hi = Hp / 2, Wi = Wp / 2;          // resolution of the pixel-shuffled T of the scale-2 block
-    // ---- this lane's B fragments: weights packed [tap][Cin/8][32][8]; lanes 0-31 take channels c..c+3, 32-63 c+4..c+7
-    f32x4_t wreg[27];
-#pragma unroll
-    for (int st = 0; st < 27; ++st) wreg[st] = *(const f32x4_t*)(wpk + ((size_t)st * 32 + l31) * 8 + half * 4);
+    for (int i = tid; i < F0_WF / 4; i += F0_THREADS) ((float4*)wl)[i] = ((const float4*)wpk)[i];   // once per persistent workgroup
     const float bs = bias[l31];
-    // A fragment base: sub-tile s = wave (2 x 2 sub-tiles of 8 x 4 pixels), tap origin (-1, -1) folded in
-    const int sx = wave & 1, sy = wave >> 1;
+    // A fragment base: sub-tile (2 x 2 sub-tiles of 8 x 4 pixels), tap origin (-1, -1) folded in
+    const int sub = wave & 3, khalf = wave >> 2;
+    const int sx = sub & 1, sy = sub >> 1;
     const int oyl = sy * 4 + (l31 >> 3), oxl = sx * 8 + (l31 & 7);
     const int abase = ((2 * oyl) * F0_TWI + 2 * oxl) * F0_S + half * 4;
+    const int bbase = l31 * 8 + half * 4;
     const size_t hi_off = (size_t)Hp * Wp * 4;
     const WarpGeo g = make_warp_geo(Wp, Hp);
     const int tiles_per_img = tiles_x * tiles_y;
@@ -853,15 +861,15 @@ __global__ __launch_bounds__(256) void trans1_conv0a_kernel(const float* __restr
         const float* P1 = Ppool + (size_t)tasks.slot1[b] * pack_stride;
         const float tstep = tasks.t[b];
         // ---- phase A: the X patch (stage_trans_kernel<1, true, 1> per pixel)
-#pragma unroll
-        for (int it = 0; it < (F0_NPIX + 255) / 256; ++it) {      // 3 pixels per thread, unrolled: their gathers overlap
-            const int p = tid + 256 * it;
+#pragma unroll 1
+        for (int it = 0; it < 2; ++it) {
+            const int p = tid + F0_THREADS * it;
             if (p >= F0_NPIX) break;
             const int py = p / F0_TWI, px = p - py * F0_TWI;
             const int Y = iy0 + py, X = ix0 + px;
-            float r[24];
+            float r[20];
 #pragma unroll
-            for (int c = 0; c < 24; ++c) r[c] = 0.f;
+            for (int c = 0; c < 20; ++c) r[c] = 0.f;
             if (Y >= 0 && X >= 0 && Y < Hp && X < Wp) {
                 const Bil by = bil_index(Y, 0.5f, Hi), bx = bil_index(X, 0.5f, Wi);
                 const TVal v = t_bilerp(t_read(Tb, Hi, Wi, by.i0, bx.i0), t_read(Tb, Hi, Wi, by.i0, bx.i1), t_read(Tb, Hi, Wi, by.i1, bx.i0),
@@ -881,35 +889,42 @@ __global__ __launch_bounds__(256) void trans1_conv0a_kernel(const float* __restr
             }
             float* d = &lds[p * F0_S];
 #pragma unroll
-            for (int q = 0; q < 6; ++q) *(float4*)(d + 4 * q) = make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
+            for (int q = 0; q < 5; ++q) *(float4*)(d + 4 * q) = make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
         }
         __syncthreads();
-        // ---- phase B: 128 output pixels x 32 channels, K = 9 taps x 24 channels
+        // ---- phase B: 128 output pixels x 32 channels, K = 9 taps x 24 channels; this wave: K-steps [14 khalf, 14 khalf + 14)
         f32x16_t acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int toff = ((t / 3) * F0_TWI + (t % 3)) * F0_S;
-#pragma unroll
-            for (int c8 = 0; c8 < 3; ++c8) {
+        for (int k = 0; k < 14; ++k) {
+            const int st = khalf * 14 + k;
+            if (st < 27) {
+                const int t = st / 3, c8 = st - 3 * t;
+                const int toff = ((t / 3) * F0_TWI + (t % 3)) * F0_S;
                 const f32x4_t av = *(const f32x4_t*)&lds[abase + toff + c8 * 8];
-                const f32x4_t bv = wreg[t * 3 + c8];
+                const f32x4_t bv = *(const f32x4_t*)&wl[st * 256 + bbase];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
             }
+            if (k & 1) __builtin_amdgcn_sched_barrier(0);    // at most two steps' fragments in flight (register budget: 128)
         }
-        // ---- epilogue: + bias, LeakyReLU, NHWC store (32 lanes = 128 contiguous bytes per pixel)
-        {
+        __syncthreads();   // the patch is consumed: its LDS now carries the upper K-half's partial sums
+        f32x16_t* red = (f32x16_t*)lds;
+        if (khalf) red[sub * 64 + lane] = acc;
+        __syncthreads();
+        if (!khalf) {
+            const f32x16_t other = red[sub * 64 + lane];
+            // ---- epilogue: + bias, LeakyReLU, NHWC store (32 lanes = 128 contiguous bytes per pixel)
             const int oy0 = Y0 + sy * 4, ox0 = X0 + sx * 8 + 4 * half;
             float* ob = A0 + ((size_t)(b * Ho + oy0) * Wo + ox0) * 32 + l31;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float v = acc[i] + bs;
+                const float v = (acc[i] + other[i]) + bs;
                 ob[((size_t)(i >> 2) * Wo + (i & 3)) * 32] = fmaxf(v, v * slope);
             }
         }
-        __syncthreads();   // the patch is consumed; the next tile may overwrite it
+        __syncthreads();   // the partial sums are consumed; the next tile may overwrite the patch
     }
 #endif
 }
@@ -930,9 +945,15 @@ int trans1_conv0a_launch(const float* Ppool, size_t pack_stride, const RifeTasks
         cus = p.multiProcessorCount;
         cus_of[dev].store(cus, std::memory_order_relaxed);
     }
-    const int grid = std::min(n_tiles, 2 * cus);      // 62.8 KB of LDS: two workgroups per CU, each walks its share of the tiles
+    // 72.5 KB of LDS (patch 44.9 + weights 27.6) and 512 threads: two workgroups per CU, each walks its share of the tiles
+    static bool attr_set[kMaxDevices] = {};
+    if (!attr_set[dev]) {
+        VFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trans1_conv0a_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (F0_XF + F0_WF) * 4));
+        attr_set[dev] = true;
+    }
+    const int grid = std::min(n_tiles, 2 * cus);
     TraceScope ts("trans1_conv0a", st);
-    hipLaunchKernelGGL(trans1_conv0a_kernel, dim3(grid), dim3(256), 0, st, Ppool, pack_stride, tasks, T, Fin, Fout, wpk, bias, A0, Hp, Wp,
+    hipLaunchKernelGGL(trans1_conv0a_kernel, dim3(grid), dim3(F0_THREADS), (F0_XF + F0_WF) * 4, st, Ppool, pack_stride, tasks, T, Fin, Fout, wpk, bias, A0, Hp, Wp,
                        n_tiles, tiles_x, tiles_y, slope);
     VFI_CHECK_HIP(hipGetLastError());
     return 0;
