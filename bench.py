@@ -8,7 +8,8 @@
 
 One "step" = one pass of the hot path over one batch of a synthetic 1080p frame-pair stream that is
 already resident in HBM: for each of B new frames  clamp/pad/encode (vfi_rife_load_frame)  and for
-each of the B frame pairs one interpolation at t=0.5 (vfi_rife_interpolate) — B new frames per step,
+each of the B frame pairs one interpolation at t=0.5 (vfi_rife_interpolate) — B new frames per step (default B = 32: one
+pass over the whole 33-frame clip of SURVEY 8d config 2),
 outputs written to HBM.  N>1: every rank runs its own stream (weak scaling, pairs are independent)
 and the new frames are all-gathered over RCCL/xGMI, overlapped with the next step.
 
@@ -37,6 +38,16 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip table
+
+
+def clip_frames(B):
+    """Frames of the resident synthetic clip: SURVEY 8(d) config 2's 33 at the default batch of 32 pairs per step."""
+    return B + 1 if B > 16 else 2 * B + 1
+
+
+def clip_base(B, k):
+    """First frame of step parity k: the whole clip every step for B > 16, alternating halves otherwise."""
+    return 0 if B > 16 else B * k
 
 
 def host_cpu_model():
@@ -227,7 +238,7 @@ def main_single_process(args):
     group = multidev.RifeDeviceGroup(sd, "4.7", devices)
     comm = group.comm if group.comm is not None else multidev.Comm(devices)      # N = 1: the degenerate clique, same calls
     gather = not args.no_gather
-    n_clip = 2 * B + 1
+    n_clip = clip_frames(B)
     raw, bufs = [None] * N, [None] * N
     for r in devices:
         torch.cuda.set_device(r)
@@ -249,7 +260,7 @@ def main_single_process(args):
         eng = group.engines[r]
         if ev_gath[r][k] is not None:
             main.wait_event(ev_gath[r][k])           # this buffer's previous all-gather has finished
-        base = B * k
+        base = clip_base(B, k)
         for j in range(B + 1):
             eng.load_frame(j, raw[r][base + j])
         eng.interpolate(slot0, slot1, ts, bufs[r][k][r * B:(r + 1) * B])
@@ -310,7 +321,7 @@ def main_single_process(args):
     t0 = time.perf_counter()
     for i in range(K):
         for j in range(B + 1):
-            eng0.load_frame(j, raw[0][B * (i & 1) + j])
+            eng0.load_frame(j, raw[0][clip_base(B, i & 1) + j])
         eng0.interpolate(slot0, slot1, ts, bufs[0][i & 1][:B])
     torch.cuda.synchronize(0)
     traced = time.perf_counter() - t0
@@ -365,7 +376,7 @@ def result_line(args, world, elapsed, traced, rep, eng, collective):
         "data": "synthetic",
         "config": {
             "workload": f"RIFE 4.7 2x, {H}x{W} synthetic frame-pair stream, {B} pairs/step/GPU resident in HBM "
-                        f"(BASELINE.json configs[1]; SURVEY 8d config 2 clip: {2 * B + 1} frames torch.manual_seed(0) torch.rand); "
+                        f"(BASELINE.json configs[1]; SURVEY 8d config 2 clip: {clip_frames(B)} frames torch.manual_seed(0) torch.rand); "
                         f"seeded random-init weights",
             "pairs_per_step_per_gpu": B,
             "per_gpu_frames_per_s": round(B * K / elapsed, 3),
@@ -395,7 +406,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("VFI_BENCH_BATCH", "16")), help="frame pairs per step per GPU")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("VFI_BENCH_BATCH", "32")), help="frame pairs per step per GPU (1..32)")
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -445,10 +456,10 @@ def main():
     n_slots = B + 1
     eng.configure(H, W, B, max(n_slots, 2), 1.0)
 
-    # synthetic stream, resident in HBM before timing: SURVEY 8(d) config 2's clip — 2B+1 frames (33 at the default batch),
-    # torch.manual_seed(0) torch.rand i.i.d. U[0,1) (seed + rank for N>1) — walked B pairs per step: step i interpolates pairs
-    # (b, b+1) for b in [B*(i&1), B*(i&1) + B)
-    n_clip = 2 * B + 1
+    # synthetic stream, resident in HBM before timing: SURVEY 8(d) config 2's clip — 33 frames at the default batch (32 pairs =
+    # the whole clip per step; 2B+1 frames walked in two halves for B <= 16), torch.manual_seed(0) torch.rand i.i.d. U[0,1)
+    # (seed + rank for N>1)
+    n_clip = clip_frames(B)
     g = torch.Generator(device="cpu").manual_seed(rank)
     raw = torch.rand((n_clip, H, W, 3), generator=g, dtype=torch.float32).to(dev)
     outs = [torch.empty((B, H, W, 3), dtype=torch.float32, device=dev) for _ in range(2)]
@@ -466,7 +477,7 @@ def main():
             pending[k] = None
         # Every frame of the step is prepared + encoded inside the timed region: B + 1 frames for B pairs (in a real clip the
         # first one would be the previous step's last and already resident: one frame more work than the node does).
-        base = B * k
+        base = clip_base(B, k)
         for j in range(B + 1):
             eng.load_frame(j, raw[base + j])
         eng.interpolate(slot0, slot1, ts, outs[k])

@@ -4,7 +4,7 @@
 
 namespace vfi {
 
-constexpr int kMaxTasks = 16;  // tasks per launch (kernel-argument table)
+constexpr int kMaxTasks = 32;  // tasks per launch (kernel-argument table: 384 bytes)
 struct RifeTasks {
     int slot0[kMaxTasks];
     int slot1[kMaxTasks];

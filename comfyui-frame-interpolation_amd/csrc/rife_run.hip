@@ -102,7 +102,7 @@ void copy_rgb(float* dst, const float* src, size_t px, int C) {
 extern "C" int vfi_rife_run(vfi_rife_t* net, const float* frames_host, int N, int H, int W, int C, const int* multipliers,
                             const uint8_t* skip, float scale_factor, int batch, float* out_host, int64_t* n_out) {
     VFI_REQUIRE(net && n_out && N >= 1 && H > 0 && W > 0 && C >= 3, "vfi_rife_run: bad arguments (N=%d H=%d W=%d C=%d)", N, H, W, C);
-    VFI_REQUIRE(batch >= 1 && batch <= 16, "vfi_rife_run: batch %d outside 1..16", batch);
+    VFI_REQUIRE(batch >= 1 && batch <= 32, "vfi_rife_run: batch %d outside 1..32", batch);
     // ---- schedule (rife/__init__.py:149-174) and output rows (:225-230)
     std::vector<Task> tasks;
     std::vector<int64_t> src_row(N);
@@ -182,8 +182,8 @@ extern "C" int vfi_rife_run(vfi_rife_t* net, const float* frames_host, int N, in
             VFI_CHECK_HIP(hipEventRecord(w.up_consumed[r], w.st));
             up_used[r] = 1;
         }
-        int s0[16], s1[16];
-        float ts[16];
+        int s0[32], s1[32];
+        float ts[32];
         for (size_t i = 0; i < nb; ++i) {
             s0[i] = slot_of[tasks[pos + i].pair];
             s1[i] = slot_of[tasks[pos + i].pair + 1];

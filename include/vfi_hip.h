@@ -362,7 +362,7 @@ int vfi_rife_interpolate(vfi_rife_t* net, int B, const int* slot0, const int* sl
  * frames_host [N,H,W,C] fp32 (C >= 3; alpha dropped) -> out_host [*n_out,H,W,3]: frame_0, its new frames, frame_1, ...,
  * frame_last (rife/__init__.py:225-230).  multipliers [N-1] (NULL = 2 everywhere; m <= 1 keeps the frame), skip [N-1] flags
  * (NULL = none; a skipped pair keeps the frame) as rife/__init__.py:149-174; scale_factor as the widget; `batch` tasks per
- * launch (1..16).  out_host == NULL only computes *n_out.  Synchronous; configures `net` itself; uses its own streams and
+ * launch (1..32).  out_host == NULL only computes *n_out.  Synchronous; configures `net` itself; uses its own streams and
  * pinned staging.  Replaces RIFE_VFI.vfi's body, vfi_models/rife/__init__.py:149-239. */
 int vfi_rife_run(vfi_rife_t* net, const float* frames_host, int N, int H, int W, int C, const int* multipliers,
                  const uint8_t* skip, float scale_factor, int batch, float* out_host, int64_t* n_out);
