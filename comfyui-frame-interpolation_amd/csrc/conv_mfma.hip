@@ -378,10 +378,12 @@ int conv_pick_variant(const ConvArgs& a, int stride, bool grouped) {
     }
     if (n2) {   // d1_m2n2 (16x16 px tile) / d1_m1n2 (16x8): the larger M tile re-uses each weight fragment twice as often
         static const long big_px = [] {
-            // pixel count from which wide layers take m2n2: measured on FILM / M2M at 1080p (profiles/r02_film_tile_experiment.txt)
-            // 100k is the best of {never, 1.5M, 400k, 100k, 20k} — by 0.6 % only; VFI_CONV_M2N2_PX overrides (-1 = never)
+            // experiment hook: pixel count from which wide layers take m2n2.  Measured on FILM / M2M at 1080p
+            // (profiles/r02_film_tile_experiment.txt): 100k is the best of {never, 1.5M, 400k, 100k, 20k} by 0.6 % only — not
+            // worth sharing the block-3 ResConv's kernel instantiation with other layers (its rocprofv3 average is the
+            // roofline cross-check), so the default stays "never"
             const char* e = getenv("VFI_CONV_M2N2_PX");
-            return e && *e ? atol(e) : 100000L;
+            return e && *e ? atol(e) : -1L;
         }();
         if (a.Cout_p == 64 || (big_px >= 0 && px >= big_px)) return kConv2Base + 0;
         return kConv2Base + 2;

@@ -29,7 +29,7 @@ template <int STRIDE, int TAPS, int MT, int NT, int WM, int WN, int CK, bool GRO
 struct Conv2Geom {
     static constexpr int KW = TAPS == 9 ? 3 : (TAPS == 4 ? 2 : 1);
     static constexpr int SUBS = WM * MT;
-    static constexpr int SUBX = SUBS >= 2 ? 2 : 1;
+    static constexpr int SUBX = SUBS >= 16 ? 4 : (SUBS >= 2 ? 2 : 1);   // 16 sub-tiles: 32 x 16 pixels (divides 480 x 272)
     static constexpr int SUBY = SUBS / SUBX;
     static constexpr int TWO = SUBX * 8, THO = SUBY * 4;
     static constexpr int TWI = STRIDE * (TWO - 1) + 3;
@@ -453,6 +453,7 @@ static const ConvVariant kVariants2[] = {
     {"d1t4_m2n1", 1, 4, 2, 1, 4, 1, 8, 0},    // 51
     {"d2t4_m2n1", 2, 4, 2, 1, 4, 1, 8, 0},    // 52: 2x2 stride 2 (M2M 'sconv(2)'), 32-channel N tile
     {"d2t4_m1n2", 2, 4, 1, 2, 4, 1, 8, 0},    // 53
+    {"d1_m4n2", 1, 9, 4, 2, 4, 1, 8, 0},      // 54: 32x16 px x 64 ch (8 accumulators per wave)
 };
 int conv2_num_variants() { return (int)(sizeof(kVariants2) / sizeof(kVariants2[0])); }
 const ConvVariant& conv2_variant(int i) { return kVariants2[i]; }
@@ -481,6 +482,7 @@ int conv2_launch(const ConvArgs& a, int idx, hipStream_t s, const char* nm) {
         case 19: return launch2_t<1, 4, 2, 1, 4, 1, 8, false>(a, s, nm);
         case 20: return launch2_t<2, 4, 2, 1, 4, 1, 8, false>(a, s, nm);
         case 21: return launch2_t<2, 4, 1, 2, 4, 1, 8, false>(a, s, nm);
+        case 22: return launch2_t<1, 9, 4, 2, 4, 1, 8, false>(a, s, nm);
     }
     set_error("conv2: bad variant %d", idx);
     return -3;

@@ -45,7 +45,8 @@ _K2 = 32                                                   # kConv2Base
 _V1 = {0: (16, 64), 1: (16, 96), 2: (16, 64), 3: (16, 96), 4: (16, 32), 5: (16, 32), 6: (16, 64), 7: (16, 128), 8: (8, 64), 9: (8, 96),
        10: (8, 32), 11: (8, 64), 12: (16, 32), 13: (16, 32)}                       # variant -> (K chunk, N tile)
 _V2 = {0: (8, 64), 1: (8, 96), 2: (8, 64), 3: (8, 96), 4: (8, 128), 5: (8, 128), 6: (16, 64), 7: (8, 64), 8: (8, 64), 9: (8, 96), 10: (8, 32),
-       11: (8, 32), 12: (8, 32), 13: (8, 32), 14: (8, 64), 15: (8, 64), 16: (8, 64), 17: (8, 64), 18: (8, 32), 19: (8, 32), 20: (8, 32), 21: (8, 64)}
+       11: (8, 32), 12: (8, 32), 13: (8, 32), 14: (8, 64), 15: (8, 64), 16: (8, 64), 17: (8, 64), 18: (8, 32), 19: (8, 32), 20: (8, 32), 21: (8, 64),
+       22: (8, 64)}
 
 
 def conv_variant(grouped, taps, stride, cin_p, cout_p, px, out_mode=0, n_cus=256):
