@@ -117,6 +117,17 @@ PROTOTYPES = {
     "vfi_rife_debug_keep": (C.c_int, [C.c_void_p, C.c_int]),
     "vfi_rife_debug_read": (C.c_int64, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64]),
     "vfi_rife_work": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "vfi_film_create": (C.c_void_p, [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int]),
+    "vfi_film_destroy": (None, [C.c_void_p]),
+    "vfi_film_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "vfi_film_release_workspace": (C.c_int, [C.c_void_p]),
+    "vfi_film_debug_read_flow": (C.c_int64, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64]),
+    "vfi_m2m_create": (C.c_void_p, [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int]),
+    "vfi_m2m_destroy": (None, [C.c_void_p]),
+    "vfi_m2m_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vfi_m2m_render": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    "vfi_m2m_release_workspace": (C.c_int, [C.c_void_p]),
+    "vfi_m2m_debug_read": (C.c_int64, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
     "vfi_attention": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
     "vfi_rife_load_frame_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),

@@ -103,6 +103,21 @@ int vfi_warp_film(const float* in_dev, int in_cs, const float* flow_dev, int flo
 int vfi_axpby(const float* a_dev, int a_cs, const float* b_dev, int b_cs, float* out_dev, int out_cs,
               int64_t pixels, int C, float alpha, float beta, void* stream);
 
+/* ---- FILM as one object ("same triplet for FILM") ------------------------------------------
+ * The interpolator of the FILM node, weights resident, workspace owned, the launch sequence of one frame pair issued by
+ * one call.  `tensors[i]` = host pointers to the 82 state_dict tensors in film_spec.film_shapes() order (== the state_dict
+ * order of film_arch.Interpolator / of the TorchScript artifact film_net_fp32.pt), reference layouts; numels checked.
+ * Replaces torch.jit.load(...) + model(frame0, frame1, dt) of vfi_models/film/__init__.py:73-76,30-39 and
+ * Interpolator.debug_forward, film_arch.py:401-455 (the model ignores dt: always the midpoint, :427-429). */
+typedef struct vfi_film vfi_film_t;
+vfi_film_t* vfi_film_create(const float* const* tensors, const int64_t* numels, int n_tensors);
+void vfi_film_destroy(vfi_film_t* net);
+/* out_dev [H,W,3] = Interpolator(x0, x1) for x0_dev, x1_dev [H,W,C] fp32 (C >= 3, alpha ignored); clamp != 0 applies the
+ * node's prediction.clamp(0, 1) (film/__init__.py:39).  H, W >= 64.  The workspace (15 GB at 1080p) is sized on first use. */
+int vfi_film_forward(vfi_film_t* net, const float* x0_dev, const float* x1_dev, int C, int H, int W, float* out_dev, int clamp,
+                     void* stream);
+int vfi_film_release_workspace(vfi_film_t* net);
+
 /* ---- M2M custom ops ---------------------------------------------------------------------- */
 
 /* Summation splat (forward warp): out[n, y', x', c] += in[n,y,x,c] * bilinear weight at the 4 integer
@@ -165,6 +180,19 @@ int vfi_m2m_splat_inputs(const float* d0_dev, int d0_cs, const float* tf_dev, co
  * with the t-blend, undo the input normalisation, crop (:569-581, :1026-1037) */
 int vfi_m2m_combine(const float* splat_dev, const float* d0_dev, int d0_cs, const float* stats_dev, float t, float* out_dev,
                     int Hp, int Wp, int H, int W, void* stream);
+
+/* ---- M2M as one object ("same triplet for M2M") ---------------------------------------------
+ * `tensors[i]` = host pointers to the 188 state_dict tensors of M2M_PWC in m2m_spec.m2m_shapes() order (== torch state_dict
+ * order), reference layouts; numels checked.  Replaces M2M_PWC() + load_state_dict (vfi_models/m2m/__init__.py:43-46) and
+ * M2M_PWC.forward (M2M_arch.py:894-1037), split where the reference's timestep loop starts (:948):
+ *   vfi_m2m_prepare — padding, normalisation, flow network, motion refinement, photometric metric: once per frame pair;
+ *   vfi_m2m_render  — the 8 splats + blend of ONE timestep t -> out_dev [H,W,3] (not clamped, like the reference). */
+typedef struct vfi_m2m vfi_m2m_t;
+vfi_m2m_t* vfi_m2m_create(const float* const* tensors, const int64_t* numels, int n_tensors);
+void vfi_m2m_destroy(vfi_m2m_t* net);
+int vfi_m2m_prepare(vfi_m2m_t* net, const float* frame0_dev, const float* frame1_dev, int C, int H, int W, void* stream);
+int vfi_m2m_render(vfi_m2m_t* net, float t, float* out_dev, void* stream);
+int vfi_m2m_release_workspace(vfi_m2m_t* net);
 
 /* ---- RIFE arch 4.0 building blocks (sudo_rife4 checkpoint; rife40.py drives them with the layer objects above) -- */
 

@@ -28,6 +28,15 @@ int64_t vfi_rife_debug_read(vfi_rife_t* net, int what, int stage, float* host_bu
 int vfi_rife_debug_keep(vfi_rife_t* net, int on);
 
 
+/* FILM: the synthesised flow pyramid of the last vfi_film_forward — direction d (0 forward, 1 backward), pyramid level l,
+ * [h_l, w_l, 2] floats to host.  Returns the number of floats or < 0. */
+int64_t vfi_film_debug_read_flow(vfi_film_t* net, int d, int level, float* host_buf, int64_t cap);
+
+/* M2M: internal tensors of the last vfi_m2m_prepare to host.  what 0: the PWC flows [2,Hp/4,Wp/4,2] (image 0 forward,
+ * 1 backward); 1: d0 [2,Hp,Wp,8] = (refined-flow base 2 | normalised image 3 | warped partner 3); 2: r [2,Hp,Wp,12] = (8 flow
+ * residuals | mask logit | pad).  Returns the number of floats or < 0. */
+int64_t vfi_m2m_debug_read(vfi_m2m_t* net, int what, float* host_buf, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

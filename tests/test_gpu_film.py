@@ -124,7 +124,7 @@ def test_interpolator_vs_oracle(engine, sd, h, w):
     msgs = []
     for d, name in ((0, "fwd_flow"), (1, "bwd_flow")):
         for l in (4, 2, 0):
-            a = engine.flow[d][l].cpu()
+            a = engine.debug_flow(d, l, h >> l, w >> l)
             b = aux[name][l][0].permute(1, 2, 0)
             msgs.append(describe_diff(a, b, f"{name}[{l}]"))
     msgs.append(describe_diff(got, want, "output"))

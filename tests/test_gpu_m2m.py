@@ -185,7 +185,20 @@ def test_normalize(lib, h, w, c):
 
 def test_cube(lib, sd):
     """pools + the three 1x1 sigmoid convs + cube_apply vs oracle._cube (EncDec attention, M2M_arch.py:786-795)"""
-    from cfi_amd.m2m import _Layer
+    class _Layer:     # a 1x1 conv of the checkpoint as a vfi_conv layer object, called with an explicit activation
+        def __init__(self, lib_, w, b):
+            w, b = w.detach().float().contiguous(), b.detach().float().contiguous()
+            self.lib, self.keep = lib_, (w, b)
+            self.h = lib_.vfi_conv_create_ex(0, w.data_ptr(), b.data_ptr(), w.shape[0], w.shape[1], 1, 1, 0, None, (w.shape[1] + 7) // 8 * 8, None)
+            assert self.h
+
+        def __call__(self, src, soff, dst, doff, act):
+            n, hin, win, cs = src.shape
+            _ck(self.lib.vfi_conv_forward_ex(self.h, src.data_ptr() + 4 * soff, cs, hin, win, dst.data_ptr() + 4 * doff, dst.shape[-1], n, act,
+                                             0.0, 0.0, 0.0, None, 0, None), "conv_forward_ex")
+
+        def close(self):
+            self.lib.vfi_conv_destroy(self.h)
 
     g = torch.Generator().manual_seed(11)
     h, w = 7, 10
