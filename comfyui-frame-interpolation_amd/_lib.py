@@ -130,6 +130,8 @@ PROTOTYPES = {
     "vfi_m2m_debug_read": (C.c_int64, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
     "vfi_attention": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
+    "vfi_window_attention": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "vfi_rife_load_frame_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "vfi_f32_to_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "vfi_rife_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_int_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p,

@@ -37,7 +37,24 @@ struct AttArgs {
     int q_cs, k_cs, v_cs, out_cs;
     int nb, Lq, Lk, DV, period;
     float alpha;
+    // window mode (win_K > 0): q / k / v / out are [B, h, w, .] token MAPS and batch entry b = (image, wy, wx) is the K x K
+    // window of the map rolled by (-sh, -sw): token l of the window = pixel ((wy wh + l / ww + sh) % h, (wx ww + l % ww + sw) % w)
+    // — torch.roll + split_feature + merge_splits + roll back (:367-436, :1059-1120) folded into the addressing.
+    int win_K, win_h, win_w, win_sh, win_sw, win_wh, win_ww;   // wh x ww = the window
+    float win_inv_ww;
 };
+
+// row (token index into the [.., cs] arrays) of token l of batch entry b
+__device__ inline size_t att_row(const AttArgs& a, int b, int l, int L, int wy0, int wx0, int img0) {
+    if (!a.win_K) return (size_t)b * L + l;
+    const int ww = a.win_ww;
+    const int ly = (int)(((float)l + 0.5f) * a.win_inv_ww);     // exact: l < 2^20, the quotient is >= 0.5 / ww from an integer
+    const int lx = l - ly * ww;
+    int y = wy0 + ly, x = wx0 + lx;                              // wy0 = wy wh + sh < 2h
+    y = y >= a.win_h ? y - a.win_h : y;
+    x = x >= a.win_w ? x - a.win_w : x;
+    return (size_t)(img0 + y) * a.win_w + x;
+}
 
 template <int DVT>   // output tiles of 32 value channels: 4 (DV = 128) or 1 (DV <= 32, e.g. the 2-channel grid / flow)
 __global__ __launch_bounds__(256) void attention_kernel(const AttArgs a) {
@@ -53,14 +70,17 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttArgs a) {
     const int q0 = blockIdx.x * 128 + wave * 32;
     const int query = q0 + l31;
     const bool qok = query < a.Lq;
-    const float* kb_ = a.k + (size_t)b * a.Lk * a.k_cs;
-    const float* vb_ = a.v + (size_t)b * a.Lk * a.v_cs;
+    int wy0 = 0, wx0 = 0, img0 = 0;
+    if (a.win_K) {
+        const int K = a.win_K, wimg = b / (K * K), wy = (b / K) % K, wx = b % K;
+        wy0 = wy * a.win_wh + a.win_sh, wx0 = wx * a.win_ww + a.win_sw, img0 = wimg * a.win_h;
+    }
     const int* lab = a.labels ? a.labels + (size_t)(b % a.period) * a.Lk : nullptr;     // (labels index tokens: Lq == Lk when used)
 
     // this lane's query row, the channels of its half: qreg[4g + j] = Q[query][8g + 4 half + j]
     float qreg[64];
     {
-        const float* qp = a.q + ((size_t)b * a.Lq + (qok ? query : 0)) * a.q_cs + 4 * half;
+        const float* qp = a.q + att_row(a, b, qok ? query : 0, a.Lq, wy0, wx0, img0) * a.q_cs + 4 * half;
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
             f32x4 t = *(const f32x4*)(qp + 8 * g);
@@ -91,7 +111,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttArgs a) {
             const int idx = tid + 256 * i;
             const int key = idx >> 5, d4 = idx & 31;
             kreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (key0 + key < a.Lk) kreg[i] = *(const f32x4*)(kb_ + (size_t)(key0 + key) * a.k_cs + 4 * d4);
+            if (key0 + key < a.Lk) kreg[i] = *(const f32x4*)(a.k + att_row(a, b, key0 + key, a.Lk, wy0, wx0, img0) * a.k_cs + 4 * d4);
         }
         if (DVT == 4) {
 #pragma unroll
@@ -99,14 +119,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttArgs a) {
                 const int idx = tid + 256 * i;
                 const int key = idx & 31, d4 = idx >> 5;     // consecutive lanes = consecutive keys: conflict-free transposed store
                 vreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (key0 + key < a.Lk) vreg[i] = *(const f32x4*)(vb_ + (size_t)(key0 + key) * a.v_cs + 4 * d4);
+                if (key0 + key < a.Lk) vreg[i] = *(const f32x4*)(a.v + att_row(a, b, key0 + key, a.Lk, wy0, wx0, img0) * a.v_cs + 4 * d4);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int idx = tid + 256 * i;
                 const int key = idx & 31, d = idx >> 5;
-                vreg[0][i] = (d < a.DV && key0 + key < a.Lk) ? vb_[(size_t)(key0 + key) * a.v_cs + d] : 0.f;
+                vreg[0][i] = (d < a.DV && key0 + key < a.Lk) ? a.v[att_row(a, b, key0 + key, a.Lk, wy0, wx0, img0) * a.v_cs + d] : 0.f;
             }
         }
         if (tid < ATT_KB) lreg = (lab && key0 + tid < a.Lk) ? lab[key0 + tid] : 0;
@@ -206,7 +226,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttArgs a) {
     // ---- normalise and store: register r of tile t = channel 32t + 8(r/4) + 4 half + r%4 of this lane's query
     if (qok) {
         const float inv = 1.0f / l_run;
-        float* op = a.out + ((size_t)b * a.Lq + query) * a.out_cs;
+        float* op = a.out + att_row(a, b, query, a.Lq, wy0, wx0, img0) * a.out_cs;
 #pragma unroll
         for (int t = 0; t < DVT; ++t)
 #pragma unroll
@@ -263,5 +283,26 @@ extern "C" int vfi_attention(const float* q_dev, int q_cs, const float* k_dev, i
     a.q_cs = q_cs, a.k_cs = k_cs, a.v_cs = v_cs, a.out_cs = out_cs;
     a.nb = nb, a.Lq = Lq, a.Lk = Lk, a.DV = DV, a.period = labels_dev ? label_period : 1;
     a.alpha = alpha;
+    a.win_K = 0, a.win_h = a.win_w = a.win_sh = a.win_sw = a.win_wh = a.win_ww = 0, a.win_inv_ww = 0.f;
     return DV == 128 ? attention_launch_t<4>(a, (hipStream_t)stream) : attention_launch_t<1>(a, (hipStream_t)stream);
+}
+
+extern "C" int vfi_window_attention(const float* q_dev, int q_cs, const float* k_dev, int k_cs, const float* v_dev, int v_cs, float* out_dev,
+                                    int out_cs, int B, int h, int w, int splits, int shift_h, int shift_w, int C, float alpha,
+                                    const int* labels_dev, void* stream) {
+    VFI_REQUIRE(q_dev && k_dev && v_dev && out_dev && B > 0 && h > 0 && w > 0 && splits > 0 && h % splits == 0 && w % splits == 0,
+                "vfi_window_attention: bad arguments (%dx%d into %d splits)", h, w, splits);
+    VFI_REQUIRE(C == ATT_C, "vfi_window_attention: head dimension %d (only %d, GMFlow's)", C, ATT_C);
+    VFI_REQUIRE(shift_h >= 0 && shift_h < h / splits && shift_w >= 0 && shift_w < w / splits, "vfi_window_attention: shift (%d,%d) outside a window", shift_h, shift_w);
+    VFI_REQUIRE(q_cs >= C && k_cs >= C && v_cs >= C && out_cs >= C && (q_cs | k_cs | v_cs | out_cs) % 4 == 0, "vfi_window_attention: bad strides");
+    VFI_REQUIRE((((uintptr_t)q_dev | (uintptr_t)k_dev | (uintptr_t)v_dev | (uintptr_t)out_dev) & 15) == 0, "vfi_window_attention: unaligned pointers");
+    VFI_REQUIRE(out_dev != q_dev && out_dev != k_dev && out_dev != v_dev, "vfi_window_attention: out aliases an input");
+    VFI_REQUIRE((long)(h / splits) * (w / splits) < (1 << 20), "vfi_window_attention: window too large");
+    AttArgs a;
+    a.q = q_dev, a.k = k_dev, a.v = v_dev, a.out = out_dev, a.labels = labels_dev;
+    a.q_cs = q_cs, a.k_cs = k_cs, a.v_cs = v_cs, a.out_cs = out_cs;
+    a.nb = B * splits * splits, a.Lq = a.Lk = (h / splits) * (w / splits), a.DV = C, a.period = splits * splits;
+    a.alpha = alpha;
+    a.win_K = splits, a.win_h = h, a.win_w = w, a.win_sh = shift_h, a.win_sw = shift_w, a.win_wh = h / splits, a.win_ww = w / splits, a.win_inv_ww = 1.0f / (float)(w / splits);
+    return attention_launch_t<4>(a, (hipStream_t)stream);
 }

@@ -7,6 +7,9 @@
 #include "../../include/vfi_hip.h"
 #include "gmfss_bodies.h"
 #include "body_launch.h"
+#ifndef VFI_HOSTCHECK
+#include "gmfss_fast.h"
+#endif
 
 using namespace vfi;
 using namespace vfi_gmfss;
@@ -40,13 +43,23 @@ int vfi_prelu_scalar(const float* in_dev, int in_cs, float* out_dev, int out_cs,
 
 int vfi_instnorm_stats(const float* x_dev, int cs, int C, int N, int64_t HW, float* stats_dev, double* workspace_dev,
                        int64_t workspace_bytes, void* stream) {
-    const int strips = 64;
     VFI_REQUIRE(x_dev && stats_dev && workspace_dev && C > 0 && cs >= C && N > 0 && HW > 0, "vfi_instnorm_stats: bad arguments");
-    VFI_REQUIRE(workspace_bytes >= (int64_t)N * strips * C * 2 * (int64_t)sizeof(double), "vfi_instnorm_stats: workspace too small");
+    // strips of the first pass: as many as the workspace holds, 64 (the minimum it must hold) .. 1024
+    const int64_t per_strip = (int64_t)N * C * 2 * (int64_t)sizeof(double);
+    VFI_REQUIRE(workspace_bytes >= 64 * per_strip, "vfi_instnorm_stats: workspace too small");
+    const int strips = (int)(workspace_bytes / per_strip < 1024 ? workspace_bytes / per_strip : 1024);
     InStatsArgs a{x_dev, cs, C, N, (long)HW, strips, workspace_dev};
-    int rc = run<InStatsArgs, instnorm_partial_body>(a, (long)N * strips * C, stream, "instnorm_partial");
+    int rc;
+#ifndef VFI_HOSTCHECK
+    if (instnorm_partial_wg_fits(a)) rc = instnorm_partial_wg_launch(a, stream);     // a workgroup per strip (gmfss_fast.hip)
+    else
+#endif
+        rc = run<InStatsArgs, instnorm_partial_body>(a, (long)N * strips * C, stream, "instnorm_partial");
     if (rc) return rc;
     InFinalArgs f{workspace_dev, C, N, (long)HW, strips, stats_dev, 1e-5f};
+#ifndef VFI_HOSTCHECK
+    return instnorm_final_wave_launch(f, stream);
+#endif
     return run<InFinalArgs, instnorm_final_body>(f, (long)N * C, stream, "instnorm_final");
 }
 
@@ -62,6 +75,9 @@ int vfi_layernorm(const float* x_dev, int cs, int C, int64_t tokens, const float
                   int out_cs, void* stream) {
     VFI_REQUIRE(x_dev && gamma_dev && beta_dev && out_dev && C > 0 && cs >= C && out_cs >= C && tokens > 0, "vfi_layernorm: bad arguments");
     LayerNormArgs a{x_dev, cs, C, (long)tokens, gamma_dev, beta_dev, out_dev, out_cs, 1e-5f};
+#ifndef VFI_HOSTCHECK
+    if (layernorm_wave_fits(a)) return layernorm_wave_launch(a, stream);     // one wave per token (gmfss_fast.hip)
+#endif
     return run<LayerNormArgs, layernorm_body>(a, (long)tokens, stream, "layernorm");
 }
 
@@ -123,6 +139,9 @@ int vfi_local_match(const float* f0_dev, int f0_cs, const float* f1_dev, int f1_
                     radius >= 1 && radius <= 5,
                 "vfi_local_match: bad arguments");
     LocalMatchArgs a{f0_dev, f0_cs, f1_dev, f1_cs, flow_dev, flow_cs, N, H, W, C, radius};
+#ifndef VFI_HOSTCHECK
+    if (local_match_mfma_fits(a)) return local_match_mfma_launch(a, stream);   // GMFlow's shape: fp32-MFMA form (gmfss_fast.hip)
+#endif
     return run<LocalMatchArgs, local_match_body>(a, (long)N * H * W, stream, "local_match");
 }
 

@@ -212,6 +212,7 @@ __global__ __launch_bounds__(256) void softsplat_tile_kernel(const float* __rest
 //     redone by the LDS-atomic tile kernel above — always correct, never silently truncated;
 //   * sources displaced by more than SPLAT_RCAP-1 px go to the far pass, as before.
 constexpr int SPLAT_K = 8;
+constexpr int SPLAT_GCAP = 4 * SPLAT_K;               // contributors of one output pixel: four cells x SPLAT_K (spills go to the tail)
 constexpr int SPLAT_CW = SPLAT_T + 1;                 // cells per row: north-west targets lx in [-1, 31]
 constexpr int SPLAT_CELLS = SPLAT_CW * SPLAT_CW;
 constexpr unsigned SPLAT_OVF_CAP = 1u << 20;          // entries of the global overflow list (8 MiB); VFI_SPLAT_SPILL_CAP lowers it (tests)
@@ -269,7 +270,8 @@ template <int NCT>   // 4: C == 4, float4 path (M2M);  0: any C, 4 channels per 
 __global__ __launch_bounds__(256) void softsplat_list_kernel(const float* __restrict__ in, const float* __restrict__ flow,
                                                              float* __restrict__ out, const float4* __restrict__ brange,
                                                              SplatCtl* __restrict__ ctl, uint2* __restrict__ ovf, unsigned ovf_cap,
-                                                             int H, int W, int C, int tiles_x, int tiles_y) {
+                                                             int H, int W, int C, int tiles_x, int tiles_y,
+                                                             uint2* __restrict__ glist, unsigned char* __restrict__ gcount) {
 #pragma clang fp contract(off)   // in * w, then +: the reference's atomicAdd(out, in * w) cannot fuse either
     __shared__ int cnt[SPLAT_CELLS];
     __shared__ unsigned short lst[SPLAT_CELLS * SPLAT_K];
@@ -336,16 +338,22 @@ __global__ __launch_bounds__(256) void softsplat_list_kernel(const float* __rest
     }
     __syncthreads();
     // ---- phase 3: gather
+    if (NCT == 0) {
+        // any channel count: this kernel only resolves, per output pixel, WHO contributes and with what weight — the (source,
+        // weight) pairs in summation order, at most 4 cells x SPLAT_K of them, to glist[pixel][.] — and softsplat_gather_kernel
+        // (one thread per output ELEMENT, coalesced over channels) does the arithmetic.  Walking the lists once per 4-channel
+        // group from here, as round 2's first version did, recomputed the weights C/4 times per pixel and read `in` 16 bytes
+        // per lane at a stride of 4C bytes: 0.9 ms per GMFSS feature splat, 3 % of its HBM bound.
 #pragma unroll 1
-    for (int q = 0; q < 4; ++q) {
-        const int px = tid & 31, py = (tid >> 5) + 8 * q;
-        const int x = X0 + px, y = Y0 + py;
-        if (x >= W || y >= H) continue;
-        float* op = out + (nbase + (size_t)y * W + x) * C;
-        for (int c0 = 0; c0 < (NCT == 4 ? 4 : C); c0 += 4) {
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int q = 0; q < 4; ++q) {
+            const int px = tid & 31, py = (tid >> 5) + 8 * q;
+            const int x = X0 + px, y = Y0 + py;
+            if (x >= W || y >= H) continue;
+            const size_t pix = nbase + (size_t)y * W + x;
+            uint2* gl = glist + pix * SPLAT_GCAP;
+            int m = 0;
 #pragma unroll
-            for (int k = 3; k >= 0; --k) {                           // k = dx + 2 dy: SE, SW, NE, NW contribution of the source
+            for (int k = 3; k >= 0; --k) {
                 const int cell = (py + 1 - (k >> 1)) * SPLAT_CW + px + 1 - (k & 1);
                 const int ne = min(cnt[cell], SPLAT_K);
                 for (int e = 0; e < ne; ++e) {
@@ -356,29 +364,60 @@ __global__ __launch_bounds__(256) void softsplat_list_kernel(const float* __rest
                     int x0, y0;
                     float w[4];
                     splat_weights((float)sx + f.x, (float)sy + f.y, x0, y0, w);
-                    const float wk = w[k];
-                    const float* ip = in + sp * C + c0;
-                    if (NCT == 4) {
-                        const float4 iv = *(const float4*)ip;
-                        a0 += iv.x * wk, a1 += iv.y * wk, a2 += iv.z * wk, a3 += iv.w * wk;
-                    } else {
-                        a0 += ip[0] * wk;
-                        if (c0 + 1 < C) a1 += ip[1] * wk;
-                        if (c0 + 2 < C) a2 += ip[2] * wk;
-                        if (c0 + 3 < C) a3 += ip[3] * wk;
-                    }
+                    gl[m++] = make_uint2((unsigned)sp, __float_as_uint(w[k]));
                 }
             }
-            if (NCT == 4) {
-                *(float4*)op = make_float4(a0, a1, a2, a3);
-            } else {
-                op[c0] = a0;
-                if (c0 + 1 < C) op[c0 + 1] = a1;
-                if (c0 + 2 < C) op[c0 + 2] = a2;
-                if (c0 + 3 < C) op[c0 + 3] = a3;
+            gcount[pix] = (unsigned char)m;
+        }
+        return;
+    }
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+        const int px = tid & 31, py = (tid >> 5) + 8 * q;
+        const int x = X0 + px, y = Y0 + py;
+        if (x >= W || y >= H) continue;
+        float* op = out + (nbase + (size_t)y * W + x) * C;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int k = 3; k >= 0; --k) {                           // k = dx + 2 dy: SE, SW, NE, NW contribution of the source
+            const int cell = (py + 1 - (k >> 1)) * SPLAT_CW + px + 1 - (k & 1);
+            const int ne = min(cnt[cell], SPLAT_K);
+            for (int e = 0; e < ne; ++e) {
+                const unsigned ent = lst[cell * SPLAT_K + e];
+                const int sx = wx0 + (int)(ent & 255u), sy = wy0 + (int)(ent >> 8);
+                const size_t sp = nbase + (size_t)sy * W + sx;
+                const float2 f = ((const float2*)flow)[sp];
+                int x0, y0;
+                float w[4];
+                splat_weights((float)sx + f.x, (float)sy + f.y, x0, y0, w);
+                const float wk = w[k];
+                const float4 iv = *(const float4*)(in + sp * C);
+                a0 += iv.x * wk, a1 += iv.y * wk, a2 += iv.z * wk, a3 += iv.w * wk;
             }
         }
+        *(float4*)op = make_float4(a0, a1, a2, a3);
     }
+}
+
+// the arithmetic of the any-channel-count splat: out[pixel][c] = sum over the pixel's list of in[source][c] * weight, in list
+// order (= the order the one-kernel form summed in: results are bit-identical to it).  One thread per output element: stores
+// are fully coalesced, loads are runs of C consecutive floats per source, the list entries are broadcast reads.
+__global__ __launch_bounds__(256) void softsplat_gather_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                               const uint2* __restrict__ glist,
+                                                               const unsigned char* __restrict__ gcount, long total, int C) {
+#pragma clang fp contract(off)
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const long pix = idx / C;
+    const int c = (int)(idx - pix * C);
+    const int m = gcount[pix];
+    const uint2* gl = glist + pix * SPLAT_GCAP;
+    float a = 0.f;
+    for (int i = 0; i < m; ++i) {
+        const uint2 e = gl[i];
+        a += in[(size_t)e.x * C + c] * __uint_as_float(e.y);
+    }
+    out[idx] = a;
 }
 
 // the spilled sources of over-full cells: global atomics onto the tile the list kernel has already written
@@ -449,10 +488,13 @@ struct SplatWs {
     uint2* ovf = nullptr;
     float4* brange = nullptr;
     size_t brange_n = 0;
+    uint2* glist = nullptr;            // any-C path: [pixels][SPLAT_GCAP] (source, weight) pairs + their count per pixel
+    unsigned char* gcount = nullptr;
+    size_t g_pixels = 0;
 };
 static SplatWs g_splat_ws[kMaxDevices];
 
-static int splat_ws(size_t n_blocks, SplatWs** out) {
+static int splat_ws(size_t n_blocks, size_t list_pixels, SplatWs** out) {
     int dev = 0;
     VFI_CHECK_HIP(hipGetDevice(&dev));
     VFI_REQUIRE(dev >= 0 && dev < kMaxDevices, "splat: device index %d out of range", dev);
@@ -465,6 +507,14 @@ static int splat_ws(size_t n_blocks, SplatWs** out) {
         if (w.brange) VFI_CHECK_HIP(hipFree(w.brange));    // (synchronises; only on growth)
         VFI_CHECK_HIP(hipMalloc((void**)&w.brange, sizeof(float4) * n_blocks));
         w.brange_n = n_blocks;
+    }
+    if (w.g_pixels < list_pixels) {
+        if (w.glist) VFI_CHECK_HIP(hipFree(w.glist));
+        if (w.gcount) VFI_CHECK_HIP(hipFree(w.gcount));
+        w.glist = nullptr, w.gcount = nullptr, w.g_pixels = 0;
+        VFI_CHECK_HIP(hipMalloc((void**)&w.glist, sizeof(uint2) * SPLAT_GCAP * list_pixels));     // 256 B per pixel; only the used
+        VFI_CHECK_HIP(hipMalloc((void**)&w.gcount, list_pixels));                                   // entries are ever touched
+        w.g_pixels = list_pixels;
     }
     *out = &w;
     return 0;
@@ -485,7 +535,10 @@ int softsplat_sum_launch(const float* in, const float* flow, float* out, int N, 
     const int tiles_x = cdiv(W, SPLAT_T), tiles_y = cdiv(H, SPLAT_T);
     const unsigned n_tiles = (unsigned)N * tiles_x * tiles_y;
     SplatWs* ws = nullptr;
-    if (int rc = splat_ws(n_tiles, &ws)) return rc;
+    const bool c4 = C == 4 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
+    const size_t pixels = (size_t)N * H * W;
+    VFI_REQUIRE(pixels < (1ull << 32), "softsplat: %zu pixels do not fit the 32-bit source index", pixels);
+    if (int rc = splat_ws(n_tiles, g_splat_mode == 0 && !c4 ? pixels : 0, &ws)) return rc;
     VFI_CHECK_HIP(hipMemsetAsync(ws->ctl, 0, sizeof(SplatCtl), s));
     {
         TraceScope ts("splat_blockrange", s);
@@ -495,12 +548,18 @@ int softsplat_sum_launch(const float* in, const float* flow, float* out, int N, 
     if (g_splat_mode == 0) {
         {
             TraceScope ts("softsplat_sum", s);
-            if (C == 4 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0)
+            if (c4)
                 hipLaunchKernelGGL(softsplat_list_kernel<4>, dim3(n_tiles), dim3(256), 0, s, in, flow, out, ws->brange, ws->ctl, ws->ovf,
-                                   g_splat_cap, H, W, C, tiles_x, tiles_y);
+                                   g_splat_cap, H, W, C, tiles_x, tiles_y, (uint2*)nullptr, (unsigned char*)nullptr);
             else
                 hipLaunchKernelGGL(softsplat_list_kernel<0>, dim3(n_tiles), dim3(256), 0, s, in, flow, out, ws->brange, ws->ctl, ws->ovf,
-                                   g_splat_cap, H, W, C, tiles_x, tiles_y);
+                                   g_splat_cap, H, W, C, tiles_x, tiles_y, ws->glist, ws->gcount);
+        }
+        if (!c4) {
+            TraceScope ts("splat_gather", s);
+            const long total = (long)pixels * C;
+            hipLaunchKernelGGL(softsplat_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, ws->glist, ws->gcount,
+                               total, C);
         }
     }
     // LDS-atomic tile kernel: the whole job when forced, otherwise only if the spill list overflowed (it then rewrites `out`)

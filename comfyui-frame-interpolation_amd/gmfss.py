@@ -200,7 +200,7 @@ class GMFSSEngine(OpsEngine):
     def _instnorm(self, x, c, relu1, add, relu2, out):
         n, h, w, cs = x.shape
         stats = self._t("in_stats", n, c, 2)
-        ws = self.scratch.setdefault(("in_ws", n, c), torch.zeros(n * 64 * c * 2, dtype=torch.float64, device=self.device))
+        ws = self.scratch.setdefault(("in_ws", n, c), torch.zeros(n * 512 * c * 2, dtype=torch.float64, device=self.device))
         self._c("vfi_instnorm_stats", _p(x), cs, c, n, h * w, _p(stats), ws.data_ptr(), ws.numel() * 8)
         self._c("vfi_instnorm_apply", _p(x), cs, _p(stats), c, n, h * w, int(relu1), _p(add) if add is not None else None,
                 add.shape[-1] if add is not None else 0, int(relu2), _p(out), out.shape[-1])
@@ -231,16 +231,12 @@ class GMFSSEngine(OpsEngine):
         """single_head_split_window_attention (:367-436) on [B,h,w,C] token maps"""
         B, c = q.shape[0], q.shape[-1]
         wh, ww = h // splits, w // splits
-        nb, lw = B * splits * splits, wh * ww
         sh, sw = (wh // 2, ww // 2) if shifted else (0, 0)
-        qw, kw, vw, ow = (self._t("att_" + n, nb, lw, c) for n in ("q", "k", "v", "o"))
-        for src, dst in ((q, qw), (k, kw), (v, vw)):
-            self._c("vfi_window_partition", _p(src), src.shape[-1], _p(dst), c, B, h, w, c, splits, sh, sw, 0)
-        # softmax(q k^T / sqrt(c) + mask) v as one flash-style MFMA kernel (csrc/attention.hip): no score matrix in HBM
+        # softmax(q k^T / sqrt(c) + mask) v as one flash-style MFMA kernel (csrc/attention.hip): no score matrix in HBM, and the
+        # roll / window split / merge / roll back are the kernel's addressing — no partitioned copies either
         labels = self._const(("labels", h, w, splits), lambda: shift_labels(h, w, splits)) if shifted else None
-        self._c("vfi_attention", _p(qw), c, _p(kw), c, _p(vw), c, _p(ow), c, nb, lw, lw, c, c, 1.0 / c ** 0.5,
-                _p(labels) if shifted else None, splits * splits)
-        self._c("vfi_window_partition", _p(ow), c, _p(out), out.shape[-1], B, h, w, c, splits, sh, sw, 1)
+        self._c("vfi_window_attention", _p(q), q.shape[-1], _p(k), k.shape[-1], _p(v), v.shape[-1], _p(out), out.shape[-1], B, h, w, splits,
+                sh, sw, c, 1.0 / c ** 0.5, _p(labels) if shifted else None)
 
     def _pair_swap(self, a, o):
         """o[2d + s] = a[2d + 1 - s]: concat1 of FeatureTransformer.forward (:664-678)"""

@@ -251,7 +251,8 @@ int vfi_normalize_channels(const float* in_dev, int in_cs, float* out_dev, int o
                            const float* std_host, void* stream);
 /* nn.PReLU() (one shared slope) over a channel window: the pre-activations of MetricNet / FeatureNet / GridNet (:1420-1561) */
 int vfi_prelu_scalar(const float* in_dev, int in_cs, float* out_dev, int out_cs, int C, int64_t pixels, float slope, void* stream);
-/* nn.InstanceNorm2d (no affine, eps 1e-5): stats [N][C][2] = (mean, 1/sqrt(var+eps)); workspace >= N*64*C*2 doubles (:165-215) */
+/* nn.InstanceNorm2d (no affine, eps 1e-5): stats [N][C][2] = (mean, 1/sqrt(var+eps)); workspace >= N*64*C*2 doubles
+ * (:165-215); a larger one is used for more, shorter strips of the first pass (up to 1024: more workgroups in flight) */
 int vfi_instnorm_stats(const float* x_dev, int cs, int C, int N, int64_t HW, float* stats_dev, double* workspace_dev,
                        int64_t workspace_bytes, void* stream);
 /* out = act2(act1((x - mean) * rstd) + add): norm(+relu) and the residual sum + relu of ResidualBlock_class (:207-215) */
@@ -283,6 +284,13 @@ int vfi_softmax_rows(float* x_dev, int nb, int rows, int cols, const float* mask
 int vfi_attention(const float* q_dev, int q_cs, const float* k_dev, int k_cs, const float* v_dev, int v_cs, float* out_dev,
                   int out_cs, int nb, int Lq, int Lk, int C, int DV, float alpha, const int* labels_dev, int label_period,
                   void* stream);
+/* single_head_split_window_attention (:367-436) on [B,h,w,.] token MAPS, with the roll + split into splits x splits windows
+ * (split_feature / merge_splits, :1059-1120) and the roll back folded into the kernel's addressing — no partitioned copies
+ * of q / k / v / out in HBM.  shift = (0,0) or (wh/2, ww/2) with labels_dev = int32 [splits^2][wh*ww] region labels (nullable).
+ * out must not alias q / k / v. */
+int vfi_window_attention(const float* q_dev, int q_cs, const float* k_dev, int k_cs, const float* v_dev, int v_cs, float* out_dev,
+                         int out_cs, int B, int h, int w, int splits, int shift_h, int shift_w, int C, float alpha,
+                         const int* labels_dev, void* stream);
 /* flow_warp / bilinear_sample: grid_sample(zeros, align_corners=True) at pixel + flow (:955-991) */
 int vfi_flow_sample(const float* in_dev, int in_cs, const float* flow_dev, int flow_cs, float* out_dev, int out_cs, int N, int H, int W,
                     int C, void* stream);

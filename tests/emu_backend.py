@@ -115,6 +115,27 @@ class EmuLib:
         self.calls["vfi_attention"] = self.calls.get("vfi_attention", 0) + 1
         return 0
 
+    def vfi_window_attention(self, q_ptr, q_cs, k_ptr, k_cs, v_ptr, v_cs, out_ptr, out_cs, B, h, w, splits, sh, sw, c, alpha, labels_ptr, stream=None):
+        """roll, split into windows, attention, merge, roll back — the torch statement of csrc/attention.hip's window mode"""
+        assert c == 128 and h % splits == 0 and w % splits == 0 and 0 <= sh < h // splits and 0 <= sw < w // splits
+        assert out_ptr not in (q_ptr, k_ptr, v_ptr)
+        wh, ww, K = h // splits, w // splits, splits
+
+        def windows(ptr, cs):
+            t = torch.roll(view(ptr, B, h, w, cs, c), shifts=(-sh, -sw), dims=(1, 2))
+            return t.view(B, K, wh, K, ww, c).permute(0, 1, 3, 2, 4, 5).reshape(B * K * K, wh * ww, c)
+
+        q, k, v = windows(q_ptr, q_cs), windows(k_ptr, k_cs), windows(v_ptr, v_cs)
+        sc = torch.matmul(q, k.transpose(1, 2)) * alpha
+        if labels_ptr:
+            lab = host_array(labels_ptr, K * K * wh * ww, C.c_int).view(K * K, wh * ww)
+            m = (lab[:, :, None] != lab[:, None, :]).float() * -100.0
+            sc = sc + m.repeat(B, 1, 1)
+        o = torch.matmul(torch.softmax(sc, dim=-1), v).view(B, K, K, wh, ww, c).permute(0, 1, 3, 2, 4, 5).reshape(B, h, w, c)
+        view(out_ptr, B, h, w, out_cs, c)[:] = torch.roll(o, shifts=(sh, sw), dims=(1, 2))
+        self.calls["vfi_window_attention"] = self.calls.get("vfi_window_attention", 0) + 1
+        return 0
+
     # ---- layer objects (vfi_conv_create_ex / vfi_conv_forward_ex) -----------------------------------------------------
     def vfi_conv_create_ex(self, kind, w_ptr, b_ptr, cout, cin, k, stride, pad_mode, chan_map, cin_phys, prelu_ptr):
         assert pad_mode == 0 and cin_phys % 8 == 0 and cin_phys >= cin

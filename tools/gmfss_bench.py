@@ -16,9 +16,14 @@ from cfi_amd import _lib, synth  # noqa: E402
 from cfi_amd.gmfss import GMFSSEngine  # noqa: E402
 
 if __name__ == "__main__":
-    H, W = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1080, 1920)
-    eng = GMFSSEngine(synth.gmfss_synth_state_dicts(1234))
-    fr = synth.smooth_frames(2, H, W, seed=2, shift=4.0)
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    H, W = (int(args[0]), int(args[1])) if len(args) >= 2 else (1080, 1920)
+    if "--coherent" in sys.argv:      # matched weights + textured frames: GMFlow finds the true (small) motion, as a trained model does
+        eng = GMFSSEngine(synth.gmfss_coherent_state_dicts(3, "union"))
+        fr = synth.texture_frames(2, H, W, seed=5)
+    else:                             # random weights: the flow is noise of arbitrary magnitude (worst case for the splats)
+        eng = GMFSSEngine(synth.gmfss_synth_state_dicts(1234))
+        fr = synth.smooth_frames(2, H, W, seed=2, shift=4.0)
     x0, x1 = fr[0].cuda().contiguous(), fr[1].cuda().contiguous()
     out = torch.empty(H, W, 3, device="cuda")
     lib = _lib.load()
@@ -33,6 +38,21 @@ if __name__ == "__main__":
         t2 = time.perf_counter()
         print(f"GMFSS union {H}x{W} (rep {rep}): prepare {1e3 * (t1 - t0):.1f} ms/pair, render {1e3 * (t2 - t1):.1f} ms/frame; "
               f"device memory {torch.cuda.memory_allocated() / 2**30:.2f} GiB", flush=True)
+    fl = eng.prepared["flows"] if isinstance(getattr(eng, "prepared", None), dict) and "flows" in eng.prepared else None
+    if fl is not None:
+        a = fl.abs().flatten()
+        print(f"   flow |f|: mean {a.mean().item():.2f}, p99 {a.kthvalue(int(0.99 * a.numel())).values.item():.2f}, max {a.max().item():.2f} px", flush=True)
+    for phase in ("prepare", "render"):        # per-kernel split of each phase
+        lib.vfi_trace_reset(); lib.vfi_trace_enable(1)
+        if phase == "prepare":
+            eng.prepare(x0, x1)
+        else:
+            eng.render(0.5, out)
+        torch.cuda.synchronize()
+        lib.vfi_trace_enable(0)
+        rep = _lib.trace_report()
+        print(f"   {phase}: " + ", ".join(f"{k} {v[0]}x {v[1]:.2f}" for k, v in sorted(rep.items(), key=lambda kv: -kv[1][1])[:22])
+              + f"  (sum {sum(v[1] for v in rep.values()):.1f} ms)", flush=True)
     lib.vfi_trace_reset(); lib.vfi_trace_enable(1)
     eng.prepare(x0, x1)
     eng.render(0.5, out)
