@@ -271,6 +271,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
                         else if (a.act == 2) v = fminf(fmaxf(v, 0.f), 1.f);
                         else if (EXT && a.act == 3) v = v > 0.f ? v : v * a.prelu[co];
                         else if (EXT && a.act == 4) v = 1.0f / (1.0f + expf(-v));
+                        else if (EXT && a.act == 5) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
                         if (EXT && a.post_scale != 0.f) v = v * a.post_scale + a.post_shift;
                     if (GROUPED && a.out_mode == 1) {
                         const int Ws = 4 * a.Wout, Hs = 4 * a.Hout, c = co >> 2;

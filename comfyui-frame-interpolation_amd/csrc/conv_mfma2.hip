@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
         // per tile, during which this wave feeds no MFMAs.
         const bool nhwc = a.out_mode == 0 && !GROUPED;
         const bool inter = EXT && GROUPED && a.out_mode == 2;       // transposed conv, parity groups interleaved into NHWC
-        const bool fast = a.res == nullptr && (nhwc || inter) && (a.act == 0 || a.act == 1 || (EXT && a.act == 3)) &&
+        const bool fast = a.res == nullptr && (nhwc || inter) && (a.act == 0 || a.act == 1 || (EXT && (a.act == 3 || a.act == 5))) &&
                           !(EXT && a.post_scale != 0.f);
         if (fast) {
             // element (r) of a sub-tile -> output pixel: NHWC (oy, ox); interleaved (2*oy + gy, 2*ox + gx) of a [2H, 2W] image
@@ -277,11 +277,13 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
                                 ob[(r >> 2) * ystr + (r & 3) * xstr] = fmaxf(v, v * uslope);
                             }
                         } else {                    // image border and / or per-channel (or out-of-range) slopes
-                            const float sl = a.act == 0 ? 1.0f : (a.act == 1 ? a.slope : a.prelu[co]);
+                            const bool gelu = EXT && a.act == 5;
+                            const float sl = a.act == 0 || gelu ? 1.0f : (a.act == 1 ? a.slope : a.prelu[co]);
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
                                 float v = (acc[mt][nt][r] + bs[nt]) * bt[nt];
                                 v = v > 0.f ? v : v * sl;
+                                if (gelu) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));   // nn.GELU(), erf form
                                 if (interior || (oy0 + (r >> 2) < a.Hout && ox0 + (r & 3) < a.Wout)) ob[(r >> 2) * ystr + (r & 3) * xstr] = v;
                             }
                         }
@@ -345,6 +347,7 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
                         else if (a.act == 2) v = fminf(fmaxf(v, 0.f), 1.f);
                         else if (EXT && a.act == 3) v = v > 0.f ? v : v * a.prelu[coc];
                         else if (EXT && a.act == 4) v = 1.0f / (1.0f + expf(-v));
+                        else if (EXT && a.act == 5) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
                         if (EXT && a.post_scale != 0.f) v = v * a.post_scale + a.post_shift;
                         if (cok && oy < a.Hout && ox < a.Wout) {
                             if (GROUPED && a.out_mode == 1) {

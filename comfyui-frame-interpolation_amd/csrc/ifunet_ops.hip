@@ -1,11 +1,14 @@
 // IFUNet kernels — SURVEY.md 8f rank 4, second half: the parts of vfi_models/ifunet/IFUNet_arch.py that are not convolutions
 // (those run on the fp32-MFMA layer objects): CBAM's channel and spatial gates, the 4-channel convex flow up-sampling of the
 // IFBlocks, the mask blends of IFUNetModel / ResynNet.  Bodies in ifunet_bodies.h, launch scheme in body_launch.h.
-// STATUS: checked on the host (tests/test_ifunet_bodies_cpu.py) and through the CPU test double; not yet run on an MI355X
-// (the round's GPU budget was spent) — the GPU tests of tests/test_gpu_ifunet.py are opt-in until then.
+// The CBAM reductions dispatch to the cooperative kernels of ifunet_fast.hip on the device; built with -DVFI_HOSTCHECK
+// (tests/hostcheck) every entry point runs its body on the host.
 #include "../../include/vfi_hip.h"
 #include "ifunet_bodies.h"
 #include "body_launch.h"
+#ifndef VFI_HOSTCHECK
+#include "ifunet_fast.h"
+#endif
 
 using namespace vfi;
 using namespace vfi_ifunet;
@@ -14,16 +17,24 @@ extern "C" {
 
 int vfi_channel_pool(const float* x_dev, int cs, int C, int N, int64_t HW, float* stats_dev, void* workspace_dev, int64_t workspace_bytes,
                      void* stream) {
-    const int strips = 64;
     VFI_REQUIRE(x_dev && stats_dev && workspace_dev && C > 0 && cs >= C && N > 0 && HW > 0, "vfi_channel_pool: bad arguments");
+    // strips of the first pass: as many as the workspace holds, 64 (the minimum it must hold) .. 1024
+    const int64_t per_strip = (int64_t)N * C * (int64_t)(sizeof(double) + sizeof(float));
+    VFI_REQUIRE(workspace_bytes >= 64 * per_strip, "vfi_channel_pool: workspace too small");
+    const int strips = (int)(workspace_bytes / per_strip < 1024 ? workspace_bytes / per_strip : 1024);
     const int64_t cells = (int64_t)N * strips * C;
-    VFI_REQUIRE(workspace_bytes >= cells * (int64_t)(sizeof(double) + sizeof(float)), "vfi_channel_pool: workspace too small");
     double* psum = (double*)workspace_dev;
     float* pmax = (float*)(psum + cells);
     PoolPartArgs a{x_dev, cs, C, N, (long)HW, strips, psum, pmax};
+    PoolFinalArgs f{psum, pmax, C, N, (long)HW, strips, stats_dev};
+#ifndef VFI_HOSTCHECK
+    if (chan_pool_partial_wg_fits(a)) {
+        if (int rc = chan_pool_partial_wg_launch(a, stream)) return rc;
+        return chan_pool_final_wave_launch(f, stream);
+    }
+#endif
     int rc = run<PoolPartArgs, chan_pool_partial_body>(a, (long)cells, stream, "channel_pool_partial");
     if (rc) return rc;
-    PoolFinalArgs f{psum, pmax, C, N, (long)HW, strips, stats_dev};
     return run<PoolFinalArgs, chan_pool_final_body>(f, (long)N * C, stream, "channel_pool_final");
 }
 
@@ -31,6 +42,9 @@ int vfi_cbam_gate(const float* stats_dev, const float* w1_dev, const float* b1_d
                   int N, float* scale_dev, void* stream) {
     VFI_REQUIRE(stats_dev && w1_dev && b1_dev && w2_dev && b2_dev && scale_dev && C > 0 && R > 0 && N > 0, "vfi_cbam_gate: bad arguments");
     GateArgs a{stats_dev, w1_dev, b1_dev, w2_dev, b2_dev, C, R, N, scale_dev};
+#ifndef VFI_HOSTCHECK
+    if (cbam_gate_wg_fits(a)) return cbam_gate_wg_launch(a, stream);
+#endif
     return run<GateArgs, cbam_gate_body>(a, (long)N * C, stream, "cbam_gate");
 }
 
@@ -39,6 +53,9 @@ int vfi_cbam_scale_compress(const float* x_dev, int cs, const float* scale_dev, 
     VFI_REQUIRE(x_dev && scale_dev && xs_dev && comp_dev && C > 0 && cs >= C && xs_cs >= C && N > 0 && HW > 0,
                 "vfi_cbam_scale_compress: bad arguments");
     ScaleCompArgs a{x_dev, cs, scale_dev, C, N, (long)HW, xs_dev, xs_cs, comp_dev};
+#ifndef VFI_HOSTCHECK
+    return cbam_scale_compress_wave_launch(a, stream);
+#endif
     return run<ScaleCompArgs, cbam_scale_compress_body>(a, (long)N * HW, stream, "cbam_scale_compress");
 }
 

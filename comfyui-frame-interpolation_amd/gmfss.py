@@ -265,8 +265,7 @@ class GMFSSEngine(OpsEngine):
                 self._c("vfi_layernorm", _p(q), c, c, B * h * w, _p(L["norm1"][0]), _p(L["norm1"][1]), _p(dst, doff), dst.shape[-1])
                 if ffn:
                     self._ax(a, 0, None, 0, cat, 0, c)
-                    self._conv(L["mlp0"], cat, 0, hid, 0)
-                    self._c("vfi_gelu", _p(hid), 8 * c, 8 * c, B * h * w)
+                    self._conv(L["mlp0"], cat, 0, hid, 0, act=5)         # Linear + nn.GELU() in the conv's epilogue
                     self._conv(L["mlp2"], hid, 0, q, 0)
                     self._c("vfi_layernorm", _p(q), c, c, B * h * w, _p(L["norm2"][0]), _p(L["norm2"][1]), _p(m), c)
                 self._ax(a, 0, m, 0, a, 0, c)

@@ -95,7 +95,7 @@ class IFUNetEngine(OpsEngine):
         """CBAM.forward (:499-503) -> new tensor"""
         n, h, w, c = x.shape
         stats, scale = self._t("cb_stats_" + tag, n, c, 2), self._t("cb_scale_" + tag, n, c)
-        ws = self._t("cb_ws", n * 64 * c * 3)
+        ws = self._t("cb_ws", n * 512 * c * 3)
         self._c("vfi_channel_pool", _p(x), c, c, n, h * w, _p(stats), ws.data_ptr(), ws.numel() * 4)
         self._c("vfi_cbam_gate", _p(stats), _p(P["w1"]), _p(P["b1"]), _p(P["w2"]), _p(P["b2"]), c, P["w1"].shape[0], n, _p(scale))
         xs, comp = self._t("cb_xs_" + tag, n, h, w, c), self._t("cb_comp_" + tag, n * h * w, 2)

@@ -147,7 +147,7 @@ int vfi_costvol9x9(const float* one_dev, int one_cs, const float* two_dev, int t
 vfi_conv_t* vfi_conv_create_ex(int kind, const float* w_host, const float* bias_host, int Cout, int Cin, int k, int stride,
                                int pad_mode, const int* chan_map, int Cin_phys, const float* prelu_host);
 /* out = post_scale * act(layer(in) + bias + res) + post_shift.  act: 0 none, 1 LeakyReLU / single-parameter PReLU
- * (slope), 2 clamp01, 3 per-channel PReLU, 4 sigmoid.  post_scale == 0 disables the affine.  res (nullable):
+ * (slope), 2 clamp01, 3 per-channel PReLU, 4 sigmoid, 5 GELU (erf form, nn.GELU()).  post_scale == 0 disables the affine.  res (nullable):
  * [N,Hout,Wout,res_cs] added before the activation (the decoder's `flow + netMain(...)`, :503).
  * Output is [N, Hin/stride, Win/stride, out_cs] (kind 0) or [N, 2*Hin, 2*Win, out_cs] (kind 1). */
 int vfi_conv_forward_ex(const vfi_conv_t* conv, const float* in_dev, int in_cs, int Hin, int Win, float* out_dev, int out_cs,
@@ -324,9 +324,10 @@ int vfi_pixel_shuffle2(const float* in_dev, int in_cs, float* out_dev, int out_c
 int vfi_clamp_crop(const float* in_dev, int in_cs, int Hp, int Wp, float* out_dev, int H, int W, int C, void* stream);
 
 /* ---- IFUNet building blocks (vfi_models/ifunet/IFUNet_arch.py; ifunet.py drives them with the layer objects above).
- * Checked on the host and through the CPU test double; first MI355X run pending (see csrc/ifunet_ops.hip). --------------- */
+ * Bodies checked on the host (tests/hostcheck) and on the MI355X against the oracle (tests/test_gpu_ifunet.py). --------------- */
 
-/* CBAM ChannelGate pooling (:411-436): stats [N][C][2] = (mean, max) over H*W; workspace >= N*64*C*12 bytes */
+/* CBAM ChannelGate pooling (:411-436): stats [N][C][2] = (mean, max) over H*W; workspace >= N*64*C*12 bytes
+ * (a larger one is used for more, shorter strips of the first pass, up to 1024) */
 int vfi_channel_pool(const float* x_dev, int cs, int C, int N, int64_t HW, float* stats_dev, void* workspace_dev, int64_t workspace_bytes,
                      void* stream);
 /* scale [N][C] = sigmoid(mlp(mean) + mlp(max)), mlp = Linear(C,R) -> ReLU -> Linear(R,C); w1 [R][C], w2 [C][R] on the device (:447-452) */

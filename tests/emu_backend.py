@@ -175,6 +175,8 @@ class EmuLib:
             y = F.prelu(y, L["prelu"])
         elif act == 4:
             y = torch.sigmoid(y)
+        elif act == 5:
+            y = F.gelu(y)
         else:
             assert act == 0
         assert post_scale == 0.0

@@ -62,6 +62,9 @@ LAYERS = [
     (0, 3, 1, 0, 0, 16, 9, 2, 21, 30),        # flow-residual + mask-logit head
     (0, 1, 1, 0, 4, 256, 4096, 2, 1, 1),      # cube conv_C (sigmoid)
     (0, 1, 1, 0, 4, 256, 16, 2, 9, 1),        # cube conv_H
+    (0, 1, 1, 0, 5, 256, 1024, 2, 34, 60),    # GMFlow's FFN: Linear(2c, 8c) + nn.GELU() in the epilogue (interior tiles)
+    (0, 1, 1, 0, 5, 256, 1024, 1, 5, 7),      # ... and border tiles
+    (0, 3, 1, 0, 5, 16, 9, 1, 9, 11),         # GELU through the generic epilogue
     (1, 4, 2, 0, 3, 768, 128, 2, 4, 6),       # deconv(): ConvTranspose2d(4, 2, 1) + PReLU
     (1, 4, 2, 0, 3, 64, 16, 2, 12, 20),
 ]
@@ -85,7 +88,7 @@ def test_layer(lib, kind, k, stride, pad_mode, act, cin, cout, n, h, w):
     res = _rand(g, *y.shape) if use_res else None
     if use_res:
         y = y + res
-    y = {0: lambda v: v, 1: lambda v: F.leaky_relu(v, slope), 3: lambda v: F.prelu(v, pre), 4: torch.sigmoid}[act](y)
+    y = {0: lambda v: v, 1: lambda v: F.leaky_relu(v, slope), 3: lambda v: F.prelu(v, pre), 4: torch.sigmoid, 5: F.gelu}[act](y)
     want = nhwc(y)
     cphys = (cin + 7) // 8 * 8
     off_in, off_out = 8, 3
