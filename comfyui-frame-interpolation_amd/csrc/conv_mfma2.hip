@@ -17,6 +17,10 @@
 #include "vfi_common.h"
 
 #include <atomic>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace vfi {
 
@@ -164,7 +168,15 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
         bt[nt] = a.beta ? a.beta[co] : 1.f;
     }
 
-    const int nchunks = a.Cin_p / CK;
+    // split-K (small images with many input channels, see launch2_e): blockIdx.z owns the K chunks [k0, k0 + nchunks) and
+    // writes its partial sums to its own slice of a workspace; conv2_split_reduce_kernel adds the slices and applies the epilogue
+    int nchunks = a.Cin_p / CK, k0 = 0;
+    float* const outp = a.out + (size_t)blockIdx.z * a.split_stride;
+    if (a.ksplit > 1) {
+        const int per = (nchunks + a.ksplit - 1) / a.ksplit;
+        k0 = blockIdx.z * per;
+        nchunks = nchunks - k0 < per ? nchunks - k0 : per;
+    }
 
     int tile = blockIdx.x;
     if (tile >= T) return;
@@ -172,7 +184,7 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
     decode(tile, n, Y0, X0);
     make_avoff(Y0, X0, avoff);
     __amdgpu_buffer_rsrc_t rsrc = make_rsrc(n);
-    issue(rsrc, avoff, 0, 0);
+    issue(rsrc, avoff, k0, 0);
     __syncthreads();  // LDS-DMA counts on vmcnt: the barrier's release drains it
     int buf = 0;
     for (;;) {
@@ -193,12 +205,12 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
             // keep the DMA queue one K-chunk ahead — across the tile boundary too, so the matrix pipe
             // never waits for a tile's first chunk and the previous tile's stores drain underneath
             if (k + 1 < nchunks) {
-                issue(rsrc, avoff, k + 1, buf ^ 1);
+                issue(rsrc, avoff, k0 + k + 1, buf ^ 1);
             } else if (has_next) {
                 decode(ntile, nn, nY0, nX0);
                 make_avoff(nY0, nX0, navoff);
                 nrsrc = make_rsrc(nn);
-                issue(nrsrc, navoff, 0, buf ^ 1);
+                issue(nrsrc, navoff, k0, buf ^ 1);
             }
             const float* sb = smem + buf * G::BUF_FLOATS;
             // K-steps of this chunk, software-pipelined: the fragments of step s+1 are requested from LDS
@@ -268,7 +280,7 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
                         const int s = wm * MT + mt;
                         const int sx = s % SUBX, sy = s / SUBX;
                         const int oy0 = Y0 + sy * 4, ox0 = X0 + sx * 8 + 4 * half;
-                        float* ob = a.out + ((size_t)(n * m * a.Hout + m * oy0 + (inter ? (g >> 1) : 0)) * (m * a.Wout) + m * ox0 +
+                        float* ob = outp + ((size_t)(n * m * a.Hout + m * oy0 + (inter ? (g >> 1) : 0)) * (m * a.Wout) + m * ox0 +
                                              (inter ? (g & 1) : 0)) * a.out_cs + co;
                         if (unif01 && interior) {   // the common case: uniform slope in [0,1] -> lrelu(v) == max(v, v*slope)
 #pragma unroll
@@ -300,7 +312,7 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
                 const int co = co0 + nt * 32 + l31;
                 if (co < a.Cout) {
                     const int c = co >> 2;
-                    float* lane_base = a.out + ((size_t)(n * planes + (c >> 2)) * Hs * Ws + (size_t)(2 * (g >> 1) + ((co >> 1) & 1)) * Ws +
+                    float* lane_base = outp + ((size_t)(n * planes + (c >> 2)) * Hs * Ws + (size_t)(2 * (g >> 1) + ((co >> 1) & 1)) * Ws +
                                                 2 * (g & 1) + (co & 1)) * 4 + (c & 3);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
@@ -353,12 +365,12 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
                             if (GROUPED && a.out_mode == 1) {
                                 const int Ws = 4 * a.Wout, Hs = 4 * a.Hout, c = co >> 2;
                                 const int Yt = 4 * oy + 2 * (g >> 1) + ((co >> 1) & 1), Xt = 4 * ox + 2 * (g & 1) + (co & 1);
-                                a.out[((size_t)(n * (a.out_planes ? a.out_planes : 2) + (c >> 2)) * Hs * Ws + (size_t)Yt * Ws + Xt) * 4 + (c & 3)] = v;
+                                outp[((size_t)(n * (a.out_planes ? a.out_planes : 2) + (c >> 2)) * Hs * Ws + (size_t)Yt * Ws + Xt) * 4 + (c & 3)] = v;
                             } else if (EXT && GROUPED && a.out_mode == 2) {
                                 const size_t q2 = (size_t)(n * 2 * a.Hout + 2 * oy + (g >> 1)) * (2 * a.Wout) + 2 * ox + (g & 1);
-                                a.out[q2 * a.out_cs + co] = v;
+                                outp[q2 * a.out_cs + co] = v;
                             } else {
-                                a.out[((size_t)(n * a.Hout + oy) * a.Wout + ox) * a.out_cs + g * a.Cout_p + co] = v;
+                                outp[((size_t)(n * a.Hout + oy) * a.Wout + ox) * a.out_cs + g * a.Cout_p + co] = v;
                             }
                         }
                     }
@@ -377,9 +389,78 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
 #endif
 }
 
+// ---- split-K support -----------------------------------------------------------------------------------------------------
+// out = epilogue(sum_z ws[z] + bias): the epilogue of the generic path of conv_mfma2_kernel, element by element
+__global__ __launch_bounds__(256) void conv2_split_reduce_kernel(const ConvArgs a, const float* __restrict__ ws, int ks, long slice) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;     // over [pixels][Cout]
+    const long total = (long)a.N * a.Hout * a.Wout * a.Cout;
+    if (idx >= total) return;
+    const long p = idx / a.Cout;
+    const int co = (int)(idx - p * a.Cout);
+    float v = 0.f;
+    for (int z = 0; z < ks; ++z) v += ws[z * slice + p * a.Cout_p + co];
+    v += a.bias[co];
+    if (a.beta) v *= a.beta[co];
+    if (a.res) v += a.res[p * a.res_cs + co];
+    if (a.act == 1) v = v > 0.f ? v : v * a.slope;
+    else if (a.act == 2) v = fminf(fmaxf(v, 0.f), 1.f);
+    else if (a.act == 3) v = v > 0.f ? v : v * a.prelu[co];
+    else if (a.act == 4) v = 1.0f / (1.0f + expf(-v));
+    else if (a.act == 5) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    if (a.post_scale != 0.f) v = v * a.post_scale + a.post_shift;
+    a.out[p * a.out_cs + co] = v;
+}
+
+static bool split_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("VFI_CONV_SPLITK");      // experiment hook: VFI_CONV_SPLITK=0 disables split-K
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
+// partial-sum workspace and a zero bias vector, per (device, stream): grow-only, kept for the life of the process
+static int split_workspace(int dev, hipStream_t s, size_t floats, int cout_p, float** ws, float** zeros) {
+    struct Ws {
+        float* p = nullptr;
+        size_t n = 0;
+        float* z = nullptr;
+        int zn = 0;
+    };
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, Ws> table;
+    std::lock_guard<std::mutex> lock(mu);
+    Ws& w = table[{dev, s}];
+    if (w.n < floats) {
+        if (w.p) VFI_CHECK_HIP(hipFree(w.p));      // (synchronises the device; only on growth)
+        w.p = nullptr, w.n = 0;
+        VFI_CHECK_HIP(hipMalloc((void**)&w.p, floats * sizeof(float)));
+        w.n = floats;
+    }
+    if (w.zn < cout_p) {
+        if (w.z) VFI_CHECK_HIP(hipFree(w.z));
+        w.z = nullptr, w.zn = 0;
+        const int n = cout_p < 4096 ? 4096 : cout_p;
+        VFI_CHECK_HIP(hipMalloc((void**)&w.z, n * sizeof(float)));
+        VFI_CHECK_HIP(hipMemset(w.z, 0, n * sizeof(float)));
+        w.zn = n;
+    }
+    *ws = w.p, *zeros = w.z;
+    return 0;
+}
+
+static int split_reduce(const ConvArgs& a, const float* ws, int ks, size_t slice, hipStream_t s) {
+    TraceScope ts("conv_split_reduce", s);
+    const long total = (long)a.N * a.Hout * a.Wout * a.Cout;
+    hipLaunchKernelGGL(conv2_split_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, ws, ks, (long)slice);
+    VFI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 template <int STRIDE, int TAPS, int MT, int NT, int WM, int WN, int CK, bool GROUPED, bool EXT>
 static int launch2_e(ConvArgs a, hipStream_t s, const char* name) {
     using G = Conv2Geom<STRIDE, TAPS, MT, NT, WM, WN, CK, GROUPED>;
+    a.ksplit = 0, a.split_stride = 0;      // launcher-owned fields (callers do not set them)
     a.tiles_x = cdiv(a.Wout, G::TWO);
     a.tiles_y = cdiv(a.Hout, G::THO);
     VFI_REQUIRE(a.Cin_p % CK == 0, "conv2 %s: Cin_p=%d not a multiple of the K chunk %d", name, a.Cin_p, CK);
@@ -411,6 +492,45 @@ static int launch2_e(ConvArgs a, hipStream_t s, const char* name) {
     const int cus = cus_of[dev].load(std::memory_order_relaxed);
     const int T = a.N * a.tiles_x * a.tiles_y;
     const int ny = a.Cout_p / G::BN;
+    // ---- split-K: a coarse pyramid level with many input channels (FILM's 1920 -> 256 at 16 x 30: 32 workgroups, each walking
+    // 240 K chunks: 7.9 TFLOP/s) is cut along K into `ks` launches-in-one (gridDim.z), partial sums to a workspace, then one
+    // reduce + epilogue kernel; fixed summation order, so still deterministic.  Chosen so that the grid reaches ~3 workgroups
+    // per slot while every split keeps >= 8 chunks (the DMA pipeline's prologue / epilogue amortised).
+    int ks = 1;
+    if (!GROUPED && a.out_mode == 0 && a.split_ok && split_enabled()) {
+        const int nchunks = a.Cin_p / CK;
+        const long wgs = (long)T * ny, want = 3L * cus * occ;
+        if (wgs < (long)cus * occ && nchunks >= 16) {      // less than one resident wave of workgroups
+            ks = (int)((want + wgs - 1) / wgs);
+            ks = ks > nchunks / 8 ? nchunks / 8 : ks;
+            ks = ks > 16 ? 16 : ks;
+            // the partial sums cost 8 ks bytes of HBM traffic per output value against 2 TAPS Cin flops: keep that below ~1/4 of
+            // the layer's time (measured on IFUNet's 256 -> 256 layers at 68 x 120: ks = 6 gave back all it gained)
+            const int ks_traffic = TAPS * a.Cin_p / 576;
+            ks = ks > ks_traffic ? ks_traffic : ks;
+            ks = ks < 1 ? 1 : ks;
+            const size_t slice = (size_t)a.N * a.Hout * a.Wout * a.Cout_p;
+            while (ks > 1 && slice * ks * sizeof(float) > (256u << 20)) --ks;
+            const int per = (nchunks + ks - 1) / ks;
+            ks = (nchunks + per - 1) / per;          // no empty split
+        }
+    }
+    if (ks > 1) {
+        const size_t slice = (size_t)a.N * a.Hout * a.Wout * a.Cout_p;
+        float *ws = nullptr, *zeros = nullptr;
+        if (int rc = split_workspace(dev, s, slice * ks, a.Cout_p, &ws, &zeros)) return rc;
+        ConvArgs p = a;                              // the partial-sum launch: raw accumulators, dense [N,H,W,Cout_p]
+        p.out = ws, p.out_cs = a.Cout_p, p.bias = zeros, p.beta = nullptr, p.res = nullptr, p.res_cs = 0;
+        p.act = 0, p.post_scale = 0.f, p.post_shift = 0.f, p.Cout = a.Cout_p;
+        p.ksplit = ks, p.split_stride = (long)slice;
+        {
+            TraceScope ts(name, s);
+            // (the same instantiation as the unsplit launch: its dynamic-LDS attribute is the one set above; pad_replicate implies EXT)
+            hipLaunchKernelGGL((conv_mfma2_kernel<STRIDE, TAPS, MT, NT, WM, WN, CK, GROUPED, EXT>), dim3(T, ny, ks), dim3(256), G::LDS_BYTES, s, p);
+            VFI_CHECK_HIP(hipGetLastError());
+        }
+        return split_reduce(a, ws, ks, slice, s);
+    }
     // Persistent (one resident wave of workgroups, each walks its share of tiles, DMA pipelined across tiles)
     // when every workgroup gets several tiles; with only a few tiles per slot a static split leaves some
     // CUs a whole tile behind, so then launch one workgroup per tile and let the dispatcher balance.

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -305,6 +306,7 @@ int vfi_conv_forward_ex(const vfi_conv_t* c, const float* in_dev, int in_cs, int
     a.ntaps = c->taps;
     a.act = act;
     a.slope = slope;
+    a.split_ok = 1;
     a.post_scale = post_scale;
     a.post_shift = post_shift;
     a.pad_replicate = c->pad_mode;
@@ -350,8 +352,11 @@ int vfi_conv_forward(const vfi_conv_t* c, const float* in_dev, int in_cs, float*
     a.tap_y0 = a.tap_x0 = c->kh == 3 ? -1 : 0;  // 'same': 3x3 centred, 2x2 pads bottom/right, 1x1
     a.act = act;
     a.slope = slope;
-    char name[48];
-    snprintf(name, sizeof(name), "conv%dx%d", c->kh, c->kw);
+    a.split_ok = 1;
+    char name[64];
+    static const bool by_shape = getenv("VFI_TRACE_SHAPES") != nullptr;      // per-shape trace rows (tools/film_bench.py --shapes)
+    if (by_shape) snprintf(name, sizeof(name), "conv%dx%d_%dto%d@%dx%d", c->kh, c->kw, c->Cin_p, c->Cout, H, W);
+    else snprintf(name, sizeof(name), "conv%dx%d", c->kh, c->kw);
     static std::map<std::string, const char*> names;  // stable storage for trace names
     auto it = names.find(name);
     if (it == names.end()) it = names.emplace(name, strdup(name)).first;

@@ -76,6 +76,10 @@ struct ConvArgs {
     int pad_replicate;     // 0: zero padding; 1: replicate (edge clamp) padding of the input
     const float* prelu;    // [Cout_p] per-channel negative slopes (act == 3)
     float post_scale, post_shift;  // y = act(...) * post_scale + post_shift  (post_scale == 0 means "not set" = 1, 0)
+    int split_ok;          // caller: the launcher may cut K over several workgroups (split-K; generic layer objects only — the
+                           //   RIFE network keeps one kernel per layer whatever the batch, so results do not depend on batching)
+    int ksplit;            // set by the launcher: > 1 = split-K launch, blockIdx.z owns a K range and the slice
+    long split_stride;     //   out + blockIdx.z * split_stride (floats) of the partial-sum workspace
 };
 
 struct ConvVariant {

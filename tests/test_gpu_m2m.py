@@ -62,6 +62,10 @@ LAYERS = [
     (0, 3, 1, 0, 0, 16, 9, 2, 21, 30),        # flow-residual + mask-logit head
     (0, 1, 1, 0, 4, 256, 4096, 2, 1, 1),      # cube conv_C (sigmoid)
     (0, 1, 1, 0, 4, 256, 16, 2, 9, 1),        # cube conv_H
+    (0, 3, 1, 0, 1, 1920, 256, 1, 16, 30),    # FILM's coarsest flow-estimator conv: 32 workgroups -> split-K over 16 (conv_mfma2.hip)
+    (0, 3, 1, 0, 1, 1920, 256, 1, 33, 60),    # ... split over fewer
+    (0, 1, 1, 0, 5, 1024, 128, 1, 17, 30),    # 1x1 + GELU, split-K: the epilogue runs in the reduce kernel
+    (0, 3, 2, 0, 3, 768, 128, 1, 18, 30),     # stride 2 + per-channel PReLU, split-K
     (0, 1, 1, 0, 5, 256, 1024, 2, 34, 60),    # GMFlow's FFN: Linear(2c, 8c) + nn.GELU() in the epilogue (interior tiles)
     (0, 1, 1, 0, 5, 256, 1024, 1, 5, 7),      # ... and border tiles
     (0, 3, 1, 0, 5, 16, 9, 1, 9, 11),         # GELU through the generic epilogue

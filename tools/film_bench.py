@@ -39,8 +39,11 @@ if __name__ == "__main__":
     lib.vfi_trace_enable(0)
     rep = _lib.trace_report()
     tot = sum(v[1] for v in rep.values())
+    import re
     for k, v in sorted(rep.items(), key=lambda kv: -kv[1][1]):
-        print(f"   {k:18s} {v[0]:4d} calls {v[1]:9.3f} ms {100 * v[1] / tot:5.1f}%")
+        m = re.match(r"conv(\d)x(\d)_(\d+)to(\d+)@(\d+)x(\d+)", k)      # VFI_TRACE_SHAPES=1: per-shape rows with their rate
+        rate = f"  {2 * int(m[1]) * int(m[2]) * int(m[3]) * int(m[4]) * int(m[5]) * int(m[6]) * v[0] / v[1] / 1e9:6.1f} TFLOP/s" if m else ""
+        print(f"   {k:30s} {v[0]:4d} calls {v[1]:9.3f} ms {100 * v[1] / tot:5.1f}%{rate}")
     if check:
         from oracle import film_oracle
         t0 = time.time()
