@@ -361,6 +361,10 @@ int conv_pick_variant(const ConvArgs& a, int stride, bool grouped) {
     if (!grouped && stride == 2 && a.ntaps == 4) return kConv2Base + (a.Cout_p % 64 == 0 ? 21 : 20);
     if (!grouped && stride == 1 && a.ntaps != 9) {  // 2x2 'same' / 1x1 convs (FILM): second generation only
         const bool big = px * (a.Cout_p / 32) >= 256L * 4 * n_cus_cached();
+        // 1x1: a K chunk of 8 channels is ONE K-step per barrier; with 32-channel chunks (4 steps) GMFlow's projections / FFN
+        // run 10-25 % faster (tools/conv1x1_bench.py, profiles/r02b_conv1x1_variants.txt); wide inputs take the 128-channel N tile
+        if (a.ntaps == 1 && a.Cout_p % 64 == 0 && a.Cin_p % 32 == 0)
+            return kConv2Base + (a.Cin_p >= 512 && a.Cout_p % 128 == 0 ? 24 : 23);     // d1t1_m2n2w22k32 / d1t1_m1n2k32
         if (a.Cout_p % 64 == 0) return kConv2Base + (a.ntaps == 4 ? (big ? 14 : 15) : (big ? 16 : 17));
         return kConv2Base + (a.ntaps == 4 ? 19 : 18);
     }

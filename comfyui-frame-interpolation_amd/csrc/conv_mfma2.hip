@@ -36,8 +36,12 @@ struct Conv2Geom {
     static constexpr int SUBX = SUBS >= 16 ? 4 : (SUBS >= 2 ? 2 : 1);   // 16 sub-tiles: 32 x 16 pixels (divides 480 x 272)
     static constexpr int SUBY = SUBS / SUBX;
     static constexpr int TWO = SUBX * 8, THO = SUBY * 4;
-    static constexpr int TWI = STRIDE * (TWO - 1) + 3;
-    static constexpr int THI = STRIDE * (THO - 1) + 3;
+    // input tile: the rows / columns the taps reach.  3x3 (pad 1) and the grouped transposed conv (2x2 taps from origin -1 or 0)
+    // need one halo pixel before and one after; 2x2 'same' (pads bottom / right) one after; 1x1 none
+    static constexpr int PADLO = (TAPS == 9 || GROUPED) ? 1 : 0;
+    static constexpr int SPAN = (TAPS == 9 || GROUPED) ? 3 : KW;
+    static constexpr int TWI = STRIDE * (TWO - 1) + SPAN;
+    static constexpr int THI = STRIDE * (THO - 1) + SPAN;
     static constexpr int NPIX = TWI * THI;
     static constexpr int Q = CK / 4;
     static constexpr int C8 = CK / 8;
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
     };
     // activation DMA: voffset per 16-byte piece inside the image; out-of-image halo -> out of range -> zero fill
     auto make_avoff = [&](int Y0, int X0, int(&avoff)[G::NAW]) {
-        const int iy0 = STRIDE * Y0 - 1, ix0 = STRIDE * X0 - 1;
+        const int iy0 = STRIDE * Y0 - G::PADLO, ix0 = STRIDE * X0 - G::PADLO;
 #pragma unroll
         for (int i = 0; i < G::NAW; ++i) {
             const int j = wave + 4 * i;
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
         const int s = wm * MT + mt;
         const int sx = s % SUBX, sy = s / SUBX;
         const int oy = sy * 4 + (l31 >> 3), ox = sx * 8 + (l31 & 7);
-        abase[mt] = ((STRIDE * oy + 1 + tby) * TWI + STRIDE * ox + 1 + tbx) * CK + half * 4;
+        abase[mt] = ((STRIDE * oy + G::PADLO + tby) * TWI + STRIDE * ox + G::PADLO + tbx) * CK + half * 4;
     }
     // B image: [group][tap][c8][BN][8]; this wave's channels start at (co0 - cob)
     const int bbase = G::A_FLOATS + (g * TAPS * C8 * BN + (co0 - cob) + l31) * 8 + half * 4;
@@ -577,6 +581,8 @@ static const ConvVariant kVariants2[] = {
     {"d2t4_m2n1", 2, 4, 2, 1, 4, 1, 8, 0},    // 52: 2x2 stride 2 (M2M 'sconv(2)'), 32-channel N tile
     {"d2t4_m1n2", 2, 4, 1, 2, 4, 1, 8, 0},    // 53
     {"d1_m4n2", 1, 9, 4, 2, 4, 1, 8, 0},      // 54: 32x16 px x 64 ch (8 accumulators per wave)
+    {"d1t1_m1n2k32", 1, 1, 1, 2, 4, 1, 32, 0},      // 55: 1x1 with 32-channel K chunks (4 K-steps per barrier instead of 1), 16x8 px x 64 ch
+    {"d1t1_m2n2w22k32", 1, 1, 2, 2, 2, 2, 32, 0},   // 56: ... 16x8 px x 128 ch (wide inputs)
 };
 int conv2_num_variants() { return (int)(sizeof(kVariants2) / sizeof(kVariants2[0])); }
 const ConvVariant& conv2_variant(int i) { return kVariants2[i]; }
@@ -606,6 +612,8 @@ int conv2_launch(const ConvArgs& a, int idx, hipStream_t s, const char* nm) {
         case 20: return launch2_t<2, 4, 2, 1, 4, 1, 8, false>(a, s, nm);
         case 21: return launch2_t<2, 4, 1, 2, 4, 1, 8, false>(a, s, nm);
         case 22: return launch2_t<1, 9, 4, 2, 4, 1, 8, false>(a, s, nm);
+        case 23: return launch2_t<1, 1, 1, 2, 4, 1, 32, false>(a, s, nm);
+        case 24: return launch2_t<1, 1, 2, 2, 2, 2, 32, false>(a, s, nm);
     }
     set_error("conv2: bad variant %d", idx);
     return -3;

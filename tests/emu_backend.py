@@ -46,7 +46,7 @@ _V1 = {0: (16, 64), 1: (16, 96), 2: (16, 64), 3: (16, 96), 4: (16, 32), 5: (16, 
        10: (8, 32), 11: (8, 64), 12: (16, 32), 13: (16, 32)}                       # variant -> (K chunk, N tile)
 _V2 = {0: (8, 64), 1: (8, 96), 2: (8, 64), 3: (8, 96), 4: (8, 128), 5: (8, 128), 6: (16, 64), 7: (8, 64), 8: (8, 64), 9: (8, 96), 10: (8, 32),
        11: (8, 32), 12: (8, 32), 13: (8, 32), 14: (8, 64), 15: (8, 64), 16: (8, 64), 17: (8, 64), 18: (8, 32), 19: (8, 32), 20: (8, 32), 21: (8, 64),
-       22: (8, 64)}
+       22: (8, 64), 23: (32, 64), 24: (32, 128)}
 
 
 def conv_variant(grouped, taps, stride, cin_p, cout_p, px, out_mode=0, n_cus=256):
@@ -54,6 +54,8 @@ def conv_variant(grouped, taps, stride, cin_p, cout_p, px, out_mode=0, n_cus=256
         return _K2 + (21 if cout_p % 64 == 0 else 20)
     if not grouped and stride == 1 and taps != 9:
         big = px * (cout_p // 32) >= 256 * 4 * n_cus
+        if taps == 1 and cout_p % 64 == 0 and cin_p % 32 == 0:
+            return _K2 + (24 if (cin_p >= 512 and cout_p % 128 == 0) else 23)
         if cout_p % 64 == 0:
             return _K2 + ((14 if big else 15) if taps == 4 else (16 if big else 17))
         return _K2 + (19 if taps == 4 else 18)
