@@ -246,21 +246,30 @@ class GMFSSEngine(OpsEngine):
     def _transformer(self, a, splits):
         """FeatureTransformer.forward on a [2D, h, w, 128] (per direction: source, target), in place"""
         B, h, w, c = a.shape
-        o = self._t("tf_o", B, h, w, c)
-        self._pair_swap(a, o)
-        q, k, v, m = (self._t("tf_" + n, B, h, w, c) for n in ("q", "k", "v", "m"))
+        q, ks, vs, m = (self._t("tf_" + n, B, h, w, c) for n in ("q", "k", "v", "m"))
         cat = self._t("tf_cat", B, h, w, 2 * c)
         hid = self._t("tf_hid", B, h, w, 8 * c)
+        kx, vx = self._t("tf_kx", B, h, w, c), self._t("tf_vx", B, h, w, c)
         for i, blk in enumerate(self.tf):
             shifted = i % 2 == 1
-            for part, tgt in (("self_attn", a), ("cross_attn_ffn", o)):
+            # The cross part attends to the OTHER image's features as they were when the block started (concat1 is rebuilt only
+            # after a whole block, :664-678): its key / value projections are taken here, before the self part updates `a`, with
+            # the (source, target) swap as the batch index of the projection's input — no swapped copy of the features.
+            for j in range(B):
+                self._conv(blk["cross_attn_ffn"]["k_proj"], a[j ^ 1:(j ^ 1) + 1], 0, kx[j:j + 1], 0)
+                self._conv(blk["cross_attn_ffn"]["v_proj"], a[j ^ 1:(j ^ 1) + 1], 0, vx[j:j + 1], 0)
+            for part in ("self_attn", "cross_attn_ffn"):
                 L = blk[part]
+                ffn = part == "cross_attn_ffn"
                 self._conv(L["q_proj"], a, 0, q, 0)
-                self._conv(L["k_proj"], tgt, 0, k, 0)
-                self._conv(L["v_proj"], tgt, 0, v, 0)
+                if ffn:
+                    k, v = kx, vx
+                else:
+                    k, v = ks, vs
+                    self._conv(L["k_proj"], a, 0, k, 0)
+                    self._conv(L["v_proj"], a, 0, v, 0)
                 self._attention(q, k, v, m, h, w, splits, shifted)
                 self._conv(L["merge"], m, 0, q, 0)
-                ffn = part == "cross_attn_ffn"
                 dst, doff = (cat, c) if ffn else (m, 0)
                 self._c("vfi_layernorm", _p(q), c, c, B * h * w, _p(L["norm1"][0]), _p(L["norm1"][1]), _p(dst, doff), dst.shape[-1])
                 if ffn:
@@ -269,7 +278,6 @@ class GMFSSEngine(OpsEngine):
                     self._conv(L["mlp2"], hid, 0, q, 0)
                     self._c("vfi_layernorm", _p(q), c, c, B * h * w, _p(L["norm2"][0]), _p(L["norm2"][1]), _p(m), c)
                 self._ax(a, 0, m, 0, a, 0, c)
-            self._pair_swap(a, o)
 
     def _add_position(self, t, splits):
         B, h, w, c = t.shape

@@ -26,3 +26,15 @@ def test_widget_lists_match_the_reference():
     assert req("GMFSS Fortuna VFI") == ["ckpt_name", "frames", "clear_cache_after_n_frames", "multiplier"]           # gmfss_fortuna
     assert m["GMFSS Fortuna VFI"].INPUT_TYPES()["required"]["ckpt_name"][0] == ["GMFSS_fortuna_union", "GMFSS_fortuna"]
     assert req("M2M VFI") == ["ckpt_name", "frames", "clear_cache_after_n_frames", "multiplier"]
+
+
+def test_rife_launch_size():
+    """tasks per launch of the RIFE node: the widget bounded to the library's range, a floor of 8 (4 from 4K up), and at least
+    four launches per host clip when it has the tasks for it (upload / compute / download overlap)"""
+    from cfi_amd.rife import effective_batch
+
+    assert effective_batch(1, 1080, 1920) == 8 and effective_batch(64, 1080, 1920) == 32 and effective_batch(1, 2160, 4096) == 4
+    assert effective_batch(16, 1080, 1920, 32) == 8          # a 33-frame clip: four launches of 8
+    assert effective_batch(16, 1080, 1920, 500) == 16        # long clips keep the widget's size
+    assert effective_batch(32, 1080, 1920, 100) == 25
+    assert effective_batch(16, 1080, 1920, 3) == 8           # (the launch is simply short)
