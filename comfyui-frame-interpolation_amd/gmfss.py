@@ -91,7 +91,7 @@ def shift_labels(h, w, k):
 
 class GMFSSEngine(OpsEngine):
     def __init__(self, state_dicts, device=None, _test_backend=None):
-        super().__init__(device, _test_backend)
+        super().__init__(device, _test_backend, pooled=True)      # 1080p: 9.9 GiB of named scratch tensors without the pool
         self.union = "ifnet" in state_dicts      # the union model carries rife46.pth; the base model has no IFNet
         shapes = gmfss_shapes("union" if self.union else "base")
         for part in shapes:
@@ -190,12 +190,13 @@ class GMFSSEngine(OpsEngine):
         """Sequential(PReLU(a), conv | deconv, PReLU(b), conv)(src[..., soff:soff+cin]) (+ res) -> dst[..., doff:]"""
         a, first, second = blk
         n, h, w, _ = src.shape
-        t = self._t("pair_in_" + tag, n, h, w, _cs(cin))
-        self._prelu(src, soff, t, 0, cin, a)
-        ho, wo = (2 * h, 2 * w) if first["kind"] == 1 else (h // first["stride"], w // first["stride"])
-        m = self._t("pair_mid_" + tag, n, ho, wo, _cs(first["cout"]))
-        self._conv(first, t, 0, m, 0)
-        self._conv(second, m, 0, dst, doff, res=res)
+        with self._scope():
+            t = self._t("pair_in_" + tag, n, h, w, _cs(cin))
+            self._prelu(src, soff, t, 0, cin, a)
+            ho, wo = (2 * h, 2 * w) if first["kind"] == 1 else (h // first["stride"], w // first["stride"])
+            m = self._t("pair_mid_" + tag, n, ho, wo, _cs(first["cout"]))
+            self._conv(first, t, 0, m, 0)
+            self._conv(second, m, 0, dst, doff, res=res)
 
     def _instnorm(self, x, c, relu1, add, relu2, out):
         n, h, w, cs = x.shape
@@ -211,20 +212,22 @@ class GMFSSEngine(OpsEngine):
         n, h, w, _ = x.shape
         ho, wo, c = h // stride, w // stride, c1["cout"]
         tag = f"{key[0]}{key[1]}"
-        a, b, y = (self._t(f"bb_{tag}_{k}", n, ho, wo, c) for k in "aby")
-        self._conv(c1, x, 0, a, 0)
-        self._instnorm(a, c, True, None, False, a)
-        self._conv(c2, a, 0, b, 0)
-        short = x
-        if ds is not None:
-            xs = x
-            if stride == 2:   # 1x1 conv with stride 2 = sample the even pixels, then the 1x1 conv
-                xs = self._t(f"bb_{tag}_sub", n, ho, wo, x.shape[-1])
-                self._c("vfi_upsample_nearest", _p(x), x.shape[-1], _p(xs), xs.shape[-1], n, h, w, ho, wo, cin)
-            short = self._t(f"bb_{tag}_s", n, ho, wo, c)
-            self._conv(ds, xs, 0, short, 0)
-            self._instnorm(short, c, False, None, False, short)
-        self._instnorm(b, c, True, short, True, y)
+        y = self._t(f"bb_{tag}_y", n, ho, wo, c)
+        with self._scope():
+            a, b = (self._t(f"bb_{tag}_{k}", n, ho, wo, c) for k in "ab")
+            self._conv(c1, x, 0, a, 0)
+            self._instnorm(a, c, True, None, False, a)
+            self._conv(c2, a, 0, b, 0)
+            short = x
+            if ds is not None:
+                xs = x
+                if stride == 2:   # 1x1 conv with stride 2 = sample the even pixels, then the 1x1 conv
+                    xs = self._t(f"bb_{tag}_sub", n, ho, wo, x.shape[-1])
+                    self._c("vfi_upsample_nearest", _p(x), x.shape[-1], _p(xs), xs.shape[-1], n, h, w, ho, wo, cin)
+                short = self._t(f"bb_{tag}_s", n, ho, wo, c)
+                self._conv(ds, xs, 0, short, 0)
+                self._instnorm(short, c, False, None, False, short)
+            self._instnorm(b, c, True, short, True, y)
         return y
 
     def _attention(self, q, k, v, out, h, w, splits, shifted):
@@ -246,38 +249,39 @@ class GMFSSEngine(OpsEngine):
     def _transformer(self, a, splits):
         """FeatureTransformer.forward on a [2D, h, w, 128] (per direction: source, target), in place"""
         B, h, w, c = a.shape
-        q, ks, vs, m = (self._t("tf_" + n, B, h, w, c) for n in ("q", "k", "v", "m"))
-        cat = self._t("tf_cat", B, h, w, 2 * c)
-        hid = self._t("tf_hid", B, h, w, 8 * c)
-        kx, vx = self._t("tf_kx", B, h, w, c), self._t("tf_vx", B, h, w, c)
-        for i, blk in enumerate(self.tf):
-            shifted = i % 2 == 1
-            # The cross part attends to the OTHER image's features as they were when the block started (concat1 is rebuilt only
-            # after a whole block, :664-678): its key / value projections are taken here, before the self part updates `a`, with
-            # the (source, target) swap as the batch index of the projection's input — no swapped copy of the features.
-            for j in range(B):
-                self._conv(blk["cross_attn_ffn"]["k_proj"], a[j ^ 1:(j ^ 1) + 1], 0, kx[j:j + 1], 0)
-                self._conv(blk["cross_attn_ffn"]["v_proj"], a[j ^ 1:(j ^ 1) + 1], 0, vx[j:j + 1], 0)
-            for part in ("self_attn", "cross_attn_ffn"):
-                L = blk[part]
-                ffn = part == "cross_attn_ffn"
-                self._conv(L["q_proj"], a, 0, q, 0)
-                if ffn:
-                    k, v = kx, vx
-                else:
-                    k, v = ks, vs
-                    self._conv(L["k_proj"], a, 0, k, 0)
-                    self._conv(L["v_proj"], a, 0, v, 0)
-                self._attention(q, k, v, m, h, w, splits, shifted)
-                self._conv(L["merge"], m, 0, q, 0)
-                dst, doff = (cat, c) if ffn else (m, 0)
-                self._c("vfi_layernorm", _p(q), c, c, B * h * w, _p(L["norm1"][0]), _p(L["norm1"][1]), _p(dst, doff), dst.shape[-1])
-                if ffn:
-                    self._ax(a, 0, None, 0, cat, 0, c)
-                    self._conv(L["mlp0"], cat, 0, hid, 0, act=5)         # Linear + nn.GELU() in the conv's epilogue
-                    self._conv(L["mlp2"], hid, 0, q, 0)
-                    self._c("vfi_layernorm", _p(q), c, c, B * h * w, _p(L["norm2"][0]), _p(L["norm2"][1]), _p(m), c)
-                self._ax(a, 0, m, 0, a, 0, c)
+        with self._scope():      # q / k / v / message / FFN buffers: 1.2 GiB at 1080p, dead when the transformer returns
+            q, ks, vs, m = (self._t("tf_" + n, B, h, w, c) for n in ("q", "k", "v", "m"))
+            cat = self._t("tf_cat", B, h, w, 2 * c)
+            hid = self._t("tf_hid", B, h, w, 8 * c)
+            kx, vx = self._t("tf_kx", B, h, w, c), self._t("tf_vx", B, h, w, c)
+            for i, blk in enumerate(self.tf):
+                shifted = i % 2 == 1
+                # The cross part attends to the OTHER image's features as they were when the block started (concat1 is rebuilt only
+                # after a whole block, :664-678): its key / value projections are taken here, before the self part updates `a`, with
+                # the (source, target) swap as the batch index of the projection's input — no swapped copy of the features.
+                for j in range(B):
+                    self._conv(blk["cross_attn_ffn"]["k_proj"], a[j ^ 1:(j ^ 1) + 1], 0, kx[j:j + 1], 0)
+                    self._conv(blk["cross_attn_ffn"]["v_proj"], a[j ^ 1:(j ^ 1) + 1], 0, vx[j:j + 1], 0)
+                for part in ("self_attn", "cross_attn_ffn"):
+                    L = blk[part]
+                    ffn = part == "cross_attn_ffn"
+                    self._conv(L["q_proj"], a, 0, q, 0)
+                    if ffn:
+                        k, v = kx, vx
+                    else:
+                        k, v = ks, vs
+                        self._conv(L["k_proj"], a, 0, k, 0)
+                        self._conv(L["v_proj"], a, 0, v, 0)
+                    self._attention(q, k, v, m, h, w, splits, shifted)
+                    self._conv(L["merge"], m, 0, q, 0)
+                    dst, doff = (cat, c) if ffn else (m, 0)
+                    self._c("vfi_layernorm", _p(q), c, c, B * h * w, _p(L["norm1"][0]), _p(L["norm1"][1]), _p(dst, doff), dst.shape[-1])
+                    if ffn:
+                        self._ax(a, 0, None, 0, cat, 0, c)
+                        self._conv(L["mlp0"], cat, 0, hid, 0, act=5)         # Linear + nn.GELU() in the conv's epilogue
+                        self._conv(L["mlp2"], hid, 0, q, 0)
+                        self._c("vfi_layernorm", _p(q), c, c, B * h * w, _p(L["norm2"][0]), _p(L["norm2"][1]), _p(m), c)
+                    self._ax(a, 0, m, 0, a, 0, c)
 
     def _add_position(self, t, splits):
         B, h, w, c = t.shape
@@ -291,42 +295,59 @@ class GMFSSEngine(OpsEngine):
         assert frame1.shape == frame0.shape and Cc >= 3 and frame0.is_contiguous() and frame1.is_contiguous()
         Hp, Wp = ((H - 1) // 64 + 1) * 64, ((W - 1) // 64 + 1) * 64
         Hh, Wh = Hp // 2, Wp // 2
+        # what render() needs stays allocated (root of the pool); everything else lives in scopes and is recycled
         img = self._t("img", 2, Hp, Wp, 8)
+        himg, flows, metric = self._t("himg", 2, Hh, Wh, 8), self._t("flows", 2, Hh, Wh, 2), self._t("metric", 1, Hh, Wh, 8)
         for i, f in enumerate((frame0, frame1)):
             self._c("vfi_pad_rgb", f.data_ptr(), Cc, H, W, _p(img[i]), 8, Hp, Wp)
         # FeatureNet on both frames
         feats, x, cin = [], img, 3
         for k, (a, first, second) in enumerate(self.fe):
             n, h, w, _ = x.shape
-            t = self._t(f"fe_in{k}", 2, h, w, _cs(cin))
-            self._prelu(x, 0, t, 0, cin, a)
-            m = self._t(f"fe_mid{k}", 2, h // 2, w // 2, first["cout"])
-            self._conv(first, t, 0, m, 0)
             f = self._t(f"feat{k}", 2, h // 2, w // 2, first["cout"])
-            self._conv(second, m, 0, f, 0)
+            with self._scope():
+                t = self._t(f"fe_in{k}", 2, h, w, _cs(cin))
+                self._prelu(x, 0, t, 0, cin, a)
+                m = self._t(f"fe_mid{k}", 2, h // 2, w // 2, first["cout"])
+                self._conv(first, t, 0, m, 0)
+                self._conv(second, m, 0, f, 0)
             feats.append(f)
             x, cin = f, first["cout"]
-        himg = self._t("himg", 2, Hh, Wh, 8)
         self._resize(img, 0, himg, 0, 3)
-        flows = self._gmflow(himg)
+        with self._scope():
+            self._gmflow(himg, flows)
         # MetricNet
-        mi = self._t("m_in", 1, Hh, Wh, 16)
-        self._c("vfi_gmfss_metric_inputs", _p(himg[0]), _p(himg[1]), 8, _p(flows[0]), _p(flows[1]), 2, _p(mi), 16, Hh, Wh)
-        feat, tmp, nxt = (self._t("m_" + n, 1, Hh, Wh, 64) for n in ("feat", "tmp", "nxt"))
-        self._conv(self.m_in, mi, 0, feat, 0)
-        for slope, conv in self.m_net:
-            self._prelu(feat, 0, tmp, 0, 64, slope)
-            self._conv(conv, tmp, 0, nxt, 0, res=feat)
-            feat, nxt = nxt, feat
-        metric = self._t("metric", 1, Hh, Wh, 8)
-        self._prelu(feat, 0, tmp, 0, 64, self.m_out[0])
-        self._conv(self.m_out[1], tmp, 0, metric, 0)
-        self._c("vfi_tanh_scale", _p(metric), 8, 2, Hh * Wh, 10.0)
+        with self._scope():
+            mi = self._t("m_in", 1, Hh, Wh, 16)
+            self._c("vfi_gmfss_metric_inputs", _p(himg[0]), _p(himg[1]), 8, _p(flows[0]), _p(flows[1]), 2, _p(mi), 16, Hh, Wh)
+            feat, tmp, nxt = (self._t("m_" + n, 1, Hh, Wh, 64) for n in ("feat", "tmp", "nxt"))
+            self._conv(self.m_in, mi, 0, feat, 0)
+            for slope, conv in self.m_net:
+                self._prelu(feat, 0, tmp, 0, 64, slope)
+                self._conv(conv, tmp, 0, nxt, 0, res=feat)
+                feat, nxt = nxt, feat
+            self._prelu(feat, 0, tmp, 0, 64, self.m_out[0])
+            self._conv(self.m_out[1], tmp, 0, metric, 0)
+            self._c("vfi_tanh_scale", _p(metric), 8, 2, Hh * Wh, 10.0)
         self.prepared = dict(H=H, W=W, Hp=Hp, Wp=Wp, img=img, himg=himg, feats=feats, flows=flows, metric=metric)
         return self.prepared
 
-    def _gmflow(self, himg):
+    def _gmflow(self, himg, flows):
         """GMFlow.forward (:1262-1372) for both directions -> flows [2, Hh, Wh, 2] (index 0 = flow01, 1 = flow10)"""
+        _, Hh, Wh, _ = himg.shape
+        h4, w4 = Hh // 4, Wh // 4
+        fhi, flo = self._t("f_hi", 2, h4, w4, 128), self._t("f_lo", 2, h4 // 2, w4 // 2, 128)
+        with self._scope():
+            self._backbone(himg, fhi, flo)
+        flow8p = self._t("s0_flowp", 2, h4 // 2, w4 // 2, 2)
+        with self._scope():
+            self._match_global(flo, flow8p)
+        with self._scope():
+            self._refine_local(fhi, flow8p, flows)
+        return flows
+
+    def _backbone(self, himg, fhi, flo):
+        """CNNEncoder (:218-272) + the trident convs: features at 1/4 (fhi) and 1/8 (flo) of the half-resolution pair"""
         _, Hh, Wh, _ = himg.shape
         nimg = self._t("nimg", 2, Hh, Wh, 8)
         mean, std = (C.c_float * 3)(*IMAGENET_MEAN), (C.c_float * 3)(*IMAGENET_STD)
@@ -342,13 +363,16 @@ class GMFSSEngine(OpsEngine):
                 x = self._res_block((name, blk), x, cin)
                 cin = x.shape[-1]
         h4, w4 = x.shape[1:3]
+        assert (h4, w4) == tuple(fhi.shape[1:3])
         f4 = self._t("bb_f4", 2, h4, w4, 128)
         self._conv(self.bb_conv2, x, 0, f4, 0)
-        fhi, flo = self._t("f_hi", 2, h4, w4, 128), self._t("f_lo", 2, h4 // 2, w4 // 2, 128)
         self._conv(self.trident[0], f4, 0, fhi, 0)
         self._conv(self.trident[1], f4, 0, flo, 0)
-        # ---- scale 0: global matching at 1/8, both directions from one transformer pass
-        h8, w8 = h4 // 2, w4 // 2
+
+    def _match_global(self, flo, flow8p):
+        """scale 0 (:1293-1335 with attn_splits 2, global correlation, global propagation) -> flow8p at 1/8"""
+        _, h8, w8, _ = flo.shape
+        # global matching at 1/8, both directions from one transformer pass
         L = h8 * w8
         a = self._t("s0_a", 2, h8, w8, 128)
         self._ax(flo, 0, None, 0, a, 0, 128)
@@ -366,9 +390,14 @@ class GMFSSEngine(OpsEngine):
         q, k = self._t("s0_q", 2, h8, w8, 128), self._t("s0_k", 2, h8, w8, 128)
         self._conv(self.prop_q, a, 0, q, 0)
         self._conv(self.prop_k, q, 0, k, 0)
-        flow8p = self._t("s0_flowp", 2, h8, w8, 2)
         self._c("vfi_attention", _p(q), 128, _p(k), 128, _p(flow8), 2, _p(flow8p), 2, 2, L, L, 128, 2, 1.0 / 128 ** 0.5, None, 0)
-        # ---- scale 1: local refinement at 1/4, one batch entry pair per direction
+
+    def _refine_local(self, fhi, flow8p, flows):
+        """scale 1 (:1293-1372 with attn_splits 8, local correlation radius 4, local propagation, convex up-sampling)"""
+        _, h4, w4, _ = fhi.shape
+        h8, w8 = h4 // 2, w4 // 2
+        Hh, Wh = flows.shape[1:3]
+        # local refinement at 1/4, one batch entry pair per direction
         flow4 = self._t("s1_flow", 2, h4, w4, 2)
         self._c("vfi_resize_bilinear_ac", _p(flow8p), 2, _p(flow4), 2, 2, h8, w8, h4, w4, 2, 2.0)
         fsw = self._t("s1_fsw", 2, h4, w4, 128)
@@ -394,9 +423,8 @@ class GMFSSEngine(OpsEngine):
         self._conv(self.up0, cat, 0, u, 0, act=1, slope=0.0)          # ReLU
         msk = self._t("s1_mask", 2, h4, w4, 144)
         self._conv(self.up2, u, 0, msk, 0)
-        flows = self._t("flows", 2, Hh, Wh, 2)
+        assert (Hh, Wh) == (4 * h4, 4 * w4)
         self._c("vfi_convex_upsample", _p(msk), 144, _p(flow4p), 2, _p(flows), 2, 2, h4, w4, 4)
-        return flows
 
     # ---- Model.inference --------------------------------------------------------------------------------------------
     def render(self, t, out):
@@ -406,141 +434,165 @@ class GMFSSEngine(OpsEngine):
         Hh, Wh = Hp // 2, Wp // 2
         t = float(t)
         himg, flows, metric, feats = P["himg"], P["flows"], P["metric"], P["feats"]
-        ft, zt = self._t("ft", 2, Hh, Wh, 2), self._t("zt", 2, Hh, Wh, 1)
-        for d, tt in ((0, t), (1, 1 - t)):
-            self._ax(flows[d:d + 1], 0, None, 0, ft[d:d + 1], 0, 2, tt)          # F_t = t * flow01, (1 - t) * flow10
-            self._ax(metric, d, None, 0, zt[d:d + 1], 0, 1, tt)                  # Z_t
-        g_in = [self._t("g_in0", 1, Hh, Wh, 16), self._t("g_in1", 1, Hh, Wh, 128), self._t("g_in2", 1, Hh // 2, Wh // 2, 256),
-                self._t("g_in3", 1, Hh // 4, Wh // 4, 384)]
-        for lvl in range(3):
-            s = 1 << lvl
-            h, w = Hh // s, Wh // s
-            if lvl == 0:
-                fl, zl = ft, zt
-            else:   # F.interpolate(F_t, 1/s) * (1/s), F.interpolate(Z_t, 1/s)
-                fl, zl = self._t(f"ft{lvl}", 2, h, w, 2), self._t(f"zt{lvl}", 2, h, w, 1)
-                self._resize(ft, 0, fl, 0, 2, 1.0 / s)
-                self._resize(zt, 0, zl, 0, 1)
-            c = feats[lvl].shape[-1]
-            for d in (0, 1):
-                if lvl == 0:   # union head: (I1t, rife, I2t); base head: (img0, I1t, I2t, img1)
-                    self._splat(himg[d:d + 1], 3, zl[d:d + 1], fl[d:d + 1], g_in[0], 6 * d if self.union else 3 + 3 * d)
-                self._splat(feats[lvl][d:d + 1], c, zl[d:d + 1], fl[d:d + 1], g_in[lvl + 1], c * d)
-        if self.union:
-            self._ifnet46(himg, t, g_in[0], 3)
-        else:
-            self._ax(himg[0:1], 0, None, 0, g_in[0], 0, 3)
-            self._ax(himg[1:2], 0, None, 0, g_in[0], 9, 3)
-        y = self._gridnet(g_in)
-        self._c("vfi_clamp_crop", _p(y), y.shape[-1], Hp, Wp, out.data_ptr(), H, W, 3)
+        with self._scope():
+            ft, zt = self._t("ft", 2, Hh, Wh, 2), self._t("zt", 2, Hh, Wh, 1)
+            for d, tt in ((0, t), (1, 1 - t)):
+                self._ax(flows[d:d + 1], 0, None, 0, ft[d:d + 1], 0, 2, tt)          # F_t = t * flow01, (1 - t) * flow10
+                self._ax(metric, d, None, 0, zt[d:d + 1], 0, 1, tt)                  # Z_t
+            g_in = [self._t("g_in0", 1, Hh, Wh, 16), self._t("g_in1", 1, Hh, Wh, 128), self._t("g_in2", 1, Hh // 2, Wh // 2, 256),
+                    self._t("g_in3", 1, Hh // 4, Wh // 4, 384)]
+            for lvl in range(3):
+                s = 1 << lvl
+                h, w = Hh // s, Wh // s
+                if lvl == 0:
+                    fl, zl = ft, zt
+                else:   # F.interpolate(F_t, 1/s) * (1/s), F.interpolate(Z_t, 1/s)
+                    fl, zl = self._t(f"ft{lvl}", 2, h, w, 2), self._t(f"zt{lvl}", 2, h, w, 1)
+                    self._resize(ft, 0, fl, 0, 2, 1.0 / s)
+                    self._resize(zt, 0, zl, 0, 1)
+                c = feats[lvl].shape[-1]
+                for d in (0, 1):
+                    if lvl == 0:   # union head: (I1t, rife, I2t); base head: (img0, I1t, I2t, img1)
+                        self._splat(himg[d:d + 1], 3, zl[d:d + 1], fl[d:d + 1], g_in[0], 6 * d if self.union else 3 + 3 * d)
+                    self._splat(feats[lvl][d:d + 1], c, zl[d:d + 1], fl[d:d + 1], g_in[lvl + 1], c * d)
+            if self.union:
+                self._ifnet46(himg, t, g_in[0], 3)
+            else:
+                self._ax(himg[0:1], 0, None, 0, g_in[0], 0, 3)
+                self._ax(himg[1:2], 0, None, 0, g_in[0], 9, 3)
+            y = self._gridnet(g_in)
+            self._c("vfi_clamp_crop", _p(y), y.shape[-1], Hp, Wp, out.data_ptr(), H, W, 3)
         return out
 
     def _splat(self, x, c, z, flow, dst, doff):
         """softsplat(x, flow, z, "soft") -> dst[..., doff:doff+c]"""
         _, h, w, _ = x.shape
-        pre, fo, s = self._t("sp_pre", h * w, c + 1), self._t("sp_flow", h * w, 2), self._t("sp_out", h * w, c + 1)
-        self._c("vfi_splat_prep", _p(x), x.shape[-1], _p(z), z.shape[-1], _p(flow), flow.shape[-1], _p(pre), _p(fo), c, h * w, 1.0, 1.0)
-        self._c("vfi_softsplat_sum", _p(pre), _p(fo), _p(s), 1, h, w, c + 1)
-        self._c("vfi_splat_normalize", _p(s), _p(dst, doff), dst.shape[-1], c, h * w)
+        with self._scope():
+            pre, fo, s = self._t("sp_pre", h * w, c + 1), self._t("sp_flow", h * w, 2), self._t("sp_out", h * w, c + 1)
+            self._c("vfi_splat_prep", _p(x), x.shape[-1], _p(z), z.shape[-1], _p(flow), flow.shape[-1], _p(pre), _p(fo), c, h * w, 1.0, 1.0)
+            self._c("vfi_softsplat_sum", _p(pre), _p(fo), _p(s), 1, h, w, c + 1)
+            self._c("vfi_splat_normalize", _p(s), _p(dst, doff), dst.shape[-1], c, h * w)
 
     def _ifnet46(self, himg, t, dst, doff):
         """IFNet("4.6").forward (rife_arch.py:465-732) on the half-resolution pair -> dst[..., doff:doff+3]"""
         _, Hh, Wh, _ = himg.shape
         Hq, Wq = ((Hh - 1) // 64 + 1) * 64, ((Wh - 1) // 64 + 1) * 64
-        x7 = self._t("r_x7", 1, Hq, Wq, 8)          # clamp(img0), clamp(img1), t, 0
-        self._c("vfi_rife40_prep", _p(himg[0]), _p(himg[1]), 8, Hh, Wh, t, _p(x7), Hq, Wq)
-        xin = self._t("r_xin", 1, Hq, Wq, 8)        # warped img0, warped img1, t, mask
-        self._ax(x7, 6, None, 0, xin, 6, 1)
-        flow, df, dm = self._t("r_flow", 1, Hq, Wq, 4), self._t("r_df", 1, Hq, Wq, 4), self._t("r_dm", 1, Hq, Wq, 1)
-        for i, scale in enumerate((8, 4, 2, 1)):
-            B = self.rife[i]
-            c = B["c"]
-            hs, ws = Hq // scale, Wq // scale
-            xs = self._t(f"r_xs{i}", 1, hs, ws, 8 if i == 0 else 16)
-            self._resize(x7 if i == 0 else xin, 0, xs, 0, 7 if i == 0 else 8)
-            if i > 0:
-                self._resize(flow, 0, xs, 8, 4, 1.0 / scale)
-            a = self._t(f"r_a{i}", 1, hs // 2, ws // 2, c // 2)
-            p, q = self._t(f"r_p{i}", 1, hs // 4, ws // 4, c), self._t(f"r_q{i}", 1, hs // 4, ws // 4, c)
-            self._conv(B["c00"], xs, 0, a, 0, act=1, slope=0.2)
-            self._conv(B["c01"], a, 0, p, 0, act=1, slope=0.2)
-            cur, nxt = p, q
-            for L in B["res"]:                      # lrelu(conv(x) * beta + x)
-                self._conv(L, cur, 0, nxt, 0, act=1, slope=0.2, res=cur)
-                cur, nxt = nxt, cur
-            t24 = self._t(f"r_t24{i}", 1, hs // 2, ws // 2, 24)
-            self._conv(B["last"], cur, 0, t24, 0)
-            t6 = self._t(f"r_t6{i}", 1, hs, ws, 8)
-            self._c("vfi_pixel_shuffle2", _p(t24), 24, _p(t6), 8, 1, hs // 2, ws // 2, 6)
-            self._resize(t6, 0, df, 0, 4, float(scale))
-            self._resize(t6, 4, dm, 0, 1)
-            if i == 0:
-                self._ax(df, 0, None, 0, flow, 0, 4)
-                self._ax(dm, 0, None, 0, xin, 7, 1)
-            else:
-                self._ax(flow, 0, df, 0, flow, 0, 4)
-                self._ax(xin, 7, dm, 0, xin, 7, 1)
-            for k in (0, 1):                        # warped_img0 = warp(img0, flow[:, :2]), warped_img1 = warp(img1, flow[:, 2:4])
-                self._c("vfi_warp_rife", _p(x7, 3 * k), 8, _p(flow, 2 * k), 4, _p(xin, 3 * k), 8, 1, Hq, Wq, 3)
-        rife = self._t("r_out", 1, Hh, Wh, 3)
-        self._c("vfi_rife40_output", _p(xin), 8, _p(xin, 7), 8, None, 0, _p(rife), 1, Hq, Wq, Hh, Wh)
-        self._ax(rife, 0, None, 0, dst, doff, 3)
+        with self._scope():
+            x7 = self._t("r_x7", 1, Hq, Wq, 8)          # clamp(img0), clamp(img1), t, 0
+            self._c("vfi_rife40_prep", _p(himg[0]), _p(himg[1]), 8, Hh, Wh, t, _p(x7), Hq, Wq)
+            xin = self._t("r_xin", 1, Hq, Wq, 8)        # warped img0, warped img1, t, mask
+            self._ax(x7, 6, None, 0, xin, 6, 1)
+            flow, df, dm = self._t("r_flow", 1, Hq, Wq, 4), self._t("r_df", 1, Hq, Wq, 4), self._t("r_dm", 1, Hq, Wq, 1)
+            for i, scale in enumerate((8, 4, 2, 1)):
+                B = self.rife[i]
+                c = B["c"]
+                hs, ws = Hq // scale, Wq // scale
+                xs = self._t(f"r_xs{i}", 1, hs, ws, 8 if i == 0 else 16)
+                self._resize(x7 if i == 0 else xin, 0, xs, 0, 7 if i == 0 else 8)
+                if i > 0:
+                    self._resize(flow, 0, xs, 8, 4, 1.0 / scale)
+                a = self._t(f"r_a{i}", 1, hs // 2, ws // 2, c // 2)
+                p, q = self._t(f"r_p{i}", 1, hs // 4, ws // 4, c), self._t(f"r_q{i}", 1, hs // 4, ws // 4, c)
+                self._conv(B["c00"], xs, 0, a, 0, act=1, slope=0.2)
+                self._conv(B["c01"], a, 0, p, 0, act=1, slope=0.2)
+                cur, nxt = p, q
+                for L in B["res"]:                      # lrelu(conv(x) * beta + x)
+                    self._conv(L, cur, 0, nxt, 0, act=1, slope=0.2, res=cur)
+                    cur, nxt = nxt, cur
+                t24 = self._t(f"r_t24{i}", 1, hs // 2, ws // 2, 24)
+                self._conv(B["last"], cur, 0, t24, 0)
+                t6 = self._t(f"r_t6{i}", 1, hs, ws, 8)
+                self._c("vfi_pixel_shuffle2", _p(t24), 24, _p(t6), 8, 1, hs // 2, ws // 2, 6)
+                self._resize(t6, 0, df, 0, 4, float(scale))
+                self._resize(t6, 4, dm, 0, 1)
+                if i == 0:
+                    self._ax(df, 0, None, 0, flow, 0, 4)
+                    self._ax(dm, 0, None, 0, xin, 7, 1)
+                else:
+                    self._ax(flow, 0, df, 0, flow, 0, 4)
+                    self._ax(xin, 7, dm, 0, xin, 7, 1)
+                for k in (0, 1):                        # warped_img0 = warp(img0, flow[:, :2]), warped_img1 = warp(img1, flow[:, 2:4])
+                    self._c("vfi_warp_rife", _p(x7, 3 * k), 8, _p(flow, 2 * k), 4, _p(xin, 3 * k), 8, 1, Hq, Wq, 3)
+            rife = self._t("r_out", 1, Hh, Wh, 3)
+            self._c("vfi_rife40_output", _p(xin), 8, _p(xin, 7), 8, None, 0, _p(rife), 1, Hq, Wq, Hh, Wh)
+            self._ax(rife, 0, None, 0, dst, doff, 3)
 
     def _gridnet(self, g_in):
-        """GridNet.forward (:1639-1688) -> [1, Hp, Wp, 8] (3 channels used)"""
+        """GridNet.forward (:1639-1688) -> [1, Hp, Wp, 8] (3 channels used).  Every state is dropped after its last reader: of the
+        24 states (2.8 GiB at 1080p) at most a handful are alive at once."""
         x, x1, x2, x3 = g_in
         _, h, w, _ = x.shape
         T = lambda name, s, c: self._t("gn_" + name, 1, h // s, w // s, c)   # noqa: E731
-        P = self._pair
+        P, D = self._pair, self._drop
         a = T("h0", 1, 64)
         P(self.gn["reshead0"], x, 0, 9 if self.union else 12, a, 0, "h0")
         x00 = T("x00", 1, 64)
         P(self.gn["reshead1"], x1, 0, 128, x00, 0, "h1", res=a)
+        D(a)
         x01 = T("x01", 1, 64)
         P(self.gn["res01"], x00, 0, 64, x01, 0, "r0", res=x00)
         b = T("h2", 2, 128)
         P(self.gn["reshead2"], x2, 0, 256, b, 0, "h2")
         x10 = T("x10", 2, 128)
         P(self.gn["down10"], x00, 0, 64, x10, 0, "d1", res=b)
+        D(b, x00)
         c = T("h3", 4, 192)
         P(self.gn["reshead3"], x3, 0, 384, c, 0, "h3")
         x20 = T("x20", 4, 192)
         P(self.gn["down20"], x10, 0, 128, x20, 0, "d2", res=c)
+        D(c)
         r11 = T("r11", 2, 128)
         P(self.gn["res11"], x10, 0, 128, r11, 0, "r1", res=x10)
+        D(x10)
         x11 = T("x11", 2, 128)
         P(self.gn["down11"], x01, 0, 64, x11, 0, "d1", res=r11)          # residual_11 + downsample_11 (the sum commutes)
+        D(r11)
         r21 = T("r21", 4, 192)
         P(self.gn["res21"], x20, 0, 192, r21, 0, "r2", res=x20)
+        D(x20)
         x21 = T("x21", 4, 192)
         P(self.gn["down21"], x11, 0, 128, x21, 0, "d2", res=r21)
+        D(r21)
         x24 = T("x24", 4, 192)
         P(self.gn["res24"], x21, 0, 192, x24, 0, "r2", res=x21)
+        D(x21)
         x25 = T("x25", 4, 192)
         P(self.gn["res25"], x24, 0, 192, x25, 0, "r2", res=x24)
         r14 = T("r14", 2, 128)
         P(self.gn["res14"], x11, 0, 128, r14, 0, "r1", res=x11)
+        D(x11)
         x14 = T("x14", 2, 128)
         P(self.gn["up14"], x24, 0, 192, x14, 0, "u1", res=r14)
+        D(r14, x24)
         r04 = T("r04", 1, 64)
         P(self.gn["res04"], x01, 0, 64, r04, 0, "r0", res=x01)
+        D(x01)
         x04 = T("x04", 1, 64)
         P(self.gn["up04"], x14, 0, 128, x04, 0, "u0", res=r04)
+        D(r04)
         r15 = T("r15", 2, 128)
         P(self.gn["res15"], x14, 0, 128, r15, 0, "r1", res=x14)
+        D(x14)
         x15 = T("x15", 2, 128)
         P(self.gn["up15"], x25, 0, 192, x15, 0, "u1", res=r15)
+        D(r15, x25)
         r05 = T("r05", 1, 64)
         P(self.gn["res05"], x04, 0, 64, r05, 0, "r0", res=x04)
+        D(x04)
         x05 = T("x05", 1, 64)
         P(self.gn["up05"], x15, 0, 128, x05, 0, "u0", res=r05)
+        D(r05, x15)
         t0, t1 = T("t0", 1, 64), T("t1", 1, 256)
         self._conv(self.tail[0], x05, 0, t0, 0)
+        D(x05)
         self._conv(self.tail[1], t0, 0, t1, 0)
+        D(t0)
         ps = self._t("gn_ps", 1, 2 * h, 2 * w, 64)
         self._c("vfi_pixel_shuffle2", _p(t1), 256, _p(ps), 64, 1, h, w, 64)
+        D(t1)
         y = self._t("gn_y", 1, 2 * h, 2 * w, 8)
         self._conv(self.tail[2], ps, 0, y, 0)
+        D(ps)
         return y
 
     def forward(self, frame0, frame1, t, out):

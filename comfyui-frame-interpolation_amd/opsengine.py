@@ -2,6 +2,7 @@
 orchestration tests only, the test double handed in through ``_test_backend``), scratch tensors, vfi_conv layer objects built
 from checkpoint tensors, and thin wrappers around the generic C-ABI calls.  Every ``torch.cat`` of the reference becomes a
 channel window of a pre-allocated NHWC tensor: wrappers take (tensor, channel offset) pairs."""
+import contextlib
 import ctypes as C
 
 import torch
@@ -36,11 +37,65 @@ class _Device:
         return _lib.last_error()
 
 
+class _Pool:
+    """Workspace memory of a pooled engine: a few large, zero-initialised device buffers with a first-fit free list each (blocks
+    split on allocation, merged with their neighbours on release).  The sequence of requests of an engine is the same on every
+    call, hence so are the addresses; a recycled block holds the finite activations of its previous user (channel padding that
+    a convolution reads against zero weights stays harmless)."""
+    CHUNK = 512 << 20
+
+    def __init__(self, device):
+        self.device, self.chunks, self.free = device, [], []      # free[i]: sorted [offset, size] holes of chunk i
+
+    def _new_chunk(self, nbytes):
+        return torch.zeros(nbytes // 4, dtype=torch.float32, device=self.device)
+
+    def take(self, nbytes):
+        n = max(256, (int(nbytes) + 255) // 256 * 256)
+        for i, holes in enumerate(self.free):
+            for k, (off, size) in enumerate(holes):
+                if size >= n:
+                    if size == n:
+                        holes.pop(k)
+                    else:
+                        holes[k] = [off + n, size - n]
+                    return (i, off, n)
+        size = max(self.CHUNK, n)
+        self.chunks.append(self._new_chunk(size))
+        self.free.append([[n, size - n]] if size > n else [])
+        return (len(self.chunks) - 1, 0, n)
+
+    def give(self, blk):
+        i, off, n = blk
+        holes = self.free[i]
+        k = 0
+        while k < len(holes) and holes[k][0] < off:
+            k += 1
+        holes.insert(k, [off, n])
+        if k + 1 < len(holes) and holes[k][0] + holes[k][1] == holes[k + 1][0]:      # merge with the hole after
+            holes[k][1] += holes.pop(k + 1)[1]
+        if k > 0 and holes[k - 1][0] + holes[k - 1][1] == holes[k][0]:               # ... and the one before
+            holes[k - 1][1] += holes.pop(k)[1]
+
+    def view(self, blk, shape):
+        numel = 1
+        for d in shape:
+            numel *= d
+        return self.chunks[blk[0]][blk[1] // 4:blk[1] // 4 + numel].view(shape)
+
+    def nbytes(self):
+        return sum(b.numel() * 4 for b in self.chunks)
+
+
 class OpsEngine:
-    def __init__(self, device=None, _test_backend=None):
+    def __init__(self, device=None, _test_backend=None, pooled=False):
         self.be = _test_backend if _test_backend is not None else _Device(device)
         self.lib, self.device = self.be.lib, self.be.device
         self.handles, self.scratch, self.consts = [], {}, {}
+        # pooled engines: scratch tensors come from a _Pool and die with the scope (``with self._scope():``) they were first asked
+        # for in, or when dropped explicitly; un-pooled engines keep every named tensor for the life of the workspace
+        self._pool = _Pool(self.device) if pooled else None
+        self._live = [{}]
 
     # ---- plumbing ---------------------------------------------------------------------------------------------------
     def _c(self, name, *args):
@@ -50,9 +105,43 @@ class OpsEngine:
 
     def _t(self, name, *shape):
         key = (name,) + tuple(shape)
-        if key not in self.scratch:
-            self.scratch[key] = torch.zeros(shape, dtype=torch.float32, device=self.device)
-        return self.scratch[key]
+        if self._pool is None:
+            if key not in self.scratch:
+                self.scratch[key] = torch.zeros(shape, dtype=torch.float32, device=self.device)
+            return self.scratch[key]
+        for d in reversed(self._live):
+            if key in d:
+                return d[key][0]
+        numel = 1
+        for n in shape:
+            numel *= n
+        blk = self._pool.take(numel * 4)
+        t = self._pool.view(blk, shape)
+        self._live[-1][key] = (t, blk)
+        return t
+
+    @contextlib.contextmanager
+    def _scope(self):
+        """scratch tensors first requested inside the block go back to the pool when it ends (no-op for un-pooled engines)"""
+        self._live.append({})
+        try:
+            yield
+        finally:
+            for _, blk in self._live.pop().values():
+                self._pool.give(blk) if self._pool is not None else None
+
+    def _drop(self, *tensors):
+        """give scratch tensors back before their scope ends (GridNet's states, dead long before the network is done)"""
+        if self._pool is None:
+            return
+        ids = {id(t) for t in tensors}            # the very objects _t returned (not views of them)
+        for d in self._live:
+            for key in [k for k, (t, _) in d.items() if id(t) in ids]:
+                self._pool.give(d.pop(key)[1])
+
+    def workspace_bytes(self):
+        legacy = sum(t.numel() * t.element_size() for t in self.scratch.values() if torch.is_tensor(t))
+        return legacy + (self._pool.nbytes() if self._pool is not None else 0)
 
     def _const(self, key, make):
         if key not in self.consts:
@@ -115,6 +204,8 @@ class OpsEngine:
 
     def release_workspace(self):
         self.scratch = {}
+        if self._pool is not None:
+            self._pool, self._live = _Pool(self.device), [{}]
 
     def __del__(self):
         try:

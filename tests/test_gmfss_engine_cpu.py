@@ -157,3 +157,65 @@ def test_conv_contract_mirror_catches_the_ifrnet_failure():
     from emu_backend import _V1
 
     assert 72 % _V1[4][0] != 0
+
+
+def test_scratch_pool_first_fit_and_scopes():
+    """opsengine._Pool / OpsEngine._scope / _drop: blocks split and merge, scoped tensors are recycled, addresses repeat"""
+    from cfi_amd.gmfss import GMFSSEngine
+    from cfi_amd.opsengine import _Pool
+
+    p = _Pool(torch.device("cpu"))
+    p.CHUNK = 1 << 20
+    a, b, c = p.take(1000), p.take(300_000), p.take(200_000)
+    assert a == (0, 0, 1024) and b[1] == 1024 and c[1] == 1024 + b[2] and len(p.chunks) == 1
+    p.give(b)
+    d = p.take(100_000)                       # first fit: the hole b left, split
+    assert d[1] == b[1] and p.free[0][0] == [b[1] + d[2], b[2] - d[2]]
+    p.give(d), p.give(a), p.give(c)           # everything merges back into one hole
+    assert p.free[0] == [[0, 1 << 20]]
+    big = p.take(3 << 20)                     # larger than a chunk: its own chunk
+    assert big == (1, 0, 3 << 20) and p.nbytes() == (1 << 20) + (3 << 20)
+    v = p.view(p.take(4 * 6), (2, 3))
+    assert v.shape == (2, 3) and float(v.abs().sum()) == 0.0
+
+    eng = GMFSSEngine(synth.gmfss_synth_state_dicts(7, "base"), _test_backend=EmuBackend())
+    try:
+        keep = eng._t("keep", 4, 4)
+        with eng._scope():
+            x = eng._t("x", 8, 8)
+            assert eng._t("x", 8, 8) is x and eng._t("keep", 4, 4) is keep
+            px = x.data_ptr()
+            y = eng._t("y", 8, 8)
+            eng._drop(y)
+            assert eng._t("y2", 8, 8).data_ptr() == y.data_ptr()      # a dropped tensor's block is the next one handed out
+        z = eng._t("z", 8, 8)
+        assert z.data_ptr() == px and eng._t("keep", 4, 4) is keep    # the scope's memory came back; the root tensor stayed
+    finally:
+        eng.close()
+
+
+def test_repeated_calls_are_bit_identical_with_recycled_scratch():
+    """second and third prepare / render cycles run on recycled (stale, non-zero) scratch blocks: same output bit for bit"""
+    from cfi_amd.gmfss import GMFSSEngine
+
+    sds = synth.gmfss_synth_state_dicts(99, "union")
+    eng = GMFSSEngine(sds, _test_backend=EmuBackend())
+    try:
+        fr = synth.smooth_frames(3, 64, 96, seed=3, shift=2.0)
+        outs = []
+        for rep in range(3):
+            pair = (fr[0], fr[1]) if rep != 1 else (fr[1], fr[2])          # another pair in between dirties every block
+            eng.prepare(pair[0].contiguous(), pair[1].contiguous())
+            o = torch.zeros(64, 96, 3)
+            eng.render(0.5, o)
+            o2 = torch.zeros(64, 96, 3)
+            eng.render(0.25, o2)
+            outs.append((o, o2))
+        assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
+        assert not torch.equal(outs[0][0], outs[1][0])
+        used = eng.workspace_bytes()
+        eng.prepare(fr[0].contiguous(), fr[1].contiguous())
+        eng.render(0.5, torch.zeros(64, 96, 3))
+        assert eng.workspace_bytes() == used, "the pool keeps growing"
+    finally:
+        eng.close()

@@ -42,10 +42,7 @@ if __name__ == "__main__":
     if fl is not None:
         a = fl.abs().flatten()
         print(f"   flow |f|: mean {a.mean().item():.2f}, p99 {a.kthvalue(int(0.99 * a.numel())).values.item():.2f}, max {a.max().item():.2f} px", flush=True)
-    if "--mem" in sys.argv:
-        sizes = sorted(((t.numel() * t.element_size(), k) for k, t in eng.scratch.items() if torch.is_tensor(t)), reverse=True)
-        print(f"   scratch: {sum(s for s, _ in sizes) / 2**30:.2f} GiB in {len(sizes)} buffers; largest: "
-              + ", ".join(f"{k[0]}{list(k[1:])} {s / 2**20:.0f} MiB" for s, k in sizes[:24]), flush=True)
+    print(f"   workspace: {eng.workspace_bytes() / 2**30:.2f} GiB (pooled scratch: {len(eng._pool.chunks)} chunks)", flush=True)
     for phase in ("prepare", "render"):        # per-kernel split of each phase
         lib.vfi_trace_reset(); lib.vfi_trace_enable(1)
         if phase == "prepare":
