@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttArgs a) {
     // V tile 32 keys x DV (DV = 128: 4 float4 per thread, transposed on the way into LDS).
     f32x4 kreg[4], vreg[4];
     int lreg = 0;
-    auto fetch = [&](int kblk) {
+    auto fetch_k = [&](int kblk) {
         const int key0 = kblk * ATT_KB;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -113,6 +113,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttArgs a) {
             kreg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (key0 + key < a.Lk) kreg[i] = *(const f32x4*)(a.k + att_row(a, b, key0 + key, a.Lk, wy0, wx0, img0) * a.k_cs + 4 * d4);
         }
+    };
+    auto fetch_v = [&](int kblk) {
+        const int key0 = kblk * ATT_KB;
         if (DVT == 4) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -131,16 +134,18 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttArgs a) {
         }
         if (tid < ATT_KB) lreg = (lab && key0 + tid < a.Lk) ? lab[key0 + tid] : 0;
     };
-    auto commit = [&](int buf) {
+    auto commit_k = [&](int buf) {
         float* kt = smem + buf * BUF;
-        float* vt = kt + KT;
-        int* lt = (int*)(vt + VT);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = tid + 256 * i;
             const int key = idx >> 5, d4 = idx & 31;
             *(f32x4*)(kt + key * ATT_KS + 4 * d4) = kreg[i];
         }
+    };
+    auto commit_v = [&](int buf) {
+        float* vt = smem + buf * BUF + KT;
+        int* lt = (int*)(vt + VT);
         if (DVT == 4) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -159,36 +164,38 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttArgs a) {
         if (tid < ATT_KB) lt[tid] = lreg;
     };
 
-    fetch(0);
-    commit(0);
-    __syncthreads();
-    for (int kblk = 0; kblk < nblk; ++kblk) {
-        const int buf = kblk & 1;
-        if (kblk + 1 < nblk) fetch(kblk + 1);
-        const float* kt = smem + buf * BUF;
-        const float* vt = kt + KT;
-        const int* lt = (const int*)(vt + VT);
-
-        // ---- S^T = K Q^T : rows = keys, this lane's column = its query
-        f32x16 s;
+    // S^T = K Q^T : rows = keys, this lane's column = its query.  Two accumulator chains (even / odd channel groups), summed at the
+    // end: 64 matrix instructions into ONE accumulator are 64 dependent issues, each waiting for the previous result to clear
+    // the pipe (the convolution kernels rotate their accumulators for the same reason, conv_mfma2.hip)
+    auto qk = [&](const float* kt) {
+        f32x16 s0, s1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        for (int r = 0; r < 16; ++r) s0[r] = 0.f, s1[r] = 0.f;
         const float* krow = kt + l31 * ATT_KS + 4 * half;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            const f32x4 kf = *(const f32x4*)(krow + 8 * g);
+        for (int g = 0; g < 16; g += 2) {
+            const f32x4 ka = *(const f32x4*)(krow + 8 * g), kb = *(const f32x4*)(krow + 8 * g + 8);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qreg[4 * g + j], s, 0, 0, 0);
+            for (int j = 0; j < 4; ++j) {
+                s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[j], qreg[4 * g + j], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kb[j], qreg[4 * g + 4 + j], s1, 0, 0, 0);
+            }
         }
-        // ---- scale, mask, online softmax (per-lane: every register of `s` belongs to this lane's query)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s0[r] += s1[r];
+        return s0;
+    };
+    // scale, mask, online softmax of block kblk (per-lane: every register of `s` belongs to this lane's query), then
+    // O^T += V^T P^T : A = V^T[channel l31 of tile t][4 keys of this half], B = the S^T registers as they are
+    auto softmax_pv = [&](f32x16 s, int kblk, const float* vt, const int* lt) {
         const int key0 = kblk * ATT_KB;
         float mloc = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int kk = 8 * (r >> 2) + 4 * half + (r & 3);
             float x = s[r] * a.alpha;
-            if (lab && lt[kk] != qlab) x += -100.0f;
-            if (key0 + kk >= a.Lk) x = -INFINITY;
+            x += lt[kk] != qlab ? -100.0f : 0.0f;        // branch-free: without labels the tile and qlab are all 0
+            x = key0 + kk >= a.Lk ? -INFINITY : x;
             s[r] = x;
             mloc = fmaxf(mloc, x);
         }
@@ -209,19 +216,31 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttArgs a) {
         for (int t = 0; t < DVT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[t][r] *= corr;
-        // ---- O^T += V^T P^T : A = V^T[channel l31 of tile t][4 keys of this half], B = the S^T registers as they are
 #pragma unroll
-        for (int t = 0; t < DVT; ++t) {
-            const float* vrow = vt + (32 * t + l31) * ATT_VS + 4 * half;
+        for (int j = 0; j < 4; ++j) {              // consecutive matrix instructions rotate through the DVT output tiles
+            f32x4 vf[DVT];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4 vf = *(const f32x4*)(vrow + 8 * j);
+            for (int t = 0; t < DVT; ++t) vf[t] = *(const f32x4*)(vt + (32 * t + l31) * ATT_VS + 4 * half + 8 * j);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[i], s[4 * j + i], o[t], 0, 0, 0);
-            }
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < DVT; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[t][i], s[4 * j + i], o[t], 0, 0, 0);
         }
-        if (kblk + 1 < nblk) commit(buf ^ 1);     // that buffer was released by the barrier that ended block kblk-1
-        __syncthreads();                          // block consumed; the next one has been written
+    };
+
+    fetch_k(0);
+    fetch_v(0);
+    commit_k(0);
+    commit_v(0);
+    __syncthreads();
+    for (int kblk = 0; kblk < nblk; ++kblk) {
+        const int buf = kblk & 1;
+        if (kblk + 1 < nblk) fetch_k(kblk + 1), fetch_v(kblk + 1);
+        const float* kt = smem + buf * BUF;
+        const float* vt = kt + KT;
+        softmax_pv(qk(kt), kblk, vt, (const int*)(vt + VT));
+        if (kblk + 1 < nblk) commit_k(buf ^ 1), commit_v(buf ^ 1);     // that buffer was released by the barrier that ended block kblk-1
+        __syncthreads();                                               // block consumed; the next one has been written
     }
     // ---- normalise and store: register r of tile t = channel 32t + 8(r/4) + 4 half + r%4 of this lane's query
     if (qok) {
