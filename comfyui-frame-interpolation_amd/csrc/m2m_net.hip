@@ -187,6 +187,28 @@ __global__ __launch_bounds__(256) void pool_global_kernel(const float* __restric
                                               ((double)H * W));
 }
 
+// mode 1 / 2 with FEW channels (IFRNet's per-image RGB mean at 1080p: row means of a [2, 1088, 1920, 4] tensor, then the mean of the
+// rows; ifrnet/IFRNet_L_arch.py: mean_ = cat(img0, img1).mean): pool_mean_kernel gives every row C = 4 working threads that walk
+// 1920 pixels each (0.37 ms, 13 % of an IFRNet_S frame).  Here the 256 threads of a row's block are 256 / C pixel lanes x C channels.
+__global__ __launch_bounds__(256) void pool_mean_fewc_kernel(const float* __restrict__ in, int in_cs, float* __restrict__ out, int out_cs,
+                                                             int H, int W, int C, int mode) {
+    __shared__ double red[256];
+    const int L = mode == 1 ? H : W, M = mode == 1 ? W : H;      // L output rows, each the mean over M pixels
+    const int n = blockIdx.x / L, l = blockIdx.x - n * L, tid = threadIdx.x;
+    const int P = 256 / C, p = tid / C, c = tid - p * C;
+    const float* b = in + (size_t)n * H * W * in_cs + c;
+    const size_t first = mode == 1 ? (size_t)l * W : (size_t)l, step = mode == 1 ? 1 : (size_t)W;
+    double s = 0.0;
+    if (p < P)
+        for (int i = p; i < M; i += P) s += b[(first + i * step) * in_cs];
+    red[tid] = s;
+    __syncthreads();
+    if (tid < C) {
+        for (int k = 1; k < P; ++k) s += red[tid + k * C];
+        out[((size_t)n * L + l) * out_cs + tid] = (float)(s / M);
+    }
+}
+
 // out[n,y,x,c] = s3[n,y,x,c] * mean_k( cC[n, k*C + c] * cH[n, y, k] * cW[n, x, k] ),  k < 16   (M2M_arch.py:786-795)
 __global__ void cube_apply_kernel(const float* __restrict__ s3, int s_cs, const float* __restrict__ cC, const float* __restrict__ cH,
                                   int h_cs, const float* __restrict__ cW, int w_cs, float* __restrict__ out, int out_cs, int N,
@@ -352,7 +374,9 @@ int vfi_pool_mean(const float* in_dev, int in_cs, float* out_dev, int out_cs, in
     VFI_REQUIRE(in_dev && out_dev && N > 0 && H > 0 && W > 0 && C > 0 && mode >= 0 && mode <= 2, "vfi_pool_mean: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     TraceScope ts("pool_mean", s);
-    if (mode == 0) {
+    if (mode != 0 && C <= 32 && (mode == 1 ? W : H) >= 256) {
+        hipLaunchKernelGGL(pool_mean_fewc_kernel, dim3(N * (mode == 1 ? H : W)), dim3(256), 0, s, in_dev, in_cs, out_dev, out_cs, H, W, C, mode);
+    } else if (mode == 0) {
         hipLaunchKernelGGL(pool_global_kernel, dim3((C + 63) / 64, N), dim3(256), 0, s, in_dev, in_cs, out_dev, out_cs, H, W, C);
     } else {
         hipLaunchKernelGGL(pool_mean_kernel, dim3(N * (mode == 1 ? H : W)), dim3(C < 256 ? 64 * ((C + 63) / 64) : 256), 0, s, in_dev,
