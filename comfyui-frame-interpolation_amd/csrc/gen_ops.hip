@@ -310,7 +310,7 @@ int vfi_conv_forward_ex(const vfi_conv_t* c, const float* in_dev, int in_cs, int
     a.post_scale = post_scale;
     a.post_shift = post_shift;
     a.pad_replicate = c->pad_mode;
-    char name[48];
+    char name[80];
     if (c->kind == 1) {
         VFI_REQUIRE(!res_dev, "vfi_conv_forward_ex: residual not supported for transposed convs");
         a.Hout = Hin;  // per parity group; the kernel interleaves the 4 groups into [2*Hin, 2*Win]
@@ -323,6 +323,8 @@ int vfi_conv_forward_ex(const vfi_conv_t* c, const float* in_dev, int in_cs, int
         a.tap_y0 = a.tap_x0 = c->kh == 3 ? -1 : 0;
         snprintf(name, sizeof(name), "conv%dx%ds%d_%dto%d", c->kh, c->kw, c->stride, c->Cin_p, c->Cout);
     }
+    static const bool by_shape = getenv("VFI_TRACE_SHAPES") != nullptr;      // per-shape trace rows: append the OUTPUT size and batch
+    if (by_shape) snprintf(name + strlen(name), sizeof(name) - strlen(name), "@%dx%dx%d", N, c->kind == 1 ? 2 * Hin : a.Hout, c->kind == 1 ? 2 * Win : a.Wout);
     static std::map<std::string, const char*> names;
     auto it = names.find(name);
     if (it == names.end()) it = names.emplace(name, strdup(name)).first;

@@ -47,8 +47,14 @@ if __name__ == "__main__":
     rep = _lib.trace_report()
     tot = sum(v[1] for v in rep.values())
     print(f"traced total {tot:.2f} ms")
+    import re
     for k, v in sorted(rep.items(), key=lambda kv: -kv[1][1]):
-        print(f"   {k:28s} {v[0]:4d} calls {v[1]:9.3f} ms {100 * v[1] / tot:5.1f}%")
+        m = re.match(r"(conv|deconv)(\d)x(\d)s(\d)_(\d+)to(\d+)@(\d+)x(\d+)x(\d+)", k)      # VFI_TRACE_SHAPES=1: rate per shape
+        rate = ""
+        if m:
+            taps = int(m[2]) * int(m[3]) / (4 if m[1] == "deconv" else 1)      # a transposed 4x4 s2 conv: 4 taps per output pixel
+            rate = f"  {2 * taps * int(m[5]) * int(m[6]) * int(m[7]) * int(m[8]) * int(m[9]) * v[0] / v[1] / 1e9:6.1f} TFLOP/s"
+        print(f"   {k:40s} {v[0]:4d} calls {v[1]:9.3f} ms {100 * v[1] / tot:5.1f}%{rate}")
     if check:
         from oracle import m2m_model_oracle as mo
         t0 = time.time()
