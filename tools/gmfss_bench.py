@@ -15,6 +15,16 @@ ge.load_package()
 from cfi_amd import _lib, synth  # noqa: E402
 from cfi_amd.gmfss import GMFSSEngine  # noqa: E402
 
+def _rate(k, v):
+    """VFI_TRACE_SHAPES=1: TFLOP/s of a conv / deconv row named conv3x3s1_64to64@1x544x960"""
+    import re
+    m = re.match(r"(conv|deconv)(\d)x(\d)s(\d)_(\d+)to(\d+)@(\d+)x(\d+)x(\d+)", k)
+    if not m:
+        return ""
+    taps = int(m[2]) * int(m[3]) / (4 if m[1] == "deconv" else 1)
+    return f" [{2 * taps * int(m[5]) * int(m[6]) * int(m[7]) * int(m[8]) * int(m[9]) * v[0] / v[1] / 1e9:.0f} TF]"
+
+
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     H, W = (int(args[0]), int(args[1])) if len(args) >= 2 else (1080, 1920)
@@ -52,7 +62,7 @@ if __name__ == "__main__":
         torch.cuda.synchronize()
         lib.vfi_trace_enable(0)
         rep = _lib.trace_report()
-        print(f"   {phase}: " + ", ".join(f"{k} {v[0]}x {v[1]:.2f}" for k, v in sorted(rep.items(), key=lambda kv: -kv[1][1])[:22])
+        print(f"   {phase}: " + ", ".join(f"{k} {v[0]}x {v[1]:.2f}{_rate(k, v)}" for k, v in sorted(rep.items(), key=lambda kv: -kv[1][1])[:22])
               + f"  (sum {sum(v[1] for v in rep.values()):.1f} ms)", flush=True)
     lib.vfi_trace_reset(); lib.vfi_trace_enable(1)
     eng.prepare(x0, x1)
