@@ -14,6 +14,10 @@
 // rescaling of the output accumulator is a per-lane multiply, and the probabilities never leave registers — the S^T
 // accumulator layout (register r of half h = key 8(r/4) + 4h + r%4) is exactly the B-operand order of the second product when
 // V^T is read from LDS four keys at a time.
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "vfi_common.h"
 
 #include "../../include/vfi_hip.h"
@@ -41,6 +45,11 @@ struct AttArgs {
     // window of the map rolled by (-sh, -sw): token l of the window = pixel ((wy wh + l / ww + sh) % h, (wx ww + l % ww + sw) % w)
     // — torch.roll + split_feature + merge_splits + roll back (:367-436, :1059-1120) folded into the addressing.
     int win_K, win_h, win_w, win_sh, win_sw, win_wh, win_ww;   // wh x ww = the window
+    // key split (set by the launcher, see attention_launch_t): blockIdx.z owns a range of key blocks and leaves its un-normalised
+    // output rows and softmax statistics (running maximum, sum) in a workspace; attention_merge_kernel combines the splits
+    int ksplit;
+    float* part_o;    // [ksplit][nb][Lq][DV]
+    float* part_ml;   // [ksplit][nb][Lq][2]
     float win_inv_ww;
 };
 
@@ -228,22 +237,41 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttArgs a) {
         }
     };
 
-    fetch_k(0);
-    fetch_v(0);
+    int kb0 = 0, kb1 = nblk;
+    if (a.ksplit > 1) {
+        const int per = (nblk + a.ksplit - 1) / a.ksplit;
+        kb0 = blockIdx.z * per;
+        kb1 = kb0 + per < nblk ? kb0 + per : nblk;      // (the launcher leaves no split empty)
+    }
+    fetch_k(kb0);
+    fetch_v(kb0);
     commit_k(0);
     commit_v(0);
     __syncthreads();
-    for (int kblk = 0; kblk < nblk; ++kblk) {
-        const int buf = kblk & 1;
-        if (kblk + 1 < nblk) fetch_k(kblk + 1), fetch_v(kblk + 1);
+    for (int kblk = kb0; kblk < kb1; ++kblk) {
+        const int buf = (kblk - kb0) & 1;
+        if (kblk + 1 < kb1) fetch_k(kblk + 1), fetch_v(kblk + 1);
         const float* kt = smem + buf * BUF;
         const float* vt = kt + KT;
         softmax_pv(qk(kt), kblk, vt, (const int*)(vt + VT));
-        if (kblk + 1 < nblk) commit_k(buf ^ 1), commit_v(buf ^ 1);     // that buffer was released by the barrier that ended block kblk-1
+        if (kblk + 1 < kb1) commit_k(buf ^ 1), commit_v(buf ^ 1);      // that buffer was released by the barrier that ended block kblk-1
         __syncthreads();                                               // block consumed; the next one has been written
     }
     // ---- normalise and store: register r of tile t = channel 32t + 8(r/4) + 4 half + r%4 of this lane's query
-    if (qok) {
+    if (qok && a.ksplit > 1) {      // partial result of this key range: raw accumulator + (m, l)
+        const size_t row = ((size_t)blockIdx.z * a.nb + b) * a.Lq + query;
+        float* op = a.part_o + row * a.DV;
+        if (half == 0) a.part_ml[2 * row] = m_run, a.part_ml[2 * row + 1] = l_run;
+#pragma unroll
+        for (int t = 0; t < DVT; ++t)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int ch = 32 * t + 8 * r4 + 4 * half;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (ch + i < a.DV) op[ch + i] = o[t][4 * r4 + i];
+            }
+    } else if (qok) {
         const float inv = 1.0f / l_run;
         float* op = a.out + att_row(a, b, query, a.Lq, wy0, wx0, img0) * a.out_cs;
 #pragma unroll
@@ -263,8 +291,54 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttArgs a) {
 #endif
 }
 
+// out[b][query][c] = sum_z o_z e^(m_z - M) / sum_z l_z e^(m_z - M),  M = max_z m_z: the online-softmax merge of the key splits
+__global__ __launch_bounds__(256) void attention_merge_kernel(const AttArgs a) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)a.nb * a.Lq * a.DV;
+    if (idx >= total) return;
+    const long row = idx / a.DV;
+    const int c = (int)(idx - row * a.DV);
+    const int b = (int)(row / a.Lq), query = (int)(row - (long)b * a.Lq);
+    const long rows = (long)a.nb * a.Lq;
+    float M = -INFINITY;
+    for (int z = 0; z < a.ksplit; ++z) M = fmaxf(M, a.part_ml[2 * (z * rows + row)]);
+    float num = 0.f, den = 0.f;
+    for (int z = 0; z < a.ksplit; ++z) {
+        const float w = __expf(a.part_ml[2 * (z * rows + row)] - M);
+        num += a.part_o[(z * rows + row) * a.DV + c] * w;
+        den += a.part_ml[2 * (z * rows + row) + 1] * w;
+    }
+    int wy0 = 0, wx0 = 0, img0 = 0;
+    if (a.win_K) {
+        const int K = a.win_K, wimg = b / (K * K), wy = (b / K) % K, wx = b % K;
+        wy0 = wy * a.win_wh + a.win_sh, wx0 = wx * a.win_ww + a.win_sw, img0 = wimg * a.win_h;
+    }
+    a.out[att_row(a, b, query, a.Lq, wy0, wx0, img0) * a.out_cs + c] = num / den;
+}
+
+// split workspace per (device, stream), grow-only
+static int attention_workspace(int dev, hipStream_t s, size_t floats, float** out) {
+    struct Ws {
+        float* p = nullptr;
+        size_t n = 0;
+    };
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, Ws> table;
+    std::lock_guard<std::mutex> lock(mu);
+    Ws& w = table[{dev, s}];
+    if (w.n < floats) {
+        if (w.p) VFI_CHECK_HIP(hipFree(w.p));
+        w.p = nullptr, w.n = 0;
+        VFI_CHECK_HIP(hipMalloc((void**)&w.p, floats * sizeof(float)));
+        w.n = floats;
+    }
+    *out = w.p;
+    return 0;
+}
+
 template <int DVT>
-static int attention_launch_t(const AttArgs& a, hipStream_t s) {
+static int attention_launch_t(const AttArgs& a_in, hipStream_t s) {
+    AttArgs a = a_in;
     constexpr int LDS = 2 * (ATT_KB * ATT_KS + DVT * 32 * ATT_VS + ATT_KB) * 4;
     static bool attr_set[kMaxDevices] = {};
     int dev = 0;
@@ -275,9 +349,44 @@ static int attention_launch_t(const AttArgs& a, hipStream_t s) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set[dev] = true;
     }
-    TraceScope ts(DVT == 4 ? "attention_c128" : "attention_c2", s);
-    hipLaunchKernelGGL(attention_kernel<DVT>, dim3(cdiv(a.Lq, 128), a.nb), dim3(256), LDS, s, a);
-    VFI_CHECK_HIP(hipGetLastError());
+    // Key split: GMFlow's coarse scale has 8 windows x 16 query blocks = 128 workgroups for 256 CUs (global matching: 2 x 64), each
+    // walking 64 ... 255 key blocks.  Then the keys are cut into `ks` ranges (gridDim.z) and a merge kernel combines the partial
+    // softmaxes; ks fills the CUs once (this kernel holds one workgroup per CU) and leaves >= 8 key blocks per range.
+    static int cus_of[kMaxDevices] = {};
+    if (!cus_of[dev]) {
+        hipDeviceProp_t p;
+        VFI_CHECK_HIP(hipGetDeviceProperties(&p, dev));
+        cus_of[dev] = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+    }
+    const int wgs = cdiv(a.Lq, 128) * a.nb, nblk = cdiv(a.Lk, ATT_KB);
+    int ks = 1;
+    if (wgs < cus_of[dev] && nblk >= 16) {
+        ks = (DVT == 4 ? 1 : 2) * cus_of[dev] / wgs;      // (the 2-channel form fits two workgroups per CU)
+        ks = ks > nblk / 8 ? nblk / 8 : ks;
+        ks = ks > 8 ? 8 : ks;
+        if (ks > 1) {
+            const int per = cdiv(nblk, ks);
+            ks = cdiv(nblk, per);          // no empty range
+        }
+    }
+    a.ksplit = ks > 1 ? ks : 0, a.part_o = nullptr, a.part_ml = nullptr;
+    if (ks > 1) {
+        const size_t rows = (size_t)ks * a.nb * a.Lq;
+        float* ws = nullptr;
+        if (int rc = attention_workspace(dev, s, rows * (a.DV + 2), &ws)) return rc;
+        a.part_o = ws, a.part_ml = ws + rows * a.DV;
+    }
+    {
+        TraceScope ts(DVT == 4 ? "attention_c128" : "attention_c2", s);
+        hipLaunchKernelGGL(attention_kernel<DVT>, dim3(cdiv(a.Lq, 128), a.nb, ks > 1 ? ks : 1), dim3(256), LDS, s, a);
+        VFI_CHECK_HIP(hipGetLastError());
+    }
+    if (ks > 1) {
+        TraceScope ts("attention_merge", s);
+        const long total = (long)a.nb * a.Lq * a.DV;
+        hipLaunchKernelGGL(attention_merge_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+        VFI_CHECK_HIP(hipGetLastError());
+    }
     return 0;
 }
 
