@@ -123,6 +123,8 @@ struct LayerNormArgs {
     const float* x; int cs, C; long tokens;
     const float* gamma; const float* beta;
     float* out; int out_cs; float eps;
+    const float* add; int add_cs;       // nullable: out = add + LN(x)   (source + message: TransformerLayer.forward's residual, :523)
+    float* out2; int out2_cs;           // nullable: a second copy of the result (the FFN's concat slot)
 };
 VFI_HD void layernorm_body(const LayerNormArgs& a, long idx) {
     if (idx >= a.tokens) return;
@@ -137,7 +139,12 @@ VFI_HD void layernorm_body(const LayerNormArgs& a, long idx) {
     }
     const float rstd = 1.0f / sqrtf(var / (float)a.C + a.eps);
     float* o = a.out + idx * a.out_cs;
-    for (int c = 0; c < a.C; ++c) o[c] = (b[c] - mean) * rstd * a.gamma[c] + a.beta[c];
+    for (int c = 0; c < a.C; ++c) {
+        float v = (b[c] - mean) * rstd * a.gamma[c] + a.beta[c];
+        if (a.add) v += a.add[idx * a.add_cs + c];
+        o[c] = v;
+        if (a.out2) a.out2[idx * a.out2_cs + c] = v;
+    }
 }
 
 // ---- nn.GELU() (erf form) in place over a channel window -----------------------------------------------------------------

@@ -19,4 +19,8 @@ int instnorm_final_wave_launch(const vfi_gmfss::InFinalArgs& a, void* stream);  
 bool local_match_mfma_fits(const vfi_gmfss::LocalMatchArgs& a);
 int local_match_mfma_launch(const vfi_gmfss::LocalMatchArgs& a, void* stream);
 
+// local window flow propagation with C = 128, radius 1: 16 lanes per pixel.
+bool local_prop_coop_fits(const vfi_gmfss::LocalPropArgs& a);
+int local_prop_coop_launch(const vfi_gmfss::LocalPropArgs& a, void* stream);
+
 }  // namespace vfi

@@ -70,7 +70,12 @@ __global__ __launch_bounds__(256) void layernorm_wave_kernel(const LayerNormArgs
 #pragma unroll
     for (int i = 0; i < LN_MAXC / 64; ++i) {
         const int c = lane + 64 * i;
-        if (c < a.C) o[c] = (v[i] - mean) * rstd * a.gamma[c] + a.beta[c];
+        if (c < a.C) {
+            float r = (v[i] - mean) * rstd * a.gamma[c] + a.beta[c];
+            if (a.add) r += a.add[tok * a.add_cs + c];
+            o[c] = r;
+            if (a.out2) a.out2[tok * a.out2_cs + c] = r;
+        }
     }
 }
 
@@ -272,6 +277,76 @@ __global__ __launch_bounds__(64) void local_match_mfma_kernel(const LocalMatchAr
 }
 
 }  // namespace
+
+// ---------------------------------------------------------------------------------------------------- local propagation
+// FeatureFlowAttention.forward_local_window_attn (:745-803), C = 128, radius 1: softmax over the 3 x 3 window of q . k / sqrt(C)
+// (padded taps score 0 and carry a zero flow, as unfold's zero padding), weighted sum of the window's flows.  The body walks
+// 9 x 128 strided floats per THREAD; here 16 lanes share a pixel (8 channels each, two float4 loads per tap) and the nine dot
+// products are reduced across them with xor-shuffles.
+namespace {
+
+__global__ __launch_bounds__(256) void local_prop_coop_kernel(const vfi_gmfss::LocalPropArgs a) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long idx = gid >> 4;                 // pixel
+    const int sub = (int)(gid & 15);           // channels [8 sub, 8 sub + 8)
+    const bool ok = idx < (long)a.N * a.H * a.W;
+    const long pid = ok ? idx : 0;
+    const int X = (int)(pid % a.W), Y = (int)((pid / a.W) % a.H);
+    const int n = (int)(pid / ((long)a.W * a.H));
+    const float* q = a.q + (size_t)pid * a.q_cs + 8 * sub;
+    const f32x4 q0 = *(const f32x4*)q, q1 = *(const f32x4*)(q + 4);
+    const float scale = sqrtf((float)a.C);
+    float sc[9], fx[9], fy[9];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const int x = X + j % 3 - 1, y = Y + j / 3 - 1;
+        const bool in = x >= 0 && x < a.W && y >= 0 && y < a.H;
+        const size_t p = ((size_t)n * a.H + (in ? y : Y)) * a.W + (in ? x : X);
+        const float* kk = a.k + p * a.k_cs + 8 * sub;
+        const f32x4 k0 = *(const f32x4*)kk, k1 = *(const f32x4*)(kk + 4);
+        float s = q0[0] * k0[0] + q0[1] * k0[1] + q0[2] * k0[2] + q0[3] * k0[3] + q1[0] * k1[0] + q1[1] * k1[1] + q1[2] * k1[2] + q1[3] * k1[3];
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+        s = in ? s / scale : 0.f;          // padded taps: key = 0 -> score 0, value 0; they DO take part in the softmax
+        fx[j] = in ? a.flow[p * a.flow_cs] : 0.f;
+        fy[j] = in ? a.flow[p * a.flow_cs + 1] : 0.f;
+        sc[j] = s;
+        mx = s > mx ? s : mx;
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        sc[j] = expf(sc[j] - mx);
+        sum += sc[j];
+    }
+    float ox = 0.f, oy = 0.f;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const float p = sc[j] / sum;
+        ox += p * fx[j];
+        oy += p * fy[j];
+    }
+    if (ok && sub == 0) {
+        a.out[idx * a.out_cs] = ox;
+        a.out[idx * a.out_cs + 1] = oy;
+    }
+}
+
+}  // namespace
+
+bool local_prop_coop_fits(const vfi_gmfss::LocalPropArgs& a) {
+    return a.C == 128 && a.R == 1 && a.q_cs % 4 == 0 && a.k_cs % 4 == 0 && (((uintptr_t)a.q | (uintptr_t)a.k) & 15) == 0;
+}
+
+int local_prop_coop_launch(const vfi_gmfss::LocalPropArgs& a, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    TraceScope ts("local_propagate", s);
+    const long threads = (long)a.N * a.H * a.W * 16;
+    hipLaunchKernelGGL(local_prop_coop_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a);
+    VFI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
 
 bool local_match_mfma_fits(const LocalMatchArgs& a) {
     return a.C == LM_C && a.R == LM_R && a.f0_cs % 4 == 0 && a.f1_cs % 4 == 0 && (((uintptr_t)a.f0 | (uintptr_t)a.f1) & 15) == 0;

@@ -81,6 +81,19 @@ int vfi_layernorm(const float* x_dev, int cs, int C, int64_t tokens, const float
     return run<LayerNormArgs, layernorm_body>(a, (long)tokens, stream, "layernorm");
 }
 
+int vfi_layernorm_add(const float* x_dev, int cs, int C, int64_t tokens, const float* gamma_dev, const float* beta_dev, const float* add_dev,
+                      int add_cs, float* out_dev, int out_cs, float* out2_dev, int out2_cs, void* stream) {
+    VFI_REQUIRE(x_dev && gamma_dev && beta_dev && add_dev && out_dev && C > 0 && cs >= C && add_cs >= C && out_cs >= C && tokens > 0 &&
+                    (!out2_dev || out2_cs >= C),
+                "vfi_layernorm_add: bad arguments");
+    VFI_REQUIRE(out_dev != x_dev && out2_dev != x_dev && (!out2_dev || out2_dev != add_dev), "vfi_layernorm_add: the output aliases x (or out2 aliases add)");
+    LayerNormArgs a{x_dev, cs, C, (long)tokens, gamma_dev, beta_dev, out_dev, out_cs, 1e-5f, add_dev, add_cs, out2_dev, out2_cs};
+#ifndef VFI_HOSTCHECK
+    if (layernorm_wave_fits(a)) return layernorm_wave_launch(a, stream);
+#endif
+    return run<LayerNormArgs, layernorm_body>(a, (long)tokens, stream, "layernorm");
+}
+
 int vfi_gelu(float* x_dev, int cs, int C, int64_t pixels, void* stream) {
     VFI_REQUIRE(x_dev && C > 0 && cs >= C && pixels > 0, "vfi_gelu: bad arguments");
     GeluArgs a{x_dev, cs, C, (long)pixels};
@@ -151,6 +164,9 @@ int vfi_local_propagate(const float* q_dev, int q_cs, const float* k_dev, int k_
                     out_cs >= 2 && radius >= 1 && radius <= 3 && flow_dev != out_dev,
                 "vfi_local_propagate: bad arguments");
     LocalPropArgs a{q_dev, q_cs, k_dev, k_cs, flow_dev, flow_cs, out_dev, out_cs, N, H, W, C, radius};
+#ifndef VFI_HOSTCHECK
+    if (local_prop_coop_fits(a)) return local_prop_coop_launch(a, stream);     // GMFlow's shape: 16 lanes per pixel (gmfss_fast.hip)
+#endif
     return run<LocalPropArgs, local_prop_body>(a, (long)N * H * W, stream, "local_propagate");
 }
 

@@ -274,14 +274,14 @@ class GMFSSEngine(OpsEngine):
                         self._conv(L["v_proj"], a, 0, v, 0)
                     self._attention(q, k, v, m, h, w, splits, shifted)
                     self._conv(L["merge"], m, 0, q, 0)
-                    dst, doff = (cat, c) if ffn else (m, 0)
-                    self._c("vfi_layernorm", _p(q), c, c, B * h * w, _p(L["norm1"][0]), _p(L["norm1"][1]), _p(dst, doff), dst.shape[-1])
-                    if ffn:
-                        self._ax(a, 0, None, 0, cat, 0, c)
+                    n1 = L["norm1"]
+                    if not ffn:      # a = a + norm1(merge(msg)), and the same value into the FFN's concat slot [a | .] of the cross part
+                        self._c("vfi_layernorm_add", _p(q), c, c, B * h * w, _p(n1[0]), _p(n1[1]), _p(a), c, _p(a), c, _p(cat), 2 * c)
+                    else:            # a = a + norm2(mlp(cat(a, norm1(merge(msg)))))
+                        self._c("vfi_layernorm", _p(q), c, c, B * h * w, _p(n1[0]), _p(n1[1]), _p(cat, c), 2 * c)
                         self._conv(L["mlp0"], cat, 0, hid, 0, act=5)         # Linear + nn.GELU() in the conv's epilogue
                         self._conv(L["mlp2"], hid, 0, q, 0)
-                        self._c("vfi_layernorm", _p(q), c, c, B * h * w, _p(L["norm2"][0]), _p(L["norm2"][1]), _p(m), c)
-                    self._ax(a, 0, m, 0, a, 0, c)
+                        self._c("vfi_layernorm_add", _p(q), c, c, B * h * w, _p(L["norm2"][0]), _p(L["norm2"][1]), _p(a), c, _p(a), c, None, 0)
 
     def _add_position(self, t, splits):
         B, h, w, c = t.shape

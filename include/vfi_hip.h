@@ -261,6 +261,10 @@ int vfi_instnorm_apply(const float* x_dev, int cs, const float* stats_dev, int C
 /* nn.LayerNorm(C) over the channel axis (eps 1e-5), TransformerLayer.norm1 / norm2 (:479-523) */
 int vfi_layernorm(const float* x_dev, int cs, int C, int64_t tokens, const float* gamma_dev, const float* beta_dev, float* out_dev,
                   int out_cs, void* stream);
+/* out = add + LayerNorm(x) (`source + message`, TransformerLayer.forward :517-523), out2 (nullable) = a second copy of the result in
+ * another channel window (the FFN's concat slot).  out may be add itself (in place); neither output may alias x. */
+int vfi_layernorm_add(const float* x_dev, int cs, int C, int64_t tokens, const float* gamma_dev, const float* beta_dev, const float* add_dev,
+                      int add_cs, float* out_dev, int out_cs, float* out2_dev, int out2_cs, void* stream);
 /* nn.GELU() (erf form) in place over a channel window (:467-471) */
 int vfi_gelu(float* x_dev, int cs, int C, int64_t pixels, void* stream);
 /* torch.roll by (-shift_h, -shift_w) + split_feature into splits x splits windows: [B,h,w,C] -> [B*K*K, (h/K)*(w/K), C];

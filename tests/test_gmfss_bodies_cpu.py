@@ -78,6 +78,12 @@ def test_instance_norm_and_layer_norm(lib):
     ln = torch.zeros(50, 128)
     ok(lib.vfi_layernorm(P(tok, 8), 136, 128, 50, P(gm), P(bt), P(ln), 128, None))
     assert (ln - F.layer_norm(tok[:, 8:], (128,), gm, bt)).abs().max() <= 2e-6
+    # source + LN(message) in place on the source, second copy into a wider tensor's channel window (TransformerLayer :517-523)
+    src, cat = torch.randn(50, 128), torch.full((50, 256), 7.0)
+    want = src + F.layer_norm(tok[:, 8:], (128,), gm, bt)
+    ok(lib.vfi_layernorm_add(P(tok, 8), 136, 128, 50, P(gm), P(bt), P(src), 128, P(src), 128, P(cat), 256, None))
+    assert (src - want).abs().max() <= 2e-6 and torch.equal(cat[:, :128], src) and (cat[:, 128:] == 7.0).all()
+    assert lib.vfi_layernorm_add(P(tok, 8), 136, 128, 50, P(gm), P(bt), P(src), 128, P(tok, 8), 136, None, 0, None) != 0   # out aliases x
 
 
 @pytest.mark.parametrize("shifted", [False, True])

@@ -35,6 +35,15 @@ def test_layernorm(hip_lib, tokens, c, cs, ocs):
     got = out.cpu()
     assert (got[:, :c] - want).abs().max().item() <= 2e-5, describe_diff(got[:, :c], want, "layernorm", chan_last=False)
     assert ocs == c or torch.isnan(got[:, c:]).all(), "wrote outside its channel window"
+    # vfi_layernorm_add: out = add + LN(x), in place on add, plus the second copy into a wider tensor
+    add = torch.randn(tokens, c, generator=g)
+    addd = add.cuda()
+    cat = torch.full((tokens, 2 * c), float("nan"), device="cuda")
+    _lib.check(hip_lib.vfi_layernorm_add(xd.data_ptr(), cs, c, tokens, gd.data_ptr(), bd.data_ptr(), addd.data_ptr(), c, addd.data_ptr(), c,
+                                         cat.data_ptr(), 2 * c, None), "vfi_layernorm_add")
+    torch.cuda.synchronize()
+    assert (addd.cpu() - (add + want)).abs().max().item() <= 2e-5
+    assert torch.equal(cat[:, :c].cpu(), addd.cpu()) and torch.isnan(cat[:, c:]).all()
 
 
 @pytest.mark.parametrize("b,h,w,gain", [(1, 16, 24, 1.0), (2, 13, 21, 1.0), (1, 34, 60, 3.0), (1, 136, 240, 1.0), (1, 5, 9, 1.0)])
@@ -129,3 +138,26 @@ def test_window_attention(hip_lib, B, h, w, splits, shifted):
     with pytest.raises(RuntimeError, match="aliases"):
         _lib.check(hip_lib.vfi_window_attention(qd.data_ptr(), c, kd.data_ptr(), c, vd.data_ptr(), c, qd.data_ptr(), c, B, h, w, splits, sh, sw, c,
                                                 1.0, None, None), "vfi_window_attention")
+
+
+@pytest.mark.parametrize("b,h,w", [(1, 10, 14), (2, 33, 47), (1, 136, 240)])
+def test_local_propagate_cooperative(hip_lib, b, h, w):
+    """C = 128, radius 1 (GMFlow's local flow propagation): 16 lanes per pixel instead of the per-pixel body"""
+    from cfi_amd import _lib
+
+    g = torch.Generator().manual_seed(h + w)
+    c = 128
+    f0 = torch.randn(b, c, h, w, generator=g)
+    flow = torch.randn(b, 2, h, w, generator=g) * 3
+    sd = {"feature_flow_attn.q_proj.weight": torch.randn(c, c, generator=g) * 0.1, "feature_flow_attn.q_proj.bias": torch.randn(c, generator=g) * 0.1,
+          "feature_flow_attn.k_proj.weight": torch.randn(c, c, generator=g) * 0.1, "feature_flow_attn.k_proj.bias": torch.randn(c, generator=g) * 0.1}
+    want = G.propagate(sd, f0, flow, 1)
+    tok = nhwc(f0)
+    qp = F.linear(tok, sd["feature_flow_attn.q_proj.weight"], sd["feature_flow_attn.q_proj.bias"]).contiguous().cuda()
+    kp = F.linear(tok, sd["feature_flow_attn.k_proj.weight"], sd["feature_flow_attn.k_proj.bias"]).contiguous().cuda()
+    fl = nhwc(flow).cuda()
+    out = torch.full((b, h, w, 2), float("nan"), device="cuda")
+    _lib.check(hip_lib.vfi_local_propagate(qp.data_ptr(), c, kp.data_ptr(), c, fl.data_ptr(), 2, out.data_ptr(), 2, b, h, w, c, 1, None), "vfi_local_propagate")
+    torch.cuda.synchronize()
+    got = out.cpu().permute(0, 3, 1, 2)
+    assert (got - want).abs().max().item() <= 2e-5, describe_diff(got, want, f"local_propagate {b}x{h}x{w}")
