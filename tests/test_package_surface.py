@@ -38,3 +38,15 @@ def test_rife_launch_size():
     assert effective_batch(16, 1080, 1920, 500) == 16        # long clips keep the widget's size
     assert effective_batch(32, 1080, 1920, 100) == 25
     assert effective_batch(16, 1080, 1920, 3) == 8           # (the launch is simply short)
+
+
+def test_rife_launch_ramp():
+    """half-size first and last launch for clips of two launches or more; every task exactly once, none above the configured size"""
+    from cfi_amd.rife import launch_sizes
+
+    assert launch_sizes(32, 8) == [4, 8, 8, 8, 4] and launch_sizes(16, 8) == [4, 8, 4] and launch_sizes(17, 8) == [4, 8, 5]
+    assert launch_sizes(15, 8) == [8, 7] and launch_sizes(3, 8) == [3] and launch_sizes(7, 2) == [2, 2, 2, 1] and launch_sizes(0, 8) == []
+    for n in range(0, 200):
+        for bs in (1, 2, 3, 4, 8, 16, 32):
+            sz = launch_sizes(n, bs)
+            assert sum(sz) == n and all(0 < x <= bs for x in sz)
