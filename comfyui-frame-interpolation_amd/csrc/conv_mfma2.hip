@@ -504,7 +504,11 @@ static int launch2_e(ConvArgs a, hipStream_t s, const char* name) {
     if (!GROUPED && a.out_mode == 0 && a.split_ok && split_enabled()) {
         const int nchunks = a.Cin_p / CK;
         const long wgs = (long)T * ny, want = 3L * cus * occ;
-        if (wgs < (long)cus * occ && nchunks >= 16) {      // less than one resident wave of workgroups
+        // ... and a K loop long enough that a fraction of it outweighs the reduce launch (~20 us): 32 chunks of a 3x3 layer
+        // (IFUNet's 128-channel layers at 16 chunks lost 0.7 ms per frame to their reduces)
+        // — or so few workgroups that the layer leaves 7/8 of the chip idle (FILM's 128-channel layers at 16 x 30 and 33 x 60)
+        const bool long_k = TAPS * nchunks >= 288, tiny = wgs * 8 <= (long)cus * occ && nchunks >= 16;
+        if (wgs < (long)cus * occ && (long_k || tiny)) {      // less than one resident wave of workgroups
             ks = (int)((want + wgs - 1) / wgs);
             ks = ks > nchunks / 8 ? nchunks / 8 : ks;
             ks = ks > 16 ? 16 : ks;
