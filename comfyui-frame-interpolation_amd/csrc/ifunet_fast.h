@@ -12,5 +12,6 @@ int chan_pool_final_wave_launch(const vfi_ifunet::PoolFinalArgs& a, void* stream
 int cbam_gate_wg_launch(const vfi_ifunet::GateArgs& a, void* stream);                 // R <= 64: a workgroup per image
 bool cbam_gate_wg_fits(const vfi_ifunet::GateArgs& a);
 int cbam_scale_compress_wave_launch(const vfi_ifunet::ScaleCompArgs& a, void* stream);   // lanes over channels
+int cbam_spatial_wave_launch(const vfi_ifunet::SpatialArgs& a, void* stream);            // taps and channels over the lanes
 
 }  // namespace vfi

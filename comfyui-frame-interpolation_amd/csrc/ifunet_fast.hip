@@ -130,7 +130,49 @@ __global__ __launch_bounds__(256) void cbam_scale_compress_wave_kernel(const Sca
     }
 }
 
+// SpatialGate (:469-482) with G lanes per pixel: the 49 taps of the 7x7 conv over the 2-channel compressed map are split over the
+// lanes and summed by shuffles, then every lane scales its channels (coalesced; the body's per-thread loop over C strided floats
+// was the cost)
+__global__ __launch_bounds__(256) void cbam_spatial_wave_kernel(const SpatialArgs a, int G) {
+    const int lane = threadIdx.x & 63;
+    const int ppw = 64 / G;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long pix = wave * ppw + lane / G;
+    const int g = lane & (G - 1);
+    const long total = (long)a.N * a.H * a.W;
+    const bool ok = pix < total;
+    const long pid = ok ? pix : 0;
+    const int X = (int)(pid % a.W), Y = (int)((pid / a.W) % a.H);
+    const int n = (int)(pid / ((long)a.W * a.H));
+    const float* cp = a.comp + (size_t)n * a.H * a.W * 2;
+    float s = 0.f;
+    for (int t = g; t < 49; t += G) {
+        const int ky = t / 7, kx = t - ky * 7;
+        const int y = Y + ky - 3, x = X + kx - 3;
+        if (y < 0 || y >= a.H || x < 0 || x >= a.W) continue;
+        const float* q = cp + ((size_t)y * a.W + x) * 2;
+        s += q[0] * a.w[t * 2] + q[1] * a.w[t * 2 + 1];
+    }
+    for (int o = G >> 1; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    const float gate = 1.0f / (1.0f + expf(-(s * a.bn_a + a.bn_b)));
+    if (ok) {
+        float* o = a.xs + pix * a.cs;
+        for (int c = g; c < a.C; c += G) o[c] *= gate;
+    }
+}
+
 }  // namespace
+
+int cbam_spatial_wave_launch(const SpatialArgs& a, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    int G = 1;
+    while (G < a.C && G < 64) G <<= 1;
+    const long pixels = (long)a.N * a.H * a.W, waves = (pixels + 64 / G - 1) / (64 / G);
+    TraceScope ts("cbam_spatial", s);
+    hipLaunchKernelGGL(cbam_spatial_wave_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a, G);
+    VFI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
 
 bool chan_pool_partial_wg_fits(const PoolPartArgs& a) { return a.C <= 256; }
 

@@ -63,6 +63,9 @@ int vfi_cbam_spatial(float* xs_dev, int cs, const float* comp_dev, const float* 
                      void* stream) {
     VFI_REQUIRE(xs_dev && comp_dev && w_dev && C > 0 && cs >= C && N > 0 && H > 0 && W > 0, "vfi_cbam_spatial: bad arguments");
     SpatialArgs a{xs_dev, cs, comp_dev, w_dev, bn_a, bn_b, C, N, H, W};
+#ifndef VFI_HOSTCHECK
+    return cbam_spatial_wave_launch(a, stream);
+#endif
     return run<SpatialArgs, cbam_spatial_body>(a, (long)N * H * W, stream, "cbam_spatial");
 }
 

@@ -62,3 +62,26 @@ def test_cbam_scale_compress(hip_lib, n, c, cs, hw):
     cp = comp.cpu().view(n, hw, 2)
     assert torch.equal(cp[..., 0], want.amax(-1))
     assert (cp[..., 1] - want.double().mean(-1).float()).abs().max().item() <= 2e-6
+
+
+@pytest.mark.parametrize("n,c,cs,h,w", [(1, 32, 32, 19, 23), (2, 96, 96, 9, 40), (1, 256, 256, 34, 60), (1, 17, 24, 8, 8)])
+def test_cbam_spatial(hip_lib, n, c, cs, h, w):
+    """SpatialGate (:469-482): xs *= sigmoid(bn(conv7x7(comp))), in place, channel window respected"""
+    import torch.nn.functional as F
+
+    from cfi_amd import _lib
+
+    g = torch.Generator().manual_seed(c + h)
+    xs = torch.randn(n, h, w, cs, generator=g)
+    comp = torch.randn(n, h, w, 2, generator=g)
+    wt = torch.randn(7, 7, 2, generator=g) * 0.1
+    bn_a, bn_b = 0.8, -0.1
+    s = F.conv2d(comp.permute(0, 3, 1, 2).double(), wt.permute(2, 0, 1)[None].double(), padding=3)[:, 0]      # [n, h, w]
+    want = xs.clone()
+    want[..., :c] = (xs[..., :c].double() * torch.sigmoid(s * bn_a + bn_b)[..., None]).float()
+    xd, cd, wd = xs.cuda(), comp.cuda(), wt.cuda()
+    _lib.check(hip_lib.vfi_cbam_spatial(xd.data_ptr(), cs, cd.data_ptr(), wd.data_ptr(), bn_a, bn_b, c, n, h, w, None), "vfi_cbam_spatial")
+    torch.cuda.synchronize()
+    got = xd.cpu()
+    assert (got[..., :c] - want[..., :c]).abs().max().item() <= 5e-6 * max(1.0, want.abs().max().item())
+    assert torch.equal(got[..., c:], xs[..., c:]), "touched channels outside its window"
