@@ -18,10 +18,11 @@ extern "C" {
 int vfi_channel_pool(const float* x_dev, int cs, int C, int N, int64_t HW, float* stats_dev, void* workspace_dev, int64_t workspace_bytes,
                      void* stream) {
     VFI_REQUIRE(x_dev && stats_dev && workspace_dev && C > 0 && cs >= C && N > 0 && HW > 0, "vfi_channel_pool: bad arguments");
-    // strips of the first pass: as many as the workspace holds, 64 (the minimum it must hold) .. 1024
+    // strips of the first pass: as many as the workspace holds, 64 (the minimum it must hold) .. 128
     const int64_t per_strip = (int64_t)N * C * (int64_t)(sizeof(double) + sizeof(float));
     VFI_REQUIRE(workspace_bytes >= 64 * per_strip, "vfi_channel_pool: workspace too small");
-    const int strips = (int)(workspace_bytes / per_strip < 1024 ? workspace_bytes / per_strip : 1024);
+    // (128 at most: the second pass reads every strip's partials of a channel, 64 of them per load instruction)
+    const int strips = (int)(workspace_bytes / per_strip < 128 ? workspace_bytes / per_strip : 128);
     const int64_t cells = (int64_t)N * strips * C;
     double* psum = (double*)workspace_dev;
     float* pmax = (float*)(psum + cells);

@@ -331,7 +331,7 @@ int vfi_clamp_crop(const float* in_dev, int in_cs, int Hp, int Wp, float* out_de
  * Bodies checked on the host (tests/hostcheck) and on the MI355X against the oracle (tests/test_gpu_ifunet.py). --------------- */
 
 /* CBAM ChannelGate pooling (:411-436): stats [N][C][2] = (mean, max) over H*W; workspace >= N*64*C*12 bytes
- * (a larger one is used for more, shorter strips of the first pass, up to 1024) */
+ * (a larger one is used for more, shorter strips of the first pass, up to 128) */
 int vfi_channel_pool(const float* x_dev, int cs, int C, int N, int64_t HW, float* stats_dev, void* workspace_dev, int64_t workspace_bytes,
                      void* stream);
 /* scale [N][C] = sigmoid(mlp(mean) + mlp(max)), mlp = Linear(C,R) -> ReLU -> Linear(R,C); w1 [R][C], w2 [C][R] on the device (:447-452) */
