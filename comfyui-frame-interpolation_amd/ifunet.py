@@ -26,7 +26,7 @@ WIDTHS = (256, 128, 64)
 
 class IFUNetEngine(OpsEngine):
     def __init__(self, state_dict, device=None, _test_backend=None):
-        super().__init__(device, _test_backend)
+        super().__init__(device, _test_backend, pooled=True)      # scratch from a pool, recycled stage by stage (see forward)
         want = ifunet_shapes()
         missing = [k for k in want if k not in state_dict]
         if missing:
@@ -172,54 +172,61 @@ class IFUNetEngine(OpsEngine):
         Hp, Wp = ((H - 1) // 64 + 1) * 64, ((W - 1) // 64 + 1) * 64
         hs, ws = self._scaled_sizes(Hp, Wp, s)
         px = Hp * Wp
-        # inputs of the three levels: x17 = (img0, img1, t, w0, w1, flow), x17e the swapped "ensemble" variant
-        x17, x17e = self._t("x17", 1, Hp, Wp, 24), self._t("x17e", 1, Hp, Wp, 24)
-        x7, x7e = self._t("x7", 1, Hp, Wp, 8), self._t("x7e", 1, Hp, Wp, 8)
-        for dst, order, tt in ((x17, (frame0, frame1), t), (x17e, (frame1, frame0), 1 - t), (x7, (frame0, frame1), t), (x7e, (frame1, frame0), 1 - t)):
-            for k, fr in enumerate(order):
-                self._c("vfi_pad_rgb", fr.data_ptr(), Cc, H, W, _p(dst, 3 * k), dst.shape[-1], Hp, Wp)
-            self._c("vfi_fill_channels", _p(dst, 6), dst.shape[-1], 1, px, tt)
-        flow, delta, flow2 = self._t("flow", 1, Hp, Wp, 4), self._t("delta", 1, Hp, Wp, 4), self._t("flow2", 1, Hp, Wp, 4)
+        with self._scope():      # everything of a call is scratch: the pool is empty again when it returns
+            # inputs of the three levels: x17 = (img0, img1, t, w0, w1, flow), x17e the swapped "ensemble" variant
+            x17, x17e = self._t("x17", 1, Hp, Wp, 24), self._t("x17e", 1, Hp, Wp, 24)
+            x7, x7e = self._t("x7", 1, Hp, Wp, 8), self._t("x7e", 1, Hp, Wp, 8)
+            for dst, order, tt in ((x17, (frame0, frame1), t), (x17e, (frame1, frame0), 1 - t), (x7, (frame0, frame1), t), (x7e, (frame1, frame0), 1 - t)):
+                for k, fr in enumerate(order):
+                    self._c("vfi_pad_rgb", fr.data_ptr(), Cc, H, W, _p(dst, 3 * k), dst.shape[-1], Hp, Wp)
+                self._c("vfi_fill_channels", _p(dst, 6), dst.shape[-1], 1, px, tt)
+            flow, delta, flow2 = self._t("flow", 1, Hp, Wp, 4), self._t("delta", 1, Hp, Wp, 4), self._t("flow2", 1, Hp, Wp, 4)
 
-        def estimate(i, xin, nimg, with_flow, tag):
-            if s != 1.0:
-                xs = self._t(f"xs{nimg}_{tag}", 1, hs, ws, xin.shape[-1])
-                self._resize(xin, 0, xs, 0, nimg)
-                if with_flow:
-                    self._resize(flow, 0, xs, 13, 4, s)            # F.interpolate(flow, scale) * scale
-            else:
-                xs = xin
-                if with_flow:
-                    self._ax(flow, 0, None, 0, xs, 13, 4)
-            self._if_block(i, self._feature_net(xs, i, tag), delta, tag)
+            def estimate(i, xin, nimg, with_flow, tag):
+                if s != 1.0:
+                    xs = self._t(f"xs{nimg}_{tag}", 1, hs, ws, xin.shape[-1])
+                    self._resize(xin, 0, xs, 0, nimg)
+                    if with_flow:
+                        self._resize(flow, 0, xs, 13, 4, s)            # F.interpolate(flow, scale) * scale
+                else:
+                    xs = xin
+                    if with_flow:
+                        self._ax(flow, 0, None, 0, xs, 13, 4)
+                self._if_block(i, self._feature_net(xs, i, tag), delta, tag)
 
-        for i in range(3):
-            if i == 0:
-                estimate(0, x7, 7, False, "a")
-                self._ax(delta, 0, None, 0, flow, 0, 4)
-                if ens:
-                    estimate(0, x7e, 7, False, "b")
-                    self._ax(flow, 0, delta, 0, flow, 0, 4, 0.5, 0.5)          # (flow + flow2) / 2
-            else:
-                estimate(i, x17, 13, True, "a")
-                self._ax(flow, 0, delta, 0, flow, 0, 4)
-                if ens:
-                    estimate(i, x17e, 13, True, "b")
-                    self._ax(flow, 0, delta, 0, flow2, 0, 4)                   # flow2 = flow + flow_d
-                    self._ax(flow, 0, flow2, 0, flow, 0, 4, 0.5, 0.5)
-            for k in (0, 1):   # warped_img0 = warp(img0, flow[:, :2]), warped_img1 = warp(img1, flow[:, 2:4]); same slots in both variants
-                self._c("vfi_warp_rife", _p(x17, 3 * k), 24, _p(flow, 2 * k), 4, _p(x17, 7 + 3 * k), 24, 1, Hp, Wp, 3)
-            self._ax(x17, 7, None, 0, x17e, 7, 6)
-        mask = self._rrdbnet(x17, flow)
-        deg = self._t("deg", 1, Hp, Wp, 4)
-        self._c("vfi_lerp_mask", _p(x17, 7), 24, _p(x17, 10), 24, _p(mask), mask.shape[-1], _p(deg), 4, 3, px)
-        imgs, masks = [], []
-        for k in (0, 1):
-            img, m = self._resyn(x17, 3 * k, deg, f"i{k}")
-            imgs.append(img)
-            masks.append(m)
-        self._c("vfi_ifunet_blend", _p(imgs[0]), _p(imgs[1]), _p(deg), 4, _p(masks[0]), _p(masks[1]), 1, out.data_ptr(), Hp, Wp, H, W)
-        return out
+            def stage(fn, *a):      # the temporaries of one stage (feature net + IFBlock, RRDBNet, a ResynNet pass) die with it
+                with self._scope():
+                    return fn(*a)
+
+            for i in range(3):
+                if i == 0:
+                    stage(estimate, 0, x7, 7, False, "a")
+                    self._ax(delta, 0, None, 0, flow, 0, 4)
+                    if ens:
+                        stage(estimate, 0, x7e, 7, False, "b")
+                        self._ax(flow, 0, delta, 0, flow, 0, 4, 0.5, 0.5)          # (flow + flow2) / 2
+                else:
+                    stage(estimate, i, x17, 13, True, "a")
+                    self._ax(flow, 0, delta, 0, flow, 0, 4)
+                    if ens:
+                        stage(estimate, i, x17e, 13, True, "b")
+                        self._ax(flow, 0, delta, 0, flow2, 0, 4)                   # flow2 = flow + flow_d
+                        self._ax(flow, 0, flow2, 0, flow, 0, 4, 0.5, 0.5)
+                for k in (0, 1):   # warped_img0 = warp(img0, flow[:, :2]), warped_img1 = warp(img1, flow[:, 2:4]); same slots in both variants
+                    self._c("vfi_warp_rife", _p(x17, 3 * k), 24, _p(flow, 2 * k), 4, _p(x17, 7 + 3 * k), 24, 1, Hp, Wp, 3)
+                self._ax(x17, 7, None, 0, x17e, 7, 6)
+            mask = self._t("rr_mask", 1, Hp, Wp, 8)              # a stage's outputs are requested here first, so that they outlive its scope
+            stage(self._rrdbnet, x17, flow)
+            deg = self._t("deg", 1, Hp, Wp, 4)
+            self._c("vfi_lerp_mask", _p(x17, 7), 24, _p(x17, 10), 24, _p(mask), mask.shape[-1], _p(deg), 4, 3, px)
+            imgs, masks = [], []
+            for k in (0, 1):
+                img, m = self._t(f"rs_img_i{k}", 1, Hp, Wp, 4), self._t(f"rs_mask_i{k}", 1, Hp, Wp, 1)
+                stage(self._resyn, x17, 3 * k, deg, f"i{k}")
+                imgs.append(img)
+                masks.append(m)
+            self._c("vfi_ifunet_blend", _p(imgs[0]), _p(imgs[1]), _p(deg), 4, _p(masks[0]), _p(masks[1]), 1, out.data_ptr(), Hp, Wp, H, W)
+            return out
 
     def _rrdbnet(self, x17, flow):
         """RRDBNet.forward (:306-328) -> sigmoid mask [1,Hp,Wp,8] (channel 0)"""

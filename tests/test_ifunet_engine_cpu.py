@@ -76,3 +76,25 @@ def test_node_against_reference_golden_on_the_test_double(golden_dir, tmp_path, 
     assert out.shape == want.shape and out.dtype == torch.float32
     assert (out - want).abs().max().item() <= 1e-3
     assert torch.equal(out[0], frames[0]) and torch.equal(out[-1], frames[-1])
+
+
+def test_repeated_calls_are_bit_identical_with_recycled_scratch():
+    """the engine's scratch comes from a pool and is recycled stage by stage: later calls run on stale, non-zero blocks — same
+    output bit for bit, and the pool stops growing after the first call of a shape"""
+    from cfi_amd.ifunet import IFUNetEngine
+
+    eng = IFUNetEngine(synth.ifunet_synth_state_dict(77), _test_backend=EmuBackend())
+    try:
+        fr = synth.smooth_frames(3, 64, 96, seed=5, shift=2.0)
+        outs = []
+        for rep, (a, b, t, ens) in enumerate(((0, 1, 0.5, True), (1, 2, 0.25, False), (0, 1, 0.5, True))):
+            o = torch.zeros(64, 96, 3)
+            eng.forward(fr[a].contiguous(), fr[b].contiguous(), t, o, scale=1.0, ensemble=ens)
+            outs.append(o)
+            if rep == 0:
+                used = eng.workspace_bytes()
+        assert torch.equal(outs[0], outs[2]) and not torch.equal(outs[0], outs[1])
+        assert eng.workspace_bytes() == used, "the pool keeps growing"
+        assert eng._live == [{}], "scratch outlived the call"
+    finally:
+        eng.close()
