@@ -16,6 +16,9 @@ PKG = os.path.dirname(CSRC)
 LIB = os.path.join(PKG, "libvfi_hip.so")
 STAMP = LIB + ".stamp"
 ARCH = "gfx950"
+# per-file flags.  conv_wino.hip: hipcc's SLP vectoriser packs the input-transform adds into v_pk_add_f32 with v_mov shuffles
+# — packed f32 VALU beside MFMAs is an anti-lever on gfx950 (MI355X_MICROARCH.md, per-instruction constants) and costs registers
+EXTRA_FLAGS = {"conv_wino.hip": ["-fno-slp-vectorize"]}
 
 
 def _sources():
@@ -24,7 +27,7 @@ def _sources():
 
 def _digest():
     h = hashlib.sha256()
-    files = _sources() + sorted(glob.glob(os.path.join(CSRC, "*.h")))
+    files = _sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.abspath(__file__)]
     files.append(os.path.join(PKG, "..", "include", "vfi_hip.h"))
     files.append(os.path.join(PKG, "..", "include", "vfi_hip_test.h"))
     for f in files:
@@ -43,7 +46,7 @@ def build_lib(force=False, verbose=True):
     procs = []
     for src in _sources():
         obj = os.path.join(CSRC, os.path.basename(src)[:-4] + ".o")
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"] + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((subprocess.Popen(cmd), src))

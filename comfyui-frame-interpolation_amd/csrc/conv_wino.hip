@@ -1,0 +1,509 @@
+// Winograd F(2x2, 3x3) convolution on the fp32 matrix cores of gfx950 (stride 1, pad 1; NHWC fp32).
+//
+// Replaces the 3x3 stride-1 convolutions of the reference — ResConv in IFBlock (vfi_models/rife/rife_arch.py:20-28,237-276),
+// FILM's 'same' 3x3 convs (film_arch.py:784-798), the M2M / IFRNet decoders — which the direct implicit-GEMM kernel
+// (conv_mfma2.hip) already runs at 0.84 of the fp32-MFMA peak: the remaining lever is the multiplication count.
+//   Y = A^T [ (G g G^T) .* (B^T d B) ] A      (Lavin & Gray; 4x4 input patch d -> 2x2 outputs, 16 products instead of 36)
+// turns the convolution into 16 independent GEMMs  M_xi[tile][co] = sum_ci V_xi[tile][ci] * U_xi[ci][co]  (xi = 0..15), i.e. 2.25x
+// fewer v_mfma_f32_32x32x2_f32 per output than the direct form, at identical (fp32, fmaf-chain) accumulation.
+//
+// MI355X mapping (one wave per SIMD, 512 registers per lane):
+//   * a wave owns a REGION of 32 tiles (8x4 tiles = 16x8 output pixels, or 16x2 = 32x4 for small images) and 32 output
+//     channels: 16 accumulators of 32x32 (tile x channel) = 256 AGPRs stay resident through the whole K loop;
+//   * the input transform B^T d B runs in registers, in EXACTLY the MFMA A-operand layout: lane (m = tile, half) reads its
+//     4x4 patch for channels 4*half .. 4*half+3 with 16 ds_read_b128 (LDS image [pixel][8 ch], LDS-DMA'd from the NHWC
+//     activation, out-of-image pixels zero-filled by the buffer descriptor), 32 v_add/v_sub per channel give the 16 V_xi
+//     values = the A operands of 16 MFMAs.  No transformed-input tensor ever exists in LDS or HBM;
+//   * U = G g G^T is computed on the host at weight-pack time, laid out [Cout/32][Cin/8][j][xi/4][half][co][xi%4] so that a
+//     (j, xi/4) slice is one 1 KiB LDS-DMA piece whose lane-linear image IS the B-operand order: one ds_read_b128 feeds the
+//     B operands of 4 MFMAs;
+//   * the output transform A^T M A runs in registers on the accumulator layout (lane = output channel, register = tile),
+//     fused with bias, beta, residual, activation and the NHWC store (32 lanes = 128 contiguous bytes per pixel);
+//   * K pipeline: 8-channel chunks, two LDS buffers, the DMA queue two chunks ahead across work-item boundaries; the patch
+//     of chunk k+1 is read right after the chunk barrier and transformed UNDER the last 16 MFMAs of chunk k;
+//   * regions are wave-private (each wave DMA's its own halo'd patch: only the weight tile is shared by the workgroup), so
+//     image sizes quantise to 16x8 (or 32x4) pixels instead of a 4-wave tile;
+//   * persistent workgroups, XCD-aware work order: the Cout/32 siblings of one region quad run on the SAME XCD at the same
+//     time (block b -> XCD b % 8), so the activation is fetched from HBM once and hit in that XCD's L2 by the siblings.
+#include "vfi_common.h"
+
+#include <atomic>
+#include <cstdlib>
+
+namespace vfi {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+struct WinoArgs {
+    ConvArgs a;     // in / bias / beta / res / prelu / out, sizes, act ... (a.w = the Winograd-packed weights)
+    int rx, ry;     // regions per image
+    int R;          // regions in total (N * ry * rx)
+    int NQ;         // region quads (4 regions = the 4 waves of a workgroup)
+    int NY;         // Cout_p / 32
+    int xcd_map;    // 1: XCD-aware work order (gridDim.x % 8 == 0)
+};
+
+template <int RTX>
+struct WinoGeom {
+    static constexpr int RTY = 32 / RTX;
+    static constexpr int RW = 2 * RTX, RH = 2 * RTY;     // output pixels of a region
+    static constexpr int PW = RW + 2, PH = RH + 2;       // its input patch
+    static constexpr int NPIX = PW * PH;
+    static constexpr int NITEM = NPIX * 2;               // 16-byte items per region per 8-channel chunk
+    static constexpr int NA = (NITEM + 63) / 64;         // 1 KiB DMA pieces per wave and chunk
+    static constexpr int A_FLOATS = NA * 256;
+    static constexpr int B_FLOATS = 16 * 256;
+    static constexpr int BUF_FLOATS = 4 * A_FLOATS + B_FLOATS;
+    static constexpr int LDS_BYTES = 2 * BUF_FLOATS * 4;
+    static_assert(NITEM % 4 == 0 && PW % 2 == 0, "swizzle stays inside the image and inside a row");
+};
+
+// LDS slot (16-byte units) of item (pixel (py, px), channel quad q) inside a wave's A image: the natural slot with its low two
+// bits XORed by a row-pair key.  A wave's ds_read_b128 of one patch position touches tiles 2 px apart = slots 4 apart, i.e.
+// only every fourth 16-byte bank group; the key spreads the four tile rows over the four groups (conflict-free for 8x4 tiles).
+__device__ __forceinline__ int wino_key(int py) { return (py >> 1) & 3; }
+
+
+// Output transform + fused epilogue of one region (one wave).  acc[xi][r]: lane = output channel (l31), register r = tile
+// m = 8 * (r >> 2) + 4 * half + (r & 3) (MFMA 32x32 D layout).  Stores and residual loads go through buffer descriptors of the
+// image: an out-of-image pixel (or a padded output channel) gets offset 0x80000000 and the hardware drops / zero-fills it —
+// no per-value branches.  MODE 0: the hot form (no residual, none / LeakyReLU with a slope in [0,1]: lrelu(v) = max(v, v*slope));
+// MODE 10 + act: the general form (residual, any activation of ConvArgs::act, post affine).
+template <int RTX, int MODE>
+__device__ __forceinline__ void wino_epilogue(const f32x16 (&acc)[16], const ConvArgs& a, int n, int oy0, int ox0, int co, int coc, int half) {
+    const int H = a.Hin, W = a.Win;
+    const float bs = a.bias[coc];
+    const float bt = a.beta ? a.beta[coc] : 1.f;
+    const float uslope = a.act == 1 ? a.slope : 1.0f;
+    const float ps = a.post_scale != 0.f ? a.post_scale : 1.0f, sh = a.post_scale != 0.f ? a.post_shift : 0.0f;
+    const float pre = MODE == 13 ? a.prelu[coc] : 0.f;
+    const __amdgpu_buffer_rsrc_t orsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)n * H * W * a.out_cs), 0, H * W * a.out_cs * 4, 0x00020000);
+    const bool has_res = MODE >= 10 && a.res != nullptr;
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(has_res ? a.res + (size_t)n * H * W * a.res_cs : a.out), 0, has_res ? H * W * a.res_cs * 4 : 0, 0x00020000);
+    constexpr int NXO = RTX == 8 ? 8 : 16;      // distinct x positions a lane stores to: 8 * half + 0..7 (+ 16 for the second tile row group)
+    int xoff[NXO], xres[NXO];
+#pragma unroll
+    for (int i = 0; i < NXO; ++i) {
+        const int xx = (i >> 3) * 16 + 8 * half + (i & 7);
+        const bool ok = ox0 + xx < W && co < a.Cout;
+        xoff[i] = ok ? ((ox0 + xx) * a.out_cs + co) * 4 : (int)0x80000000;
+        xres[i] = ok ? ((ox0 + xx) * a.res_cs + co) * 4 : (int)0x80000000;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m0 = 8 * (r >> 2) + (r & 3);          // tile index without the lane's half (added through xoff)
+        const int tyy = m0 / RTX, txx0 = m0 % RTX;      // RTX 8: (r >> 2, r & 3); RTX 16: (r >> 3, 8 * ((r >> 2) & 1) + (r & 3))
+        float s0[4], s1[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float q0 = acc[c][r], q1 = acc[4 + c][r], q2 = acc[8 + c][r], q3 = acc[12 + c][r];
+            s0[c] = (q0 + q1) + q2;
+            s1[c] = (q1 - q2) - q3;
+        }
+        float y[4];
+        y[0] = (s0[0] + s0[1]) + s0[2];
+        y[1] = (s0[1] - s0[2]) - s0[3];
+        y[2] = (s1[0] + s1[1]) + s1[2];
+        y[3] = (s1[1] - s1[2]) - s1[3];
+#pragma unroll
+        for (int ey = 0; ey < 2; ++ey) {
+            const int oy = oy0 + 2 * tyy + ey;          // wave-uniform
+            if (oy < H) {
+                const int rowo = oy * W * a.out_cs * 4, rowr = oy * W * a.res_cs * 4;
+#pragma unroll
+                for (int ex = 0; ex < 2; ++ex) {
+                    const int xi = (txx0 >> 3) * 8 + 2 * (txx0 & 7) + ex;      // index into xoff: xx = 2 * txx + ex, txx = txx0 + 4 * half
+                    float v = (y[ey * 2 + ex] + bs) * bt;
+                    if (MODE == 0) {
+                        v = fmaxf(v, v * uslope);
+                    } else {
+                        if (has_res) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrsrc, xres[xi] + rowr, 0, 0));
+                        if (MODE == 11) v = v > 0.f ? v : v * a.slope;
+                        else if (MODE == 12) v = fminf(fmaxf(v, 0.f), 1.f);
+                        else if (MODE == 13) v = v > 0.f ? v : v * pre;
+                        else if (MODE == 14) v = 1.0f / (1.0f + expf(-v));
+                        else if (MODE == 15) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                        v = v * ps + sh;
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orsrc, xoff[xi] + rowo, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // one tile at a time: left alone, hipcc hoists all 256 accumulator reads (spills)
+    }
+}
+
+template <int RTX, bool EXT>
+__global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using G = WinoGeom<RTX>;
+    constexpr int PW = G::PW, RW = G::RW, RH = G::RH, NA = G::NA;
+    const ConvArgs& a = p.a;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int ty = l31 / RTX, tx = l31 % RTX;
+    const int C8 = a.Cin_p >> 3;
+    const int H = a.Hin, W = a.Win;
+    const int img_floats = H * W * a.in_cs;
+
+    // ---- work order -----------------------------------------------------------------------------------------------------
+    struct Cur {
+        int nb, n, Ry0, Rx0;
+        bool valid;    // this wave's region exists
+    };
+    const int gsz = gridDim.x, wg = blockIdx.x;
+    auto item = [&](int i, Cur& c) -> bool {
+        int quad;
+        if (p.xcd_map) {
+            const int x = wg & 7, slot = wg >> 3, S = gsz >> 3;
+            const int jl = slot + i * S;
+            const int nqx = x < p.NQ ? (p.NQ - x + 7) >> 3 : 0;
+            if (jl >= nqx * p.NY) return false;
+            quad = x + 8 * (jl / p.NY);
+            c.nb = jl % p.NY;
+        } else {
+            const long idx = (long)wg + (long)i * gsz;
+            if (idx >= (long)p.NQ * p.NY) return false;
+            quad = (int)(idx / p.NY);
+            c.nb = (int)(idx % p.NY);
+        }
+        const int rg = quad * 4 + wave;
+        c.valid = rg < p.R;
+        const int rr = c.valid ? rg : 0;
+        const int per = p.rx * p.ry;
+        c.n = rr / per;
+        const int rem = rr - c.n * per;
+        const int ryi = rem / p.rx;
+        c.Ry0 = ryi * RH;
+        c.Rx0 = (rem - ryi * p.rx) * RW;
+        return true;
+    };
+
+    // ---- activation DMA: per lane and piece, the (py, px, q) it fetches (kernel constants), then per region the byte offsets
+    int pcode[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int sp = i * 64 + lane;                    // swizzled slot = where the DMA puts this lane's 16 bytes
+        const int py = (sp >> 1) / PW;
+        const int s = sp ^ wino_key(py);
+        const int pix = s >> 1;
+        pcode[i] = sp < G::NITEM ? ((py << 16) | ((pix - py * PW) << 1) | (s & 1)) : -1;
+    }
+    auto make_avoff = [&](const Cur& c, int(&avoff)[NA]) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int code = pcode[i];
+            const int iy = c.Ry0 - 1 + (code >> 16), ix = c.Rx0 - 1 + ((code >> 1) & 0x7fff);
+            const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);       // replicate padding = edge clamp
+            const bool ok = code >= 0 && c.valid && (a.pad_replicate || (cy == iy && cx == ix));
+            avoff[i] = ok ? ((cy * W + cx) * a.in_cs + (code & 1) * 4) * 4 : (int)0x80000000;
+        }
+    };
+    auto make_rsrc = [&](int n) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)n * img_floats), 0, img_floats * 4, 0x00020000);
+    };
+    auto issue = [&](const __amdgpu_buffer_rsrc_t& rsrc, const int(&avoff)[NA], int nb, int k, int buf) {
+        float* abuf = smem + buf * G::BUF_FLOATS + wave * G::A_FLOATS;
+        float* bbuf = smem + buf * G::BUF_FLOATS + 4 * G::A_FLOATS;
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(abuf + i * 256), 16, avoff[i] + k * 32, 0, 0, 0);
+        const float* wb = a.w + ((size_t)(nb * C8 + k) * 16) * 256 + lane * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = wave + 4 * i;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(wb + piece * 256), (lds_ptr_t)(bbuf + piece * 256), 16, 0, 0);
+        }
+    };
+
+    // ---- patch read offsets (floats inside the wave's A image): 4 lane-dependent bases + compile-time (dy, dx) offsets
+    int pb[4];   // index (dx & 1) * 2 + (dy >> 1)
+    {
+        const int base = (2 * ty * PW + 2 * tx) * 2;     // multiple of 4
+#pragma unroll
+        for (int dxp = 0; dxp < 2; ++dxp)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) pb[dxp * 2 + kk] = (base + ((half + 2 * dxp) ^ ((ty + kk) & 3))) * 4;
+    }
+
+    f32x4 P[16];
+    f32x4 Bc[4], Bn[4];
+    float Vc[16], Vn[16];
+    f32x16 acc[16];
+
+    auto read_patch = [&](int buf) {
+        const float* sA = smem + buf * G::BUF_FLOATS + wave * G::A_FLOATS;
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx)
+                P[dy * 4 + dx] = *(const f32x4*)(sA + pb[(dx & 1) * 2 + (dy >> 1)] + ((((dy * PW + dx) * 2) & ~3) * 4));
+    };
+    auto read_b = [&](int buf, int j, f32x4(&B)[4]) {
+        const float* sB = smem + buf * G::BUF_FLOATS + 4 * G::A_FLOATS + lane * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) B[q] = *(const f32x4*)(sB + (j * 4 + q) * 256);
+    };
+
+    // ---- prologue: two chunks of DMA in flight, first patch transformed
+    Cur dcur, ccur;
+    int d_it = 0, d_k = 0;
+    bool d_ok = item(0, dcur);
+    if (!d_ok) return;
+    int davoff[NA];
+    make_avoff(dcur, davoff);
+    __amdgpu_buffer_rsrc_t drsrc = make_rsrc(dcur.n);
+    auto dma_issue = [&](int buf) {      // the cursor's chunk into `buf`
+        if (d_ok) issue(drsrc, davoff, dcur.nb, d_k, buf);
+    };
+    auto dma_advance = [&]() {
+        if (d_ok && ++d_k == C8) {
+            d_k = 0;
+            d_ok = item(++d_it, dcur);
+            if (d_ok) {
+                make_avoff(dcur, davoff);
+                drsrc = make_rsrc(dcur.n);
+            }
+        }
+    };
+    dma_issue(0);
+    dma_advance();
+    __syncthreads();     // (s_waitcnt vmcnt(0) + barrier: chunk 0 of every wave has landed)
+    dma_issue(1);
+    dma_advance();
+    read_patch(0);
+    read_b(0, 0, Bc);
+
+#define WINO_TRANSFORM(J, V)                                                              \
+    {                                                                                     \
+        float t_[16];                                                                     \
+        _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) {                                \
+            const float d0 = P[c_][J], d1 = P[4 + c_][J], d2 = P[8 + c_][J], d3 = P[12 + c_][J]; \
+            t_[c_] = d0 - d2;                                                             \
+            t_[4 + c_] = d1 + d2;                                                         \
+            t_[8 + c_] = d2 - d1;                                                         \
+            t_[12 + c_] = d1 - d3;                                                        \
+        }                                                                                 \
+        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                \
+            V[r_ * 4 + 0] = t_[r_ * 4] - t_[r_ * 4 + 2];                                  \
+            V[r_ * 4 + 1] = t_[r_ * 4 + 1] + t_[r_ * 4 + 2];                              \
+            V[r_ * 4 + 2] = t_[r_ * 4 + 2] - t_[r_ * 4 + 1];                              \
+            V[r_ * 4 + 3] = t_[r_ * 4 + 1] - t_[r_ * 4 + 3];                              \
+        }                                                                                 \
+    }
+    // One sub-step = the 16 MFMAs of (chunk, j) in 4 groups, with the NEXT sub-step's operands prepared underneath: its B
+    // fragments are requested behind group 0 (hipcc waits lgkmcnt(0) before a fragment's first use: they get 3/4 of a sub-step),
+    // its transform (channel JN of the patch in registers) runs behind groups 2 and 3 — at a chunk boundary that leaves the
+    // freshly requested patch two MFMA groups to arrive.  sched_barrier(0) pins the groups (left alone hipcc clusters the VALU in
+    // front of the MFMAs); PRE is extra work issued behind group 0 / 1 (the chunk DMA at a boundary).
+#define WINO_SUBSTEP(JN, NEXTBUF, PRE0, PRE1)                                                                       \
+    {                                                                                                               \
+        float t_[16];                                                                                               \
+        _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                                      \
+            _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_)                                                        \
+                acc[g_ * 4 + e_] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vc[g_ * 4 + e_], Bc[g_][e_], acc[g_ * 4 + e_], 0, 0, 0); \
+            if (g_ == 0) {                                                                                          \
+                read_b(NEXTBUF, JN, Bn);                                                                            \
+                PRE0;                                                                                               \
+            } else if (g_ == 1) {                                                                                   \
+                PRE1;                                                                                               \
+            } else if (g_ == 2) {                                                                                   \
+                _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) {                                                  \
+                    const float d0 = P[c_][JN], d1 = P[4 + c_][JN], d2 = P[8 + c_][JN], d3 = P[12 + c_][JN];        \
+                    t_[c_] = d0 - d2;                                                                               \
+                    t_[4 + c_] = d1 + d2;                                                                           \
+                    t_[8 + c_] = d2 - d1;                                                                           \
+                    t_[12 + c_] = d1 - d3;                                                                          \
+                }                                                                                                   \
+            } else {                                                                                                \
+                _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                                  \
+                    Vn[r_ * 4 + 0] = t_[r_ * 4] - t_[r_ * 4 + 2];                                                   \
+                    Vn[r_ * 4 + 1] = t_[r_ * 4 + 1] + t_[r_ * 4 + 2];                                               \
+                    Vn[r_ * 4 + 2] = t_[r_ * 4 + 2] - t_[r_ * 4 + 1];                                               \
+                    Vn[r_ * 4 + 3] = t_[r_ * 4 + 1] - t_[r_ * 4 + 3];                                               \
+                }                                                                                                   \
+            }                                                                                                       \
+            if (g_ >= 2) { /* 16 VALU of the transform: 4 behind each MFMA, not 16 behind the first */               \
+                _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                                  \
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                              \
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                              \
+                }                                                                                                   \
+            }                                                                                                       \
+        }                                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) Vc[i_] = Vn[i_];                                          \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) Bc[i_] = Bn[i_];                                           \
+    }
+
+    WINO_TRANSFORM(0, Vc);
+
+    int gchunk = 0;                      // chunk counter of this workgroup's stream: buffer = gchunk & 1
+    for (int it = 0; item(it, ccur); ++it) {
+#pragma unroll
+        for (int x = 0; x < 16; ++x)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+        bool more = true;                // a chunk follows the current one in this workgroup's stream
+        for (int k = 0; k < C8; ++k, ++gchunk) {
+            const int buf = gchunk & 1;
+            WINO_SUBSTEP(1, buf, (void)0, (void)0);
+            WINO_SUBSTEP(2, buf, (void)0, (void)0);
+            WINO_SUBSTEP(3, buf, (void)0, (void)0);
+            // chunk boundary: every wave has pulled chunk k into registers; chunk k+1 has landed (vmcnt(0) in the barrier)
+            __syncthreads();
+            // does a chunk follow in this workgroup's stream?  Inside the item always; at its end iff the NEXT item exists (the
+            // DMA cursor is two chunks ahead, so its state does not say: ask the work order)
+            if (k + 1 == C8) {
+                Cur tmp;
+                more = item(it + 1, tmp);
+            }
+            if (more) read_patch(buf ^ 1);
+            // last 16 MFMAs of chunk k; underneath: chunk gchunk + 2 into the buffer just released, B fragments and transform
+            // of (k + 1, j = 0)
+            WINO_SUBSTEP(0, buf ^ 1, dma_issue(buf), dma_advance());
+        }
+
+        // ---- epilogue: Y = A^T M A per tile in registers, + bias, * beta, (+ residual), activation, NHWC store
+        if (ccur.valid) {
+            const int co = ccur.nb * 32 + l31;
+            const int coc = co < a.Cout ? co : a.Cout - 1;
+            if (!EXT) {
+                wino_epilogue<RTX, 0>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half);
+            } else {
+                switch (a.act) {
+                    case 0: wino_epilogue<RTX, 10>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half); break;
+                    case 1: wino_epilogue<RTX, 11>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half); break;
+                    case 2: wino_epilogue<RTX, 12>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half); break;
+                    case 3: wino_epilogue<RTX, 13>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half); break;
+                    case 4: wino_epilogue<RTX, 14>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half); break;
+                    default: wino_epilogue<RTX, 15>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half); break;
+                }
+            }
+        }
+    }
+#undef WINO_SUBSTEP
+#undef WINO_TRANSFORM
+#endif
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------
+// U = G g G^T per (co, ci), laid out [Cout_p/32][Cin_p/8][j][xi/4][half][co%32][xi%4]; physical input channel
+// pc = c8 * 8 + half * 4 + j.  chan_map translates logical to physical input channels (concat windows), nullptr = identity.
+void pack_wino3x3(const float* w_oihw, int Cout, int Cin, const int* chan_map, int Cin_p, int Cout_p, std::vector<float>& wp) {
+    const int C8 = Cin_p / 8;
+    wp.assign((size_t)16 * Cin_p * Cout_p, 0.f);
+    static const double Gm[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    for (int co = 0; co < Cout; ++co)
+        for (int ci = 0; ci < Cin; ++ci) {
+            const int pc = chan_map ? chan_map[ci] : ci;
+            const float* g = w_oihw + ((size_t)co * Cin + ci) * 9;
+            double tmp[4][3], U[4][4];
+            for (int r = 0; r < 4; ++r)
+                for (int c = 0; c < 3; ++c) tmp[r][c] = Gm[r][0] * g[0 * 3 + c] + Gm[r][1] * g[1 * 3 + c] + Gm[r][2] * g[2 * 3 + c];
+            for (int r = 0; r < 4; ++r)
+                for (int c = 0; c < 4; ++c) U[r][c] = tmp[r][0] * Gm[c][0] + tmp[r][1] * Gm[c][1] + tmp[r][2] * Gm[c][2];
+            const int nb = co / 32, c32 = co % 32, c8 = pc / 8, hf = (pc % 8) / 4, j = pc % 4;
+            for (int xi = 0; xi < 16; ++xi) {
+                const size_t idx = ((((((size_t)nb * C8 + c8) * 4 + j) * 4 + (xi >> 2)) * 2 + hf) * 32 + c32) * 4 + (xi & 3);
+                wp[idx] += (float)U[xi >> 2][xi & 3];
+            }
+        }
+}
+
+static bool wino_env_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("VFI_CONV_WINOGRAD");     // experiment hook: VFI_CONV_WINOGRAD=0 keeps every 3x3 on the direct kernel
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
+static int wino_cus(int dev) {
+    static std::atomic<int> cus_of[kMaxDevices];
+    int c = cus_of[dev].load(std::memory_order_relaxed);
+    if (!c) {
+        hipDeviceProp_t pr;
+        if (hipGetDeviceProperties(&pr, dev) != hipSuccess) return 256;
+        c = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+        cus_of[dev].store(c, std::memory_order_relaxed);
+    }
+    return c;
+}
+
+// Is the Winograd kernel the better choice for this layer on this launch?  (3x3 stride 1 only; enough work items to fill the
+// chip — coarse pyramid levels with long K stay on the direct kernel's split-K path.)
+bool conv_wino_eligible(const ConvArgs& a) {
+    if (!wino_env_enabled()) return false;
+    if (a.ntaps != 9 || a.Hout != a.Hin || a.Wout != a.Win || a.in_plane || a.out_mode != 0) return false;
+    if (a.Cin_p % 8 || a.Cout_p % 32) return false;
+    if ((long)a.Hin * a.Win * a.in_cs * 4 >= 0x7fffffffL) return false;
+    const long regions = (long)a.N * cdiv(a.Hin, 8) * cdiv(a.Win, 16);
+    return regions / 4 * (a.Cout_p / 32) >= 192;
+}
+
+template <int RTX, bool EXT>
+static int wino_launch_t(WinoArgs& p, hipStream_t s, const char* name) {
+    using G = WinoGeom<RTX>;
+    ConvArgs& a = p.a;
+    p.rx = cdiv(a.Win, G::RW);
+    p.ry = cdiv(a.Hin, G::RH);
+    p.R = a.N * p.rx * p.ry;
+    p.NQ = cdiv(p.R, 4);
+    p.NY = a.Cout_p / 32;
+    int dev = 0;
+    VFI_CHECK_HIP(hipGetDevice(&dev));
+    VFI_REQUIRE(dev >= 0 && dev < kMaxDevices, "conv_wino %s: device index %d out of range", name, dev);
+    static std::atomic<int> attr_set[kMaxDevices];
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
+        VFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<RTX, EXT>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+        attr_set[dev].store(1, std::memory_order_release);
+    }
+    const int cus = wino_cus(dev);
+    const long items = (long)p.NQ * p.NY;
+    int grid = (int)(items < cus ? items : cus);
+    grid = round_up(grid, 8);
+    p.xcd_map = 1;
+    TraceScope ts(name, s);
+    hipLaunchKernelGGL((conv_wino_kernel<RTX, EXT>), dim3(grid), dim3(256), G::LDS_BYTES, s, p);
+    VFI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// a.w must point at pack_wino3x3's output (device).  variant: 0 = pick, 8 / 16 = region shape (tiles per row)
+int conv_wino_launch(const ConvArgs& a, int variant, hipStream_t s, const char* name) {
+    VFI_REQUIRE(a.ntaps == 9 && a.Hout == a.Hin && a.Wout == a.Win && !a.in_plane && a.out_mode == 0,
+                "conv_wino %s: 3x3 stride-1 NHWC layers only", name);
+    VFI_REQUIRE(a.Cin_p % 8 == 0 && a.Cout_p % 32 == 0 && a.in_cs >= a.Cin_p && a.in_cs % 4 == 0, "conv_wino %s: bad channel padding Cin_p=%d Cout_p=%d in_cs=%d",
+                name, a.Cin_p, a.Cout_p, a.in_cs);
+    VFI_REQUIRE(((uintptr_t)a.in & 15) == 0 && ((uintptr_t)a.w & 15) == 0, "conv_wino %s: unaligned pointers", name);
+    VFI_REQUIRE((long)a.Hin * a.Win * a.in_cs * 4 < 0x7fffffffL, "conv_wino %s: image larger than 2 GiB", name);
+    VFI_REQUIRE(a.act != 3 || a.prelu, "conv_wino %s: act 3 needs per-channel slopes", name);
+    WinoArgs p;
+    p.a = a;
+    if (variant == 0) {     // region shape by covered-area efficiency: 16x8 pixels unless 32x4 wastes clearly less
+        const double area = (double)a.Hin * a.Win;
+        const double e8 = area / ((double)cdiv(a.Win, 16) * 16 * cdiv(a.Hin, 8) * 8);
+        const double e16 = area / ((double)cdiv(a.Win, 32) * 32 * cdiv(a.Hin, 4) * 4);
+        variant = e16 > e8 * 1.03 ? 16 : 8;
+    }
+    VFI_REQUIRE(variant == 8 || variant == 16, "conv_wino %s: bad variant %d", name, variant);
+    VFI_REQUIRE((long)a.Hin * a.Win * a.out_cs * 4 < 0x7fffffffL && (!a.res || (long)a.Hin * a.Win * a.res_cs * 4 < 0x7fffffffL),
+                "conv_wino %s: output / residual image larger than 2 GiB", name);
+    // the hot epilogue: no residual, no post affine, none / LeakyReLU with a slope in [0,1]
+    const bool ext = a.res != nullptr || a.post_scale != 0.f || !(a.act == 0 || (a.act == 1 && a.slope >= 0.f && a.slope <= 1.f));
+    if (variant == 16) return ext ? wino_launch_t<16, true>(p, s, name) : wino_launch_t<16, false>(p, s, name);
+    return ext ? wino_launch_t<8, true>(p, s, name) : wino_launch_t<8, false>(p, s, name);
+}
+
+}  // namespace vfi

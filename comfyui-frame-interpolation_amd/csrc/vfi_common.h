@@ -107,6 +107,14 @@ void pack_conv3x3(const float* w_oihw, const float* bias, int Cout, int Cin, int
 void pack_deconv4x4(const float* w_iohw, const float* bias, int Cin, int Cout, int Cin_p,
                     int Cout_p, std::vector<float>& wp, std::vector<float>& bp);
 void conv3x3_taps(ConvArgs& a);
+
+// ---- Winograd F(2x2,3x3) form of the 3x3 stride-1 convolution (conv_wino.hip) ------------------------------------------------
+// Weights: U = G g G^T, packed [Cout_p/32][Cin_p/8][j][xi/4][half][co%32][xi%4] (16 * Cin_p * Cout_p floats); chan_map translates
+// logical to physical input channels (nullptr = identity).  Launch: ConvArgs as for the direct kernel with a.w = that pack;
+// variant 0 = pick the region shape, 8 / 16 = 16x8 / 32x4 output pixels per wave.
+void pack_wino3x3(const float* w_oihw, int Cout, int Cin, const int* chan_map, int Cin_p, int Cout_p, std::vector<float>& wp);
+bool conv_wino_eligible(const ConvArgs& a);
+int conv_wino_launch(const ConvArgs& a, int variant, hipStream_t s, const char* trace_name);
 void deconv4x4_taps(ConvArgs& a);
 
 int conv_naive_launch(const float* in, const float* w_oihw_dev, const float* bias_dev,

@@ -279,3 +279,24 @@ def noise_frames(n, h, w, seed=0, c=3):
     g = torch.Generator(device="cpu")
     g.manual_seed(seed)
     return torch.rand(n, h, w, c, generator=g, dtype=torch.float32)
+
+
+# ---- "hot" checkpoints: the same keys / shapes with gains that make the networks move pixels by tens of px (trained
+# checkpoints do; torch-default init gives 3-5 px).  Goldens: oracle/make_golden_bocchi.py; tests: *_bocchi_* / *_hot_*.
+
+def rife47_hot_state_dict(seed=1234, gain=8.0):
+    """RIFE 4.7 with every ``lastconv`` (flow + mask + feature heads) x ``gain``: flows of 40-70 px per block on real
+    1080p content, mask logits of tens of units, warps leaving the frame at the borders."""
+    return {k: ((v * gain).contiguous() if "lastconv" in k else v) for k, v in rife47_synth_state_dict(seed).items()}
+
+
+def film_hot_state_dict(seed=1234):
+    """FILM: ``film_synth_state_dict``'s variance-preserving gain already yields 20+ px residual flows per pyramid level
+    (80+ px accumulated at the finest level of a 1080p pair); gain 1.3 roughly doubles that without overflowing."""
+    return film_synth_state_dict(seed, gain=1.3)
+
+
+def m2m_hot_state_dict(seed=1234):
+    """M2M with gain 1.3: PWC flows of ~10 px at quarter resolution, refined multi-branch flows of 30-100 px, i.e. the
+    splat works on strongly convergent / divergent fields (occlusions, holes filled by the linear blend)."""
+    return m2m_synth_state_dict(seed, gain=1.3)

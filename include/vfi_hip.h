@@ -57,7 +57,8 @@ int vfi_warp_border(const float* in_dev, const float* flow_dev, float* out_dev,
  *   in  [N,H,W,Cin]  out [N,Ho,Wo,Cout]   Ho = (H+2-3)/stride+1
  *   beta (host, [Cout]) may be NULL; if given: y = lrelu(conv*beta + in) (requires Cin==Cout, stride 1)
  *   act: 0 none, 1 LeakyReLU(slope)
- *   variant: -1 = heuristic, >=0 selects a tile configuration (see csrc/conv_mfma.hip). */
+ *   variant: -1 = heuristic, >=0 selects a tile configuration (see csrc/conv_mfma.hip); 100 / 101 = the Winograd F(2x2,3x3)
+ *            form (stride 1; csrc/conv_wino.hip) with 16x8 / 32x4 output pixels per wave. */
 int vfi_conv3x3(const float* in_dev, const float* weight_host, const float* bias_host,
                 const float* beta_host, float* out_dev, int N, int H, int W, int Cin, int Cout,
                 int stride, int act, float slope, int variant, void* stream);

@@ -20,6 +20,11 @@ int vfi_conv3x3_naive(const float* in_dev, const float* weight_host, const float
                       int Cout, int stride, int act, float slope, void* stream);
 
 
+/* The Winograd F(2x2,3x3) weight pack of a 3x3 layer (csrc/conv_wino.hip: U = G g G^T, layout
+ * [Cout_p/32][Cin_p/8][j][xi/4][half][co%32][xi%4], physical input channel = c8*8 + half*4 + j), written to a HOST buffer: lets the
+ * CPU suite check the pack and emulate the kernel's addressing (tests/test_wino_emulation.py).  Returns floats written or < 0. */
+int64_t vfi_test_pack_wino3x3(const float* weight_host, int Cout, int Cin, const int* chan_map, int Cin_p, float* out_host, int64_t cap);
+
 /* Debug taps for parity tests: copy internal tensors of the LAST interpolate call to host.
  * what: 0 = flow after stage `stage` [B,Hp,Wp,4];  1 = stage input X of `stage`, planar4 [B,Cx/4,Hs,Ws,4];
  *       2 = frame slot pack, planar4 [2,Hp,Wp,4] = (rgb0 | encode features) (stage = slot).

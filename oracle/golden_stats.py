@@ -1,0 +1,59 @@
+"""ORACLE tooling (test infrastructure only) — compact fingerprints of a full-size frame.
+
+A 1080p fp32 frame is 25 MB; the committed goldens of the real-image cases keep instead
+  * ``crops``: 12 fixed 128x128 windows (corners, borders, centre, seeded interior positions) at full precision —
+    the per-pixel |d| <= 1e-3 gate is asserted on them;
+  * ``pool_mean`` / ``pool_max``: the mean (float64 accumulate) and max over every 8x8 block of the WHOLE frame
+    ([H/8, W/8, C] each, 0.4 MB at 1080p).  One pixel off by e anywhere moves its block mean by e/64, so the block-mean
+    gate (POOL_MEAN_TOL = 1.6e-5 = 1e-3 / 64, plus the fp32 noise floor measured ~1e-6) covers every pixel of the frame
+    against a single-pixel deviation above 1e-3, and pool_max bounds the per-block peak directly.
+Used by oracle/make_golden_bocchi.py (writer) and tests/test_*bocchi* (readers).
+"""
+import numpy as np
+
+CROP = 128
+POOL = 8
+POOL_MEAN_TOL = 1.6e-5 + 2e-6
+POOL_MAX_TOL = 1e-3
+
+
+def crop_positions(h, w, n_random=3, seed=20260924):
+    """(y, x) top-left corners: 4 corners, 4 border midpoints, centre, n_random seeded interior positions."""
+    c = CROP
+    ys, xs = h - c, w - c
+    pos = [(0, 0), (0, xs), (ys, 0), (ys, xs), (0, xs // 2), (ys, xs // 2), (ys // 2, 0), (ys // 2, xs), (ys // 2, xs // 2)]
+    rng = np.random.RandomState(seed)
+    for _ in range(n_random):
+        pos.append((int(rng.randint(0, ys + 1)), int(rng.randint(0, xs + 1))))
+    return pos
+
+
+def fingerprint(frame):
+    """frame: [H,W,C] float32 numpy -> dict(crops [K,128,128,C], crop_pos [K,2], pool_mean, pool_max)."""
+    frame = np.asarray(frame, dtype=np.float32)
+    h, w, c = frame.shape
+    pos = crop_positions(h, w)
+    crops = np.stack([frame[y:y + CROP, x:x + CROP] for (y, x) in pos])
+    hb, wb = h // POOL, w // POOL
+    blocks = frame[:hb * POOL, :wb * POOL].reshape(hb, POOL, wb, POOL, c)
+    return {
+        "crops": crops,
+        "crop_pos": np.asarray(pos, dtype=np.int32),
+        "pool_mean": blocks.astype(np.float64).mean(axis=(1, 3)).astype(np.float32),
+        "pool_max": blocks.max(axis=(1, 3)),
+    }
+
+
+def check(frame, fp, tol=1e-3, name=""):
+    """Assert that ``frame`` matches fingerprint ``fp``; returns (crop max|d|, pool-mean max|d|, pool-max max|d|)."""
+    frame = np.asarray(frame, dtype=np.float32)
+    got = fingerprint(frame)
+    assert np.array_equal(got["crop_pos"], fp["crop_pos"]), "fingerprint layout changed"
+    d_crop = float(np.abs(got["crops"] - fp["crops"]).max())
+    d_mean = float(np.abs(got["pool_mean"].astype(np.float64) - fp["pool_mean"]).max())
+    d_max = float(np.abs(got["pool_max"] - fp["pool_max"]).max())
+    msg = f"{name}: crops max|d|={d_crop:.3e} (tol {tol:g}), 8x8 block mean max|d|={d_mean:.3e} (tol {POOL_MEAN_TOL:g}), block max max|d|={d_max:.3e}"
+    assert d_crop <= tol, msg
+    assert d_mean <= POOL_MEAN_TOL, msg
+    assert d_max <= POOL_MAX_TOL, msg
+    return d_crop, d_mean, d_max

@@ -306,3 +306,37 @@ def test_ifunet_spec_table():
     assert len(sh) == 608 and sh["flownet.block0.maskconvx16.weight"] == (2304, 256, 1, 1) and sh["refinenet.block1.conv0.0.0.weight"] == (64, 12, 3, 3)
     sd = synth.ifunet_synth_state_dict(2)
     assert all(tuple(sd[k].shape) == tuple(v) for k, v in sh.items())
+
+
+# ---- real-image 1080p goldens (oracle/make_golden_bocchi.py): the oracle against the REAL reference node's fingerprints ------
+def _bocchi(golden_dir):
+    import numpy as np
+
+    u8 = np.load(os.path.join(golden_dir, "bocchi_pair_u8.npz"))["frames_u8"]
+    return torch.from_numpy(u8.astype(np.float32) / 255.0)
+
+
+@pytest.mark.parametrize("tag,m,k", [("default", 2, 1), ("hot", 4, 1)])
+def test_rife_oracle_vs_reference_node_bocchi_1080p(golden_dir, tag, m, k):
+    import numpy as np
+
+    from oracle import golden_stats, rife_oracle
+
+    sd = synth.rife47_synth_state_dict(1234) if tag == "default" else synth.rife47_hot_state_dict(1234)
+    out = rife_oracle.rife_vfi(sd, _bocchi(golden_dir), multiplier=m)
+    npz = np.load(os.path.join(golden_dir, "rife47_bocchi1080.npz"))
+    fp = {f: npz[f"{tag}_x{m}_{k}/{f}"] for f in ("crops", "crop_pos", "pool_mean", "pool_max")}
+    d = golden_stats.check(out[k].numpy(), fp, tol=0.0, name=f"oracle vs reference node, RIFE 4.7 {tag} x{m}")
+    assert d[0] == 0.0 and d[2] == 0.0          # bit-exact on the crops and the block maxima
+
+
+def test_m2m_oracle_vs_reference_node_bocchi_1080p(golden_dir):
+    import numpy as np
+
+    from oracle import golden_stats, m2m_model_oracle
+
+    out = m2m_model_oracle.m2m_vfi(synth.m2m_synth_state_dict(1234), _bocchi(golden_dir), multiplier=2)
+    npz = np.load(os.path.join(golden_dir, "m2m_bocchi1080.npz"))
+    fp = {f: npz[f"default_x2_1/{f}"] for f in ("crops", "crop_pos", "pool_mean", "pool_max")}
+    d = golden_stats.check(out[1].numpy(), fp, tol=0.0, name="oracle vs reference node, M2M default x2")
+    assert d[0] == 0.0 and d[2] == 0.0
