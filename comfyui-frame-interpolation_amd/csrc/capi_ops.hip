@@ -101,6 +101,8 @@ int vfi_conv3x3(const float* in_dev, const float* weight_host, const float* bias
     return 0;
 }
 
+int vfi_test_conv_algo(int mode) { return conv_wino_mode(mode); }
+
 int64_t vfi_test_pack_wino3x3(const float* weight_host, int Cout, int Cin, const int* chan_map, int Cin_p, float* out_host, int64_t cap) {
     if (!weight_host || !out_host || Cout <= 0 || Cin <= 0 || Cin_p % 8 || Cin_p < Cin) {
         set_error("vfi_test_pack_wino3x3: bad arguments");

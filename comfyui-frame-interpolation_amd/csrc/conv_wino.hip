@@ -57,7 +57,8 @@ struct WinoGeom {
     static constexpr int A_FLOATS = NA * 256;
     static constexpr int B_FLOATS = 16 * 256;
     static constexpr int BUF_FLOATS = 4 * A_FLOATS + B_FLOATS;
-    static constexpr int LDS_BYTES = 2 * BUF_FLOATS * 4;
+    static constexpr int TAB_FLOATS = 4 * NA * 64;       // per wave: the DMA cursor's NA byte offsets per lane (kept in LDS, not in VGPRs)
+    static constexpr int LDS_BYTES = (2 * BUF_FLOATS + TAB_FLOATS) * 4;
     static_assert(NITEM % 4 == 0 && PW % 2 == 0, "swizzle stays inside the image and inside a row");
 };
 
@@ -85,15 +86,12 @@ __device__ __forceinline__ void wino_epilogue(const f32x16 (&acc)[16], const Con
     const bool has_res = MODE >= 10 && a.res != nullptr;
     const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(has_res ? a.res + (size_t)n * H * W * a.res_cs : a.out), 0, has_res ? H * W * a.res_cs * 4 : 0, 0x00020000);
-    constexpr int NXO = RTX == 8 ? 8 : 16;      // distinct x positions a lane stores to: 8 * half + 0..7 (+ 16 for the second tile row group)
-    int xoff[NXO], xres[NXO];
-#pragma unroll
-    for (int i = 0; i < NXO; ++i) {
-        const int xx = (i >> 3) * 16 + 8 * half + (i & 7);
-        const bool ok = ox0 + xx < W && co < a.Cout;
-        xoff[i] = ok ? ((ox0 + xx) * a.out_cs + co) * 4 : (int)0x80000000;
-        xres[i] = ok ? ((ox0 + xx) * a.res_cs + co) * 4 : (int)0x80000000;
-    }
+    const int xlane = ox0 + 8 * half;          // this lane's first output column; + xq per store
+    const bool cok = co < a.Cout;
+    const bool interior = ox0 + 2 * RTX <= W;  // every column of the region is inside the image (wave-uniform)
+    // lane part of the byte offsets in a VGPR (0x80000000 = dropped by the descriptor's range check), per-store part scalar
+    const int lane_o = cok ? (xlane * a.out_cs + co) * 4 : (int)0x80000000;
+    const int lane_r = cok ? (xlane * a.res_cs + co) * 4 : (int)0x80000000;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m0 = 8 * (r >> 2) + (r & 3);          // tile index without the lane's half (added through xoff)
@@ -117,12 +115,13 @@ __device__ __forceinline__ void wino_epilogue(const f32x16 (&acc)[16], const Con
                 const int rowo = oy * W * a.out_cs * 4, rowr = oy * W * a.res_cs * 4;
 #pragma unroll
                 for (int ex = 0; ex < 2; ++ex) {
-                    const int xi = (txx0 >> 3) * 8 + 2 * (txx0 & 7) + ex;      // index into xoff: xx = 2 * txx + ex, txx = txx0 + 4 * half
+                    const int xq = (txx0 >> 3) * 16 + 2 * (txx0 & 7) + ex;     // column inside the region = xq + 8 * half (txx = txx0 + 4 * half)
+                    const bool ok = interior || xlane + xq < W;
                     float v = (y[ey * 2 + ex] + bs) * bt;
                     if (MODE == 0) {
                         v = fmaxf(v, v * uslope);
                     } else {
-                        if (has_res) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrsrc, xres[xi] + rowr, 0, 0));
+                        if (has_res) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrsrc, ok ? lane_r : (int)0x80000000, rowr + xq * a.res_cs * 4, 0));
                         if (MODE == 11) v = v > 0.f ? v : v * a.slope;
                         else if (MODE == 12) v = fminf(fmaxf(v, 0.f), 1.f);
                         else if (MODE == 13) v = v > 0.f ? v : v * pre;
@@ -130,7 +129,7 @@ __device__ __forceinline__ void wino_epilogue(const f32x16 (&acc)[16], const Con
                         else if (MODE == 15) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
                         v = v * ps + sh;
                     }
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orsrc, xoff[xi] + rowo, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orsrc, ok ? lane_o : (int)0x80000000, rowo + xq * a.out_cs * 4, 0);
                 }
             }
         }
@@ -138,7 +137,9 @@ __device__ __forceinline__ void wino_epilogue(const f32x16 (&acc)[16], const Con
     }
 }
 
-template <int RTX, bool EXT>
+// ABL: compile-time ablations for timing experiments only (results become wrong): 1 no activation DMA, 2 no weight DMA, 4 no epilogue,
+// 8 no chunk barrier, 16 no input transform, 32 no B-fragment reads, 64 no patch reads.  The product kernels are ABL = 0.
+template <int RTX, bool EXT, int ABL = 0>
 __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using G = WinoGeom<RTX>;
@@ -150,9 +151,16 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    const int ty = l31 / RTX, tx = l31 % RTX;
     const int C8 = a.Cin_p >> 3;
     const int H = a.Hin, W = a.Win;
+    // Lane-derived address pieces are cheap to recompute and expensive to keep: 256 AGPRs hold the accumulators, the 256 VGPRs are
+    // for the patch / operands.  LICM would hoist every lane-only expression out of the loops and then SPILL it (a scratch reload in
+    // the hot loop waits vmcnt(0), i.e. for the LDS-DMA in flight): an opaque copy of the lane id per use keeps them local.
+    auto opaque_lane = [&]() {
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        return l;
+    };
     const int img_floats = H * W * a.in_cs;
 
     // ---- work order -----------------------------------------------------------------------------------------------------
@@ -189,59 +197,68 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
     };
 
     // ---- activation DMA: per lane and piece, the (py, px, q) it fetches (kernel constants), then per region the byte offsets
-    int pcode[NA];
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int sp = i * 64 + lane;                    // swizzled slot = where the DMA puts this lane's 16 bytes
-        const int py = (sp >> 1) / PW;
-        const int s = sp ^ wino_key(py);
-        const int pix = s >> 1;
-        pcode[i] = sp < G::NITEM ? ((py << 16) | ((pix - py * PW) << 1) | (s & 1)) : -1;
-    }
-    auto make_avoff = [&](const Cur& c, int(&avoff)[NA]) {
+    // The cursor's per-lane byte offsets live in a per-wave LDS table: six more registers held through the loop were six scratch
+    // reloads per chunk (each behind s_waitcnt vmcnt(0), i.e. behind the LDS-DMA in flight).
+    int* const avtab = (int*)(smem + 2 * G::BUF_FLOATS) + wave * (NA * 64);
+    auto make_avoff = [&](const Cur& c) {
+        const int ol = opaque_lane();
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int code = pcode[i];
-            const int iy = c.Ry0 - 1 + (code >> 16), ix = c.Rx0 - 1 + ((code >> 1) & 0x7fff);
+            const int sp = i * 64 + ol;                      // swizzled slot = where the DMA puts this lane's 16 bytes
+            const int py = (sp >> 1) / PW;
+            const int sl = sp ^ wino_key(py);
+            const int code = sp < G::NITEM ? (sl & 1) : -1;
+            const int iy = c.Ry0 - 1 + py, ix = c.Rx0 - 1 + ((sl >> 1) - py * PW);
             const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);       // replicate padding = edge clamp
             const bool ok = code >= 0 && c.valid && (a.pad_replicate || (cy == iy && cx == ix));
-            avoff[i] = ok ? ((cy * W + cx) * a.in_cs + (code & 1) * 4) * 4 : (int)0x80000000;
+            avtab[i * 64 + ol] = ok ? ((cy * W + cx) * a.in_cs + (code & 1) * 4) * 4 : (int)0x80000000;
         }
     };
     auto make_rsrc = [&](int n) {
         return __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)n * img_floats), 0, img_floats * 4, 0x00020000);
     };
-    auto issue = [&](const __amdgpu_buffer_rsrc_t& rsrc, const int(&avoff)[NA], int nb, int k, int buf) {
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 16 * a.Cin_p * a.Cout_p * 4, 0x00020000);
+    auto issue = [&](const __amdgpu_buffer_rsrc_t& rsrc, int nb, int k, int buf) {
         float* abuf = smem + buf * G::BUF_FLOATS + wave * G::A_FLOATS;
         float* bbuf = smem + buf * G::BUF_FLOATS + 4 * G::A_FLOATS;
+        if (!(ABL & 1)) {
+            const int ol = opaque_lane();
+            int avoff[NA];
 #pragma unroll
-        for (int i = 0; i < NA; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(abuf + i * 256), 16, avoff[i] + k * 32, 0, 0, 0);
-        const float* wb = a.w + ((size_t)(nb * C8 + k) * 16) * 256 + lane * 4;
+            for (int i = 0; i < NA; ++i) avoff[i] = avtab[i * 64 + ol];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int piece = wave + 4 * i;
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(wb + piece * 256), (lds_ptr_t)(bbuf + piece * 256), 16, 0, 0);
+            for (int i = 0; i < NA; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(abuf + i * 256), 16, avoff[i], k * 32, 0, 0);
+        }
+        if (!(ABL & 2)) {
+            const int wbase = (nb * C8 + k) * (16 * 1024);      // bytes: 16 pieces of 1 KiB per (channel block, chunk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int piece = wave + 4 * i;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)(bbuf + piece * 256), 16, lane * 16, wbase + piece * 1024, 0, 0);
+            }
         }
     };
 
     // ---- patch read offsets (floats inside the wave's A image): 4 lane-dependent bases + compile-time (dy, dx) offsets
-    int pb[4];   // index (dx & 1) * 2 + (dy >> 1)
-    {
-        const int base = (2 * ty * PW + 2 * tx) * 2;     // multiple of 4
-#pragma unroll
-        for (int dxp = 0; dxp < 2; ++dxp)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) pb[dxp * 2 + kk] = (base + ((half + 2 * dxp) ^ ((ty + kk) & 3))) * 4;
-    }
-
     f32x4 P[16];
     f32x4 Bc[4], Bn[4];
     float Vc[16], Vn[16];
     f32x16 acc[16];
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
+    // patch read offsets (floats inside the wave's A image): 4 lane-dependent bases (index (dx & 1) * 2 + (dy >> 1), recomputed per
+    // chunk: cheaper than four registers held through the loop) + compile-time (dy, dx) offsets
     auto read_patch = [&](int buf) {
         const float* sA = smem + buf * G::BUF_FLOATS + wave * G::A_FLOATS;
+        const int ol = opaque_lane();
+        const int half = ol >> 5, ty = (ol & 31) / RTX, tx = (ol & 31) % RTX;
+        const int base = (2 * ty * PW + 2 * tx) * 2;     // multiple of 4
+        int pb[4];
+#pragma unroll
+        for (int dxp = 0; dxp < 2; ++dxp)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) pb[dxp * 2 + kk] = (base + ((half + 2 * dxp) ^ ((ty + kk) & 3))) * 4;
 #pragma unroll
         for (int dy = 0; dy < 4; ++dy)
 #pragma unroll
@@ -259,25 +276,25 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
     int d_it = 0, d_k = 0;
     bool d_ok = item(0, dcur);
     if (!d_ok) return;
-    int davoff[NA];
-    make_avoff(dcur, davoff);
+    make_avoff(dcur);
     __amdgpu_buffer_rsrc_t drsrc = make_rsrc(dcur.n);
     auto dma_issue = [&](int buf) {      // the cursor's chunk into `buf`
-        if (d_ok) issue(drsrc, davoff, dcur.nb, d_k, buf);
+        if (d_ok) issue(drsrc, dcur.nb, d_k, buf);
     };
     auto dma_advance = [&]() {
         if (d_ok && ++d_k == C8) {
             d_k = 0;
             d_ok = item(++d_it, dcur);
             if (d_ok) {
-                make_avoff(dcur, davoff);
+                make_avoff(dcur);
                 drsrc = make_rsrc(dcur.n);
             }
         }
     };
     dma_issue(0);
     dma_advance();
-    __syncthreads();     // (s_waitcnt vmcnt(0) + barrier: chunk 0 of every wave has landed)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();     // chunk 0 of every wave has landed
     dma_issue(1);
     dma_advance();
     read_patch(0);
@@ -305,18 +322,20 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
     // its transform (channel JN of the patch in registers) runs behind groups 2 and 3 — at a chunk boundary that leaves the
     // freshly requested patch two MFMA groups to arrive.  sched_barrier(0) pins the groups (left alone hipcc clusters the VALU in
     // front of the MFMAs); PRE is extra work issued behind group 0 / 1 (the chunk DMA at a boundary).
-#define WINO_SUBSTEP(JN, NEXTBUF, PRE0, PRE1)                                                                       \
+#define WINO_SUBSTEP(JN, NEXTBUF, PRE0, PRE1, FIRST)                                                                       \
     {                                                                                                               \
         float t_[16];                                                                                               \
         _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                          \
             __builtin_amdgcn_sched_barrier(0);                                                                      \
             _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_)                                                        \
-                acc[g_ * 4 + e_] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vc[g_ * 4 + e_], Bc[g_][e_], acc[g_ * 4 + e_], 0, 0, 0); \
+                acc[g_ * 4 + e_] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vc[g_ * 4 + e_], Bc[g_][e_], FIRST ? zero16 : acc[g_ * 4 + e_], 0, 0, 0); \
             if (g_ == 0) {                                                                                          \
-                read_b(NEXTBUF, JN, Bn);                                                                            \
+                if (!(ABL & 32)) read_b(NEXTBUF, JN, Bn);                                                           \
                 PRE0;                                                                                               \
             } else if (g_ == 1) {                                                                                   \
                 PRE1;                                                                                               \
+            } else if (ABL & 16) {                                                                                  \
+                if (g_ == 2) { _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) Vn[i_] = P[i_][JN]; }              \
             } else if (g_ == 2) {                                                                                   \
                 _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) {                                                  \
                     const float d0 = P[c_][JN], d1 = P[4 + c_][JN], d2 = P[8 + c_][JN], d3 = P[12 + c_][JN];        \
@@ -333,7 +352,7 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
                     Vn[r_ * 4 + 3] = t_[r_ * 4 + 1] - t_[r_ * 4 + 3];                                               \
                 }                                                                                                   \
             }                                                                                                       \
-            if (g_ >= 2) { /* 16 VALU of the transform: 4 behind each MFMA, not 16 behind the first */               \
+            if (g_ >= 2 && !(ABL & 16)) { /* 16 VALU of the transform: 4 behind each MFMA, not 16 behind the first */               \
                 _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                                  \
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                              \
                     __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                              \
@@ -356,25 +375,30 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
         bool more = true;                // a chunk follows the current one in this workgroup's stream
         for (int k = 0; k < C8; ++k, ++gchunk) {
             const int buf = gchunk & 1;
-            WINO_SUBSTEP(1, buf, (void)0, (void)0);
-            WINO_SUBSTEP(2, buf, (void)0, (void)0);
-            WINO_SUBSTEP(3, buf, (void)0, (void)0);
+            WINO_SUBSTEP(1, buf, (void)0, (void)0, false);
+            WINO_SUBSTEP(2, buf, (void)0, (void)0, false);
+            WINO_SUBSTEP(3, buf, (void)0, (void)0, false);
             // chunk boundary: every wave has pulled chunk k into registers; chunk k+1 has landed (vmcnt(0) in the barrier)
-            __syncthreads();
+            // vmcnt(0) spelled out: hipcc does not know that the LDS-DMA feeds the ds_reads below and may leave DMA pieces in
+            // flight across the barrier (it emitted vmcnt(2) here)
+            if (!(ABL & 8)) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
             // does a chunk follow in this workgroup's stream?  Inside the item always; at its end iff the NEXT item exists (the
             // DMA cursor is two chunks ahead, so its state does not say: ask the work order)
             if (k + 1 == C8) {
                 Cur tmp;
                 more = item(it + 1, tmp);
             }
-            if (more) read_patch(buf ^ 1);
+            if (more && !(ABL & 64)) read_patch(buf ^ 1);
             // last 16 MFMAs of chunk k; underneath: chunk gchunk + 2 into the buffer just released, B fragments and transform
             // of (k + 1, j = 0)
-            WINO_SUBSTEP(0, buf ^ 1, dma_issue(buf), dma_advance());
+            WINO_SUBSTEP(0, buf ^ 1, dma_issue(buf), dma_advance(), false);
         }
 
         // ---- epilogue: Y = A^T M A per tile in registers, + bias, * beta, (+ residual), activation, NHWC store
-        if (ccur.valid) {
+        if (ccur.valid && !(ABL & 4)) {
             const int co = ccur.nb * 32 + l31;
             const int coc = co < a.Cout ? co : a.Cout - 1;
             if (!EXT) {
@@ -420,12 +444,18 @@ void pack_wino3x3(const float* w_oihw, int Cout, int Cin, const int* chan_map, i
         }
 }
 
-static bool wino_env_enabled() {
-    static const bool on = [] {
-        const char* e = getenv("VFI_CONV_WINOGRAD");     // experiment hook: VFI_CONV_WINOGRAD=0 keeps every 3x3 on the direct kernel
-        return !(e && e[0] == '0');
-    }();
-    return on;
+// 0 = automatic (VFI_CONV_WINOGRAD=0 in the environment keeps every 3x3 on the direct kernel), 1 = direct kernel only,
+// 2 = Winograd wherever the layer shape allows it (test hook vfi_test_conv_algo: both forms of one layer object on one input)
+static std::atomic<int> g_wino_mode{-1};
+int conv_wino_mode(int set) {
+    if (set >= 0) g_wino_mode.store(set, std::memory_order_relaxed);
+    int m = g_wino_mode.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char* e = getenv("VFI_CONV_WINOGRAD");
+        m = (e && e[0] == '0') ? 1 : ((e && e[0] == '2') ? 2 : 0);
+        g_wino_mode.store(m, std::memory_order_relaxed);
+    }
+    return m;
 }
 
 static int wino_cus(int dev) {
@@ -443,15 +473,18 @@ static int wino_cus(int dev) {
 // Is the Winograd kernel the better choice for this layer on this launch?  (3x3 stride 1 only; enough work items to fill the
 // chip — coarse pyramid levels with long K stay on the direct kernel's split-K path.)
 bool conv_wino_eligible(const ConvArgs& a) {
-    if (!wino_env_enabled()) return false;
+    const int mode = conv_wino_mode(-1);
+    if (mode == 1) return false;
     if (a.ntaps != 9 || a.Hout != a.Hin || a.Wout != a.Win || a.in_plane || a.out_mode != 0) return false;
     if (a.Cin_p % 8 || a.Cout_p % 32) return false;
-    if ((long)a.Hin * a.Win * a.in_cs * 4 >= 0x7fffffffL) return false;
+    if ((long)a.Hin * a.Win * a.in_cs * 4 >= 0x7fffffffL || (long)a.Hin * a.Win * a.out_cs * 4 >= 0x7fffffffL) return false;
+    if (a.res && (long)a.Hin * a.Win * a.res_cs * 4 >= 0x7fffffffL) return false;
+    if (mode == 2) return true;
     const long regions = (long)a.N * cdiv(a.Hin, 8) * cdiv(a.Win, 16);
     return regions / 4 * (a.Cout_p / 32) >= 192;
 }
 
-template <int RTX, bool EXT>
+template <int RTX, bool EXT, int ABL = 0>
 static int wino_launch_t(WinoArgs& p, hipStream_t s, const char* name) {
     using G = WinoGeom<RTX>;
     ConvArgs& a = p.a;
@@ -465,7 +498,7 @@ static int wino_launch_t(WinoArgs& p, hipStream_t s, const char* name) {
     VFI_REQUIRE(dev >= 0 && dev < kMaxDevices, "conv_wino %s: device index %d out of range", name, dev);
     static std::atomic<int> attr_set[kMaxDevices];
     if (!attr_set[dev].load(std::memory_order_acquire)) {
-        VFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<RTX, EXT>),
+        VFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<RTX, EXT, ABL>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
         attr_set[dev].store(1, std::memory_order_release);
     }
@@ -475,7 +508,7 @@ static int wino_launch_t(WinoArgs& p, hipStream_t s, const char* name) {
     grid = round_up(grid, 8);
     p.xcd_map = 1;
     TraceScope ts(name, s);
-    hipLaunchKernelGGL((conv_wino_kernel<RTX, EXT>), dim3(grid), dim3(256), G::LDS_BYTES, s, p);
+    hipLaunchKernelGGL((conv_wino_kernel<RTX, EXT, ABL>), dim3(grid), dim3(256), G::LDS_BYTES, s, p);
     VFI_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -503,6 +536,14 @@ int conv_wino_launch(const ConvArgs& a, int variant, hipStream_t s, const char* 
     // the hot epilogue: no residual, no post affine, none / LeakyReLU with a slope in [0,1]
     const bool ext = a.res != nullptr || a.post_scale != 0.f || !(a.act == 0 || (a.act == 1 && a.slope >= 0.f && a.slope <= 1.f));
     if (variant == 16) return ext ? wino_launch_t<16, true>(p, s, name) : wino_launch_t<16, false>(p, s, name);
+    if (!ext) {     // timing experiments: VFI_WINO_ABLATE selects a compile-time ablated copy of the hot kernel (see ABL above)
+        static const int abl = [] { const char* e = getenv("VFI_WINO_ABLATE"); return e ? atoi(e) : 0; }();
+        if (abl == 1) return wino_launch_t<8, false, 1>(p, s, name);
+        if (abl == 4) return wino_launch_t<8, false, 4>(p, s, name);
+        if (abl == 15) return wino_launch_t<8, false, 15>(p, s, name);
+        if (abl == 31) return wino_launch_t<8, false, 31>(p, s, name);
+        if (abl == 127) return wino_launch_t<8, false, 127>(p, s, name);
+    }
     return ext ? wino_launch_t<8, true>(p, s, name) : wino_launch_t<8, false>(p, s, name);
 }
 

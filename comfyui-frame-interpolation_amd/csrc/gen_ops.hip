@@ -154,6 +154,7 @@ using namespace vfi;
 
 struct vfi_conv {
     float* w = nullptr;
+    float* ww = nullptr;     // Winograd F(2x2,3x3) pack of a 3x3 stride-1 layer (conv_wino.hip), next to the direct kernel's
     float* bias = nullptr;
     float* prelu = nullptr;  // per-channel PReLU slopes [Cout_p] (optional)
     int Cout = 0, Cout_p = 0, Cin = 0, Cin_p = 0, kh = 0, kw = 0, taps = 0;
@@ -202,12 +203,23 @@ vfi_conv_t* vfi_conv_create(const float* w_oihw_host, const float* bias_host, in
         vfi_conv_destroy(c);
         return nullptr;
     }
+    if (kh == 3) {
+        std::vector<float> ww;
+        pack_wino3x3(w_oihw_host, Cout, Cin, chan_map, Cin_phys, c->Cout_p, ww);
+        if (hipMalloc((void**)&c->ww, ww.size() * sizeof(float)) != hipSuccess ||
+            hipMemcpy(c->ww, ww.data(), ww.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+            set_error("vfi_conv_create: device allocation/upload failed (Winograd pack)");
+            vfi_conv_destroy(c);
+            return nullptr;
+        }
+    }
     return c;
 }
 
 void vfi_conv_destroy(vfi_conv_t* c) {
     if (!c) return;
     if (c->w) (void)hipFree(c->w);
+    if (c->ww) (void)hipFree(c->ww);
     if (c->bias) (void)hipFree(c->bias);
     if (c->prelu) (void)hipFree(c->prelu);
     delete c;
@@ -265,6 +277,11 @@ vfi_conv_t* vfi_conv_create_ex(int kind, const float* w_host, const float* bias_
         for (int g = 0; g < ngrp; ++g)
             for (int co = 0; co < Cout; ++co) bp[(size_t)g * c->Cout_p + co] = bias_host[co];
     bool ok = upload(&c->w, wp) && upload(&c->bias, bp);
+    if (ok && kind == 0 && k == 3 && stride == 1) {
+        std::vector<float> ww;
+        pack_wino3x3(w_host, Cout, Cin, chan_map, Cin_phys, c->Cout_p, ww);
+        ok = upload(&c->ww, ww);
+    }
     if (ok && prelu_host) {
         std::vector<float> pp(c->Cout_p, 0.f);
         for (int co = 0; co < Cout; ++co) pp[co] = prelu_host[co];
@@ -328,6 +345,10 @@ int vfi_conv_forward_ex(const vfi_conv_t* c, const float* in_dev, int in_cs, int
     static std::map<std::string, const char*> names;
     auto it = names.find(name);
     if (it == names.end()) it = names.emplace(name, strdup(name)).first;
+    if (c->ww && c->kind == 0 && c->stride == 1 && conv_wino_eligible(a)) {
+        a.w = c->ww;
+        return conv_wino_launch(a, 0, (hipStream_t)stream, it->second);
+    }
     return conv_launch(a, c->kind == 1 ? 1 : c->stride, c->kind == 1, -1, (hipStream_t)stream, it->second);
 }
 
@@ -362,6 +383,10 @@ int vfi_conv_forward(const vfi_conv_t* c, const float* in_dev, int in_cs, float*
     static std::map<std::string, const char*> names;  // stable storage for trace names
     auto it = names.find(name);
     if (it == names.end()) it = names.emplace(name, strdup(name)).first;
+    if (c->ww && conv_wino_eligible(a)) {
+        a.w = c->ww;
+        return conv_wino_launch(a, 0, (hipStream_t)stream, it->second);
+    }
     return conv_launch(a, 1, false, -1, (hipStream_t)stream, it->second);
 }
 

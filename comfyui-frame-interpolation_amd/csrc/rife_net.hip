@@ -68,7 +68,7 @@ int upload(DevBuf& b, const std::vector<float>& h) {
 }
 
 struct ConvLayer {
-    DevBuf w, bias, beta;
+    DevBuf w, ww, bias, beta;   // ww: Winograd F(2x2,3x3) pack (3x3 stride-1 layers: the ResConvs and the 4.17 / 4.26 head)
     int Cin = 0, Cin_p = 0, Cout = 0, Cout_p = 0;
     bool folded = false;  // residual folded into the centre tap (ResConv)
 };
@@ -130,7 +130,7 @@ static int bind_arena(vfi_rife* net, const std::vector<WeightView>& views, size_
 }
 
 static int make_conv3x3(ConvLayer& L, const float* w, const float* b, const float* beta, int Cout, int Cin,
-                        int Cin_p) {
+                        int Cin_p, bool wino = false) {
     L.Cin = Cin;
     L.Cin_p = Cin_p;
     L.Cout = Cout;
@@ -153,6 +153,11 @@ static int make_conv3x3(ConvLayer& L, const float* w, const float* b, const floa
     }
     pack_conv3x3(w, b, Cout, Cin, Cin_p, L.Cout_p, wp, bp);
     if (upload(L.w, wp) || upload(L.bias, bp)) return -1;
+    if (wino) {
+        std::vector<float> wq;
+        pack_wino3x3(w, Cout, Cin, nullptr, Cin_p, L.Cout_p, wq);
+        if (upload(L.ww, wq)) return -1;
+    }
     if (beta) {
         std::vector<float> be(L.Cout_p, 1.f);
         for (int i = 0; i < Cout; ++i) be[i] = beta[i];
@@ -217,7 +222,7 @@ vfi_rife_t* vfi_rife_create(int arch_ver_x10, const float* const* tensors, const
             const float* beta = next(c);
             w = beta ? next((int64_t)c * c * 9) : nullptr;
             bi = w ? next(c) : nullptr;
-            ok = ok && bi && !make_conv3x3(net->res[b][i], w, bi, beta, c, c, c);
+            ok = ok && bi && !make_conv3x3(net->res[b][i], w, bi, beta, c, c, c, true);
         }
         if (!ok) break;
         w = next((int64_t)c * LO * 16);
@@ -241,7 +246,7 @@ vfi_rife_t* vfi_rife_create(int arch_ver_x10, const float* const* tensors, const
         for (int m = 0; m < net->n_mid && ok; ++m) {   // Head.cnn1 / cnn2: 3x3, LeakyReLU(0.2) applied at launch
             const float* w = next((int64_t)CM * CM * 9);
             const float* bi = w ? next(CM) : nullptr;
-            ok = bi && !make_conv3x3(net->enc_mid[m], w, bi, nullptr, CM, CM, CM);
+            ok = bi && !make_conv3x3(net->enc_mid[m], w, bi, nullptr, CM, CM, CM, true);
         }
         const float* w1 = ok ? next((int64_t)CM * CF * 16) : nullptr;
         const float* b1 = w1 ? next(CF) : nullptr;
@@ -305,11 +310,13 @@ void vfi_rife_destroy(vfi_rife_t* net) {
     for (int b = 0; b < kMaxBlocks; ++b) {
         for (ConvLayer* L : {&net->conv00[b], &net->conv01[b], &net->last[b]}) {
             L->w.release();
+            L->ww.release();
             L->bias.release();
             L->beta.release();
         }
         for (int i = 0; i < 8; ++i) {
             net->res[b][i].w.release();
+            net->res[b][i].ww.release();
             net->res[b][i].bias.release();
             net->res[b][i].beta.release();
         }
@@ -318,6 +325,7 @@ void vfi_rife_destroy(vfi_rife_t* net) {
     }
     for (ConvLayer& L : net->enc_mid) {
         L.w.release();
+        L.ww.release();
         L.bias.release();
     }
     net->E2.release();
@@ -433,7 +441,12 @@ static int load_frame_impl(vfi_rife_t* net, int slot, const float* f32, const un
         conv3x3_taps(a);
         a.act = 1;
         a.slope = 0.2f;
-        if (conv_launch(a, 1, false, -1, st, "encode_mid")) return -1;
+        if (conv_wino_mode(-1) != 1 && net->enc_mid[m].ww.p) {
+            a.w = net->enc_mid[m].ww.p;
+            if (conv_wino_launch(a, 0, st, "encode_mid")) return -1;
+        } else if (conv_launch(a, 1, false, -1, st, "encode_mid")) {
+            return -1;
+        }
         std::swap(cur, nxt);
     }
     return encode_deconv_launch(cur, P, net->enc_w1.p, net->enc_b1.p, net->CM, net->CF, Hp, Wp, st);
@@ -534,7 +547,14 @@ int vfi_rife_interpolate(vfi_rife_t* net, int B, const int* slot0, const int* sl
             a.res_cs = c;
             a.act = 1;
             a.slope = 0.2f;
-            if (conv_launch(a, 1, false, -1, st, kResName[i])) return -1;
+            // Winograd F(2x2,3x3) form (conv_wino.hip) unless switched off: chosen per PROCESS, never per launch, so a frame's
+            // result does not depend on how it was batched
+            if (conv_wino_mode(-1) != 1 && net->res[i][r].ww.p) {
+                a.w = net->res[i][r].ww.p;
+                if (conv_wino_launch(a, 0, st, kResName[i])) return -1;
+            } else if (conv_launch(a, 1, false, -1, st, kResName[i])) {
+                return -1;
+            }
             std::swap(cur, nxt);
         }
         // lastconv: ConvTranspose2d(c, 24 | 52, 4, 2, 1) as 4 parity groups

@@ -114,6 +114,7 @@ void conv3x3_taps(ConvArgs& a);
 // variant 0 = pick the region shape, 8 / 16 = 16x8 / 32x4 output pixels per wave.
 void pack_wino3x3(const float* w_oihw, int Cout, int Cin, const int* chan_map, int Cin_p, int Cout_p, std::vector<float>& wp);
 bool conv_wino_eligible(const ConvArgs& a);
+int conv_wino_mode(int set);      // set < 0: query.  0 automatic, 1 direct kernel only, 2 Winograd wherever legal
 int conv_wino_launch(const ConvArgs& a, int variant, hipStream_t s, const char* trace_name);
 void deconv4x4_taps(ConvArgs& a);
 

@@ -20,6 +20,11 @@ int vfi_conv3x3_naive(const float* in_dev, const float* weight_host, const float
                       int Cout, int stride, int act, float slope, void* stream);
 
 
+/* Algorithm choice of the 3x3 stride-1 layers (layer objects and the RIFE network): 0 automatic (Winograd where the launch has
+ * enough work items), 1 direct implicit-GEMM kernel only, 2 Winograd wherever the shape allows; mode < 0 queries.  Returns the
+ * mode in force.  Lets a test run BOTH forms of one layer / network on one input. */
+int vfi_test_conv_algo(int mode);
+
 /* The Winograd F(2x2,3x3) weight pack of a 3x3 layer (csrc/conv_wino.hip: U = G g G^T, layout
  * [Cout_p/32][Cin_p/8][j][xi/4][half][co%32][xi%4], physical input channel = c8*8 + half*4 + j), written to a HOST buffer: lets the
  * CPU suite check the pack and emulate the kernel's addressing (tests/test_wino_emulation.py).  Returns floats written or < 0. */

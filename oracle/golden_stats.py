@@ -44,7 +44,7 @@ def fingerprint(frame):
     }
 
 
-def check(frame, fp, tol=1e-3, name=""):
+def check(frame, fp, tol=1e-3, name="", pool_mean_tol=POOL_MEAN_TOL):
     """Assert that ``frame`` matches fingerprint ``fp``; returns (crop max|d|, pool-mean max|d|, pool-max max|d|)."""
     frame = np.asarray(frame, dtype=np.float32)
     got = fingerprint(frame)
@@ -52,8 +52,8 @@ def check(frame, fp, tol=1e-3, name=""):
     d_crop = float(np.abs(got["crops"] - fp["crops"]).max())
     d_mean = float(np.abs(got["pool_mean"].astype(np.float64) - fp["pool_mean"]).max())
     d_max = float(np.abs(got["pool_max"] - fp["pool_max"]).max())
-    msg = f"{name}: crops max|d|={d_crop:.3e} (tol {tol:g}), 8x8 block mean max|d|={d_mean:.3e} (tol {POOL_MEAN_TOL:g}), block max max|d|={d_max:.3e}"
+    msg = f"{name}: crops max|d|={d_crop:.3e} (tol {tol:g}), 8x8 block mean max|d|={d_mean:.3e} (tol {pool_mean_tol:g}), block max max|d|={d_max:.3e}"
     assert d_crop <= tol, msg
-    assert d_mean <= POOL_MEAN_TOL, msg
+    assert d_mean <= pool_mean_tol, msg
     assert d_max <= POOL_MAX_TOL, msg
     return d_crop, d_mean, d_max

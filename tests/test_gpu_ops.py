@@ -112,6 +112,78 @@ def test_conv3x3_tiny_and_exact_tile(lib):
     _conv_case(lib, 3, 16, 16, 64, 64, 1, True, 0)     # exactly one 16x16 tile per image
 
 
+# ---- Winograd F(2x2,3x3) form of the 3x3 stride-1 convolution (csrc/conv_wino.hip): variant 100 = 16x8-pixel regions per wave,
+# 101 = 32x4.  Tolerance as for the direct kernels: fp32 round-off only (the transforms add / subtract and halve, nothing else).
+WINO = [(100, 64, 64, 2, 37, 45, True), (100, 8, 32, 1, 8, 16, False), (100, 24, 40, 3, 19, 33, False), (100, 192, 192, 1, 34, 60, True),
+        (101, 64, 64, 2, 37, 45, True), (101, 96, 96, 1, 34, 60, True), (101, 16, 128, 1, 5, 70, False), (100, 64, 64, 1, 1, 1, False),
+        (100, 128, 128, 2, 68, 120, True), (101, 128, 128, 2, 68, 120, False), (100, 64, 64, 9, 272, 480, False)]
+
+
+@pytest.mark.parametrize("variant,cin,cout,n,h,w,res", WINO)
+def test_conv3x3_winograd(lib, variant, cin, cout, n, h, w, res):
+    _conv_case(lib, n, h, w, cin, cout, 1, res, variant)
+
+
+@pytest.mark.parametrize("act,post,pad_mode,res", [(0, None, 0, False), (1, None, 0, False), (3, None, 1, False), (4, (0.8, 0.1), 0, False), (5, None, 0, False),
+                                                   (3, None, 0, True), (1, (2.0, -0.5), 1, True), (2, None, 0, False)])
+def test_layer_object_winograd_matches_direct_and_torch(lib, act, post, pad_mode, res):
+    """One vfi_conv_create_ex layer (3x3, stride 1; chan_map, channel windows, zero / replicate padding, every activation of the
+    generic epilogue, residual-before-activation, post affine) run in BOTH forms on one input (vfi_test_conv_algo) vs torch."""
+    import ctypes as C
+
+    g = torch.Generator().manual_seed(act * 10 + pad_mode)
+    n, h, w, cin, cout = 2, 27, 41, 20, 48
+    x = torch.rand(n, cin, h, w, generator=g) * 2 - 1
+    wt = (torch.rand(cout, cin, 3, 3, generator=g) * 2 - 1) / (cin * 9) ** 0.5
+    b = torch.rand(cout, generator=g) - 0.5
+    slopes = 0.1 + 0.3 * torch.rand(cout, generator=g)
+    r = torch.rand(n, cout, h, w, generator=g) - 0.5
+    xp = F.pad(x, (1, 1, 1, 1), mode="replicate" if pad_mode else "constant")
+    y = F.conv2d(xp.double(), wt.double(), b.double())
+    if res:
+        y = y + r.double()
+    if act == 1:
+        y = F.leaky_relu(y, 0.2)
+    elif act == 2:
+        y = y.clamp(0, 1)
+    elif act == 3:
+        y = torch.where(y > 0, y, y * slopes.double().view(1, -1, 1, 1))
+    elif act == 4:
+        y = torch.sigmoid(y)
+    elif act == 5:
+        y = F.gelu(y)
+    if post:
+        y = y * post[0] + post[1]
+    want = nhwc(y.float())
+    cphys = 24
+    cmap = [cphys - 1 - c for c in range(cin)]
+    xin = torch.rand(n, h, w, cphys + 8, generator=g)           # garbage in the unmapped / outer channels
+    xin[..., 4:4 + cphys][..., cmap] = x.permute(0, 2, 3, 1)
+    xin[..., 4:4 + cphys][..., [c for c in range(cphys) if c not in cmap]] = 0.0
+    xd, rd = xin.cuda(), nhwc(r).cuda().contiguous()
+    cm = (C.c_int * cin)(*cmap)
+    hnd = lib.vfi_conv_create_ex(0, wt.data_ptr(), b.data_ptr(), cout, cin, 3, 1, pad_mode, cm, cphys, slopes.data_ptr() if act == 3 else None)
+    assert hnd, "create failed"
+    outs = {}
+    try:
+        for mode in (1, 2):
+            assert lib.vfi_test_conv_algo(mode) == mode
+            out = torch.full((n, h, w, cout + 5), float("nan"), device="cuda")
+            _check(lib, lib.vfi_conv_forward_ex(hnd, xd.data_ptr() + 16, cphys + 8, h, w, out.data_ptr() + 12, cout + 5, n, act, 0.2,
+                                                post[0] if post else 0.0, post[1] if post else 0.0, rd.data_ptr() if res else None, cout, None), "conv_forward_ex")
+            torch.cuda.synchronize()
+            got = out.cpu()
+            assert torch.isnan(got[..., :3]).all() and torch.isnan(got[..., 3 + cout:]).all(), "wrote outside its channel window"
+            outs[mode] = got[..., 3:3 + cout]
+    finally:
+        lib.vfi_test_conv_algo(0)
+        lib.vfi_conv_destroy(hnd)
+    tol = 2e-5 * max(1.0, want.abs().max().item())
+    for mode, got in outs.items():
+        assert not torch.isnan(got).any(), f"mode {mode}: unwritten outputs"
+        assert (got - want).abs().max().item() <= tol, describe_diff(got, want, f"mode {mode} act {act}")
+
+
 @pytest.mark.parametrize("gvariant", [None, 12, 13, 43, 44])
 @pytest.mark.parametrize("cin,h,w", [(64, 17, 30), (192, 9, 15), (96, 34, 60)])
 def test_deconv4x4_pixelshuffle(lib, cin, h, w, gvariant, monkeypatch):
