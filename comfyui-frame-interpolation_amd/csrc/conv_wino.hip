@@ -19,7 +19,7 @@
 //     B operands of 4 MFMAs;
 //   * the output transform A^T M A runs in registers on the accumulator layout (lane = output channel, register = tile),
 //     fused with bias, beta, residual, activation and the NHWC store (32 lanes = 128 contiguous bytes per pixel);
-//   * K pipeline: 8-channel chunks, two LDS buffers, the DMA queue two chunks ahead across work-item boundaries; the patch
+//   * K pipeline: 8-channel chunks, three LDS buffers, the DMA queue two chunks ahead across work-item boundaries; the patch
 //     of chunk k+1 is read right after the chunk barrier and transformed UNDER the last 16 MFMAs of chunk k;
 //   * regions are wave-private (each wave DMA's its own halo'd patch: only the weight tile is shared by the workgroup), so
 //     image sizes quantise to 16x8 (or 32x4) pixels instead of a 4-wave tile;
@@ -44,6 +44,7 @@ struct WinoArgs {
     int NQ;         // region quads (4 regions = the 4 waves of a workgroup)
     int NY;         // Cout_p / 32
     int xcd_map;    // 1: XCD-aware work order (gridDim.x % 8 == 0)
+    float inv_NY, inv_per, inv_rx;   // 1 / NY, 1 / (rx * ry), 1 / rx: the work decode divides by multiplication (see wino_div)
 };
 
 template <int RTX>
@@ -58,7 +59,8 @@ struct WinoGeom {
     static constexpr int B_FLOATS = 16 * 256;
     static constexpr int BUF_FLOATS = 4 * A_FLOATS + B_FLOATS;
     static constexpr int TAB_FLOATS = 4 * NA * 64;       // per wave: the DMA cursor's NA byte offsets per lane (kept in LDS, not in VGPRs)
-    static constexpr int LDS_BYTES = (2 * BUF_FLOATS + TAB_FLOATS) * 4;
+    static constexpr int NBUF = 3;                       // LDS chunk buffers: the DMA queue runs two chunks ahead of the MFMAs
+    static constexpr int LDS_BYTES = (NBUF * BUF_FLOATS + TAB_FLOATS) * 4;
     static_assert(NITEM % 4 == 0 && PW % 2 == 0, "swizzle stays inside the image and inside a row");
 };
 
@@ -66,6 +68,16 @@ struct WinoGeom {
 // bits XORed by a row-pair key.  A wave's ds_read_b128 of one patch position touches tiles 2 px apart = slots 4 apart, i.e.
 // only every fourth 16-byte bank group; the key spreads the four tile rows over the four groups (conflict-free for 8x4 tiles).
 __device__ __forceinline__ int wino_key(int py) { return (py >> 1) & 3; }
+
+// n / d for 0 <= n < 2^24 with the host's 1.0f / d: float product, one fix-up step.  (hipcc's own integer division keeps a hoisted
+// reciprocal in a VGPR for the whole kernel — one more register to spill, and its reload in the per-item code sat behind
+// s_waitcnt vmcnt(0), i.e. behind all LDS-DMA in flight.)
+__device__ __forceinline__ int wino_div(int n, int d, float inv_d) {
+    int q = (int)((float)n * inv_d);
+    const int r = n - q * d;
+    q += (r >= d ? 1 : 0) - (r < 0 ? 1 : 0);
+    return __builtin_amdgcn_readfirstlane(q);      // wave-uniform by construction; tell hipcc (the float ops run on the VALU)
+}
 
 
 // Output transform + fused epilogue of one region (one wave).  acc[xi][r]: lane = output channel (l31), register r = tile
@@ -148,16 +160,15 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
+    const int lane = tid & 63;   // (prologue only: the loops take the lane id from opaque_lane())
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = lane >> 5, l31 = lane & 31;
     const int C8 = a.Cin_p >> 3;
     const int H = a.Hin, W = a.Win;
     // Lane-derived address pieces are cheap to recompute and expensive to keep: 256 AGPRs hold the accumulators, the 256 VGPRs are
     // for the patch / operands.  LICM would hoist every lane-only expression out of the loops and then SPILL it (a scratch reload in
     // the hot loop waits vmcnt(0), i.e. for the LDS-DMA in flight): an opaque copy of the lane id per use keeps them local.
     auto opaque_lane = [&]() {
-        int l = lane;
+        int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));    // lane id from the exec mask: no live register
         asm volatile("" : "+v"(l));
         return l;
     };
@@ -176,21 +187,22 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
             const int jl = slot + i * S;
             const int nqx = x < p.NQ ? (p.NQ - x + 7) >> 3 : 0;
             if (jl >= nqx * p.NY) return false;
-            quad = x + 8 * (jl / p.NY);
-            c.nb = jl % p.NY;
+            const int q = wino_div(jl, p.NY, p.inv_NY);
+            quad = x + 8 * q;
+            c.nb = jl - q * p.NY;
         } else {
-            const long idx = (long)wg + (long)i * gsz;
-            if (idx >= (long)p.NQ * p.NY) return false;
-            quad = (int)(idx / p.NY);
-            c.nb = (int)(idx % p.NY);
+            const int idx = wg + i * gsz;
+            if (idx >= p.NQ * p.NY) return false;
+            quad = wino_div(idx, p.NY, p.inv_NY);
+            c.nb = idx - quad * p.NY;
         }
         const int rg = quad * 4 + wave;
         c.valid = rg < p.R;
         const int rr = c.valid ? rg : 0;
         const int per = p.rx * p.ry;
-        c.n = rr / per;
+        c.n = wino_div(rr, per, p.inv_per);
         const int rem = rr - c.n * per;
-        const int ryi = rem / p.rx;
+        const int ryi = wino_div(rem, p.rx, p.inv_rx);
         c.Ry0 = ryi * RH;
         c.Rx0 = (rem - ryi * p.rx) * RW;
         return true;
@@ -199,7 +211,7 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
     // ---- activation DMA: per lane and piece, the (py, px, q) it fetches (kernel constants), then per region the byte offsets
     // The cursor's per-lane byte offsets live in a per-wave LDS table: six more registers held through the loop were six scratch
     // reloads per chunk (each behind s_waitcnt vmcnt(0), i.e. behind the LDS-DMA in flight).
-    int* const avtab = (int*)(smem + 2 * G::BUF_FLOATS) + wave * (NA * 64);
+    int* const avtab = (int*)(smem + G::NBUF * G::BUF_FLOATS) + wave * (NA * 64);
     auto make_avoff = [&](const Cur& c) {
         const int ol = opaque_lane();
 #pragma unroll
@@ -217,25 +229,30 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
     auto make_rsrc = [&](int n) {
         return __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)n * img_floats), 0, img_floats * 4, 0x00020000);
     };
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 16 * a.Cin_p * a.Cout_p * 4, 0x00020000);
-    auto issue = [&](const __amdgpu_buffer_rsrc_t& rsrc, int nb, int k, int buf) {
+    // One DMA piece per call, so that the chunk boundary can put ONE piece behind each MFMA (a piece costs the issuing wave tens of
+    // cycles; ten in a row idle the matrix pipe of a one-wave-per-SIMD kernel).  At the stream's tail the cursor's descriptors are
+    // null (num_records 0: zero fill, no memory traffic): the piece count per chunk — and with it the vmcnt arithmetic of the
+    // boundary — never changes, and no branch is needed.
+    auto issue_a = [&](const __amdgpu_buffer_rsrc_t& rsrc, int i, int voff, int k, int buf) {
         float* abuf = smem + buf * G::BUF_FLOATS + wave * G::A_FLOATS;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(abuf + i * 256), 16, voff, k * 32, 0, 0);
+    };
+    auto issue_b = [&](const __amdgpu_buffer_rsrc_t& rsrc, int i, int nb, int k, int buf) {
         float* bbuf = smem + buf * G::BUF_FLOATS + 4 * G::A_FLOATS;
-        if (!(ABL & 1)) {
-            const int ol = opaque_lane();
-            int avoff[NA];
+        const int piece = wave + 4 * i;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(bbuf + piece * 256), 16, opaque_lane() * 16, ((nb * C8 + k) * 16 + piece) * 1024, 0, 0);
+    };
+    auto load_avoff = [&](int(&av)[NA]) {
+        const int ol = opaque_lane();
 #pragma unroll
-            for (int i = 0; i < NA; ++i) avoff[i] = avtab[i * 64 + ol];
+        for (int i = 0; i < NA; ++i) av[i] = avtab[i * 64 + ol];
+        if (ABL & 0x380) {   // access-pattern experiments (same piece count, wrong data): 0x80 fully contiguous pieces, 0x100 / 0x200: 64 / 128
+                             // contiguous bytes per pixel (what a 16- / 32-channel activation chunk would fetch)
+            const int per = (ABL & 0x80) ? 64 : ((ABL & 0x100) ? 4 : 8);
 #pragma unroll
-            for (int i = 0; i < NA; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(abuf + i * 256), 16, avoff[i], k * 32, 0, 0);
-        }
-        if (!(ABL & 2)) {
-            const int wbase = (nb * C8 + k) * (16 * 1024);      // bytes: 16 pieces of 1 KiB per (channel block, chunk)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int piece = wave + 4 * i;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_ptr_t)(bbuf + piece * 256), 16, lane * 16, wbase + piece * 1024, 0, 0);
+            for (int i = 0; i < NA; ++i) {
+                const int first = __builtin_amdgcn_readfirstlane(av[i]) & 0x7fffffff;
+                av[i] = first + (ol / per) * a.in_cs * 4 + (ol % per) * 16;
             }
         }
     };
@@ -266,7 +283,7 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
                 P[dy * 4 + dx] = *(const f32x4*)(sA + pb[(dx & 1) * 2 + (dy >> 1)] + ((((dy * PW + dx) * 2) & ~3) * 4));
     };
     auto read_b = [&](int buf, int j, f32x4(&B)[4]) {
-        const float* sB = smem + buf * G::BUF_FLOATS + 4 * G::A_FLOATS + lane * 4;
+        const float* sB = smem + buf * G::BUF_FLOATS + 4 * G::A_FLOATS + opaque_lane() * 4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) B[q] = *(const f32x4*)(sB + (j * 4 + q) * 256);
     };
@@ -277,28 +294,43 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
     bool d_ok = item(0, dcur);
     if (!d_ok) return;
     make_avoff(dcur);
-    __amdgpu_buffer_rsrc_t drsrc = make_rsrc(dcur.n);
-    auto dma_issue = [&](int buf) {      // the cursor's chunk into `buf`
-        if (d_ok) issue(drsrc, dcur.nb, d_k, buf);
+    auto make_wrsrc = [&](bool live) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, live ? 16 * a.Cin_p * a.Cout_p * 4 : 0, 0x00020000);
+    };
+    auto make_arsrc = [&](int n, bool live) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)n * img_floats), 0, live ? img_floats * 4 : 0, 0x00020000);
+    };
+    __amdgpu_buffer_rsrc_t drsrc = make_arsrc(dcur.n, true), dwrsrc = make_wrsrc(true);
+    auto dma_issue_all = [&](int buf) {       // prologue: a whole chunk at once
+        int av[NA];
+        load_avoff(av);
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            if (!(ABL & 1)) issue_a(drsrc, i, av[i], d_k, buf);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (!(ABL & 2)) issue_b(dwrsrc, i, dcur.nb, d_k, buf);
     };
     auto dma_advance = [&]() {
         if (d_ok && ++d_k == C8) {
             d_k = 0;
             d_ok = item(++d_it, dcur);
-            if (d_ok) {
-                make_avoff(dcur);
-                drsrc = make_rsrc(dcur.n);
-            }
+            if (d_ok) make_avoff(dcur);
+            drsrc = make_arsrc(d_ok ? dcur.n : 0, d_ok);
+            dwrsrc = make_wrsrc(d_ok);
+            if (!d_ok) dcur.nb = 0;
         }
     };
-    dma_issue(0);
+    // DMA pieces a wave issues per chunk; LDS-DMA completes in order, so "chunk g+1 landed, chunk g+2 may still fly" is vmcnt(NPC)
+    constexpr int NPC = ((ABL & 1) ? 0 : NA) + ((ABL & 2) ? 0 : 4);
+    dma_issue_all(0);
     dma_advance();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();     // chunk 0 of every wave has landed
-    dma_issue(1);
+    dma_issue_all(1);
     dma_advance();
-    read_patch(0);
-    read_b(0, 0, Bc);
+    dma_issue_all(2);
+    dma_advance();
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPC) : "memory");      // chunk 0 has landed, chunks 1 and 2 stay in flight
+    __builtin_amdgcn_s_barrier();
 
 #define WINO_TRANSFORM(J, V)                                                              \
     {                                                                                     \
@@ -364,42 +396,84 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) Bc[i_] = Bn[i_];                                           \
     }
 
-    WINO_TRANSFORM(0, Vc);
+    // The sub-step that ends a chunk (its last 16 MFMAs), one step per MFMA, every step pinned: behind MFMA 0 the B fragments of
+    // the next sub-step and the cursor's byte offsets are requested; behind MFMAs 1.. ONE LDS-DMA piece each (activation pieces, then
+    // weight pieces) of chunk +3 into the buffer just released; then the cursor advance; the transform of (k + 1, j = 0) rides
+    // behind MFMAs 8 .. 15 as in the other sub-steps.
+#define WINO_BOUNDARY(NEXTBUF, RELBUF)                                                                              \
+    {                                                                                                               \
+        float t_[16];                                                                                               \
+        int av_[NA];                                                                                                \
+        _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) {                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                                      \
+            acc[e_] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vc[e_], Bc[e_ >> 2][e_ & 3], acc[e_], 0, 0, 0);          \
+            if (e_ == 0) {                                                                                          \
+                if (!(ABL & 32)) read_b(NEXTBUF, 0, Bn);                                                            \
+                load_avoff(av_);                                                                                    \
+            }                                                                                                       \
+            if (e_ >= 1 && e_ <= NA && !(ABL & 1)) issue_a(drsrc, e_ - 1, av_[e_ - 1], d_k, RELBUF);                \
+            if (e_ >= NA + 1 && e_ <= NA + 4 && !(ABL & 2)) issue_b(dwrsrc, e_ - NA - 1, dcur.nb, d_k, RELBUF);     \
+            if (e_ == 12) dma_advance();                                                                            \
+            if (!(ABL & 16)) {                                                                                      \
+                if (e_ >= 8 && e_ < 12) {                                                                           \
+                    const int c_ = e_ - 8;                                                                          \
+                    const float d0 = P[c_][0], d1 = P[4 + c_][0], d2 = P[8 + c_][0], d3 = P[12 + c_][0];            \
+                    t_[c_] = d0 - d2;                                                                               \
+                    t_[4 + c_] = d1 + d2;                                                                           \
+                    t_[8 + c_] = d2 - d1;                                                                           \
+                    t_[12 + c_] = d1 - d3;                                                                          \
+                } else if (e_ >= 12) {                                                                              \
+                    const int r_ = e_ - 12;                                                                         \
+                    Vn[r_ * 4 + 0] = t_[r_ * 4] - t_[r_ * 4 + 2];                                                   \
+                    Vn[r_ * 4 + 1] = t_[r_ * 4 + 1] + t_[r_ * 4 + 2];                                               \
+                    Vn[r_ * 4 + 2] = t_[r_ * 4 + 2] - t_[r_ * 4 + 1];                                               \
+                    Vn[r_ * 4 + 3] = t_[r_ * 4 + 1] - t_[r_ * 4 + 3];                                               \
+                }                                                                                                   \
+            } else if (e_ == 8) {                                                                                   \
+                _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) Vn[i_] = P[i_][0];                                \
+            }                                                                                                       \
+        }                                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) Vc[i_] = Vn[i_];                                          \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) Bc[i_] = Bn[i_];                                           \
+    }
 
-    int gchunk = 0;                      // chunk counter of this workgroup's stream: buffer = gchunk & 1
+    unsigned gchunk = 0;                 // chunk counter of this workgroup's stream: LDS buffer = gchunk % 3
     for (int it = 0; item(it, ccur); ++it) {
+        // An item starts from LDS: nothing but the accumulators is live across the previous item's epilogue (holding the next
+        // item's patch / operands in registers through it made hipcc spill ~100 registers per item).  Its first chunk has landed:
+        // the boundary that ended the previous item (or the prologue) waited for it.
+        read_patch((int)(gchunk % G::NBUF));
+        read_b((int)(gchunk % G::NBUF), 0, Bc);
 #pragma unroll
         for (int x = 0; x < 16; ++x)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
-        bool more = true;                // a chunk follows the current one in this workgroup's stream
+        WINO_TRANSFORM(0, Vc);
         for (int k = 0; k < C8; ++k, ++gchunk) {
-            const int buf = gchunk & 1;
+            const int buf = (int)(gchunk % G::NBUF), nbuf = (int)((gchunk + 1) % G::NBUF);
             WINO_SUBSTEP(1, buf, (void)0, (void)0, false);
             WINO_SUBSTEP(2, buf, (void)0, (void)0, false);
             WINO_SUBSTEP(3, buf, (void)0, (void)0, false);
-            // chunk boundary: every wave has pulled chunk k into registers; chunk k+1 has landed (vmcnt(0) in the barrier)
-            // vmcnt(0) spelled out: hipcc does not know that the LDS-DMA feeds the ds_reads below and may leave DMA pieces in
-            // flight across the barrier (it emitted vmcnt(2) here)
+            // Chunk boundary.  Every wave has pulled chunk k into registers (lgkmcnt(0): its LDS reads are complete) and its own
+            // pieces of chunk k+1 have landed; the pieces of chunk k+2 stay in flight (in-order completion: vmcnt(NPC)).  Spelled
+            // out with a bare s_barrier: __syncthreads() would drain vmcnt to what hipcc thinks the ds_reads need (it does not
+            // know that the LDS-DMA feeds them).
             if (!(ABL & 8)) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NPC) : "memory");
+                __builtin_amdgcn_s_barrier();
             }
-            // does a chunk follow in this workgroup's stream?  Inside the item always; at its end iff the NEXT item exists (the
-            // DMA cursor is two chunks ahead, so its state does not say: ask the work order)
-            if (k + 1 == C8) {
-                Cur tmp;
-                more = item(it + 1, tmp);
-            }
-            if (more && !(ABL & 64)) read_patch(buf ^ 1);
-            // last 16 MFMAs of chunk k; underneath: chunk gchunk + 2 into the buffer just released, B fragments and transform
+            if (k + 1 < C8 && !(ABL & 64)) read_patch(nbuf);
+            // last 16 MFMAs of chunk k; underneath: chunk gchunk + 3 into the buffer just released, B fragments and transform
             // of (k + 1, j = 0)
-            WINO_SUBSTEP(0, buf ^ 1, dma_issue(buf), dma_advance(), false);
+            WINO_BOUNDARY(nbuf, buf);
         }
 
         // ---- epilogue: Y = A^T M A per tile in registers, + bias, * beta, (+ residual), activation, NHWC store
         if (ccur.valid && !(ABL & 4)) {
-            const int co = ccur.nb * 32 + l31;
+            const int ole = opaque_lane();
+            const int half = ole >> 5;
+            const int co = ccur.nb * 32 + (ole & 31);
             const int coc = co < a.Cout ? co : a.Cout - 1;
             if (!EXT) {
                 wino_epilogue<RTX, 0>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half);
@@ -415,6 +489,8 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the tail's dummy pieces write (zeros) into this workgroup's LDS: drain before exit
+#undef WINO_BOUNDARY
 #undef WINO_SUBSTEP
 #undef WINO_TRANSFORM
 #endif
@@ -493,6 +569,8 @@ static int wino_launch_t(WinoArgs& p, hipStream_t s, const char* name) {
     p.R = a.N * p.rx * p.ry;
     p.NQ = cdiv(p.R, 4);
     p.NY = a.Cout_p / 32;
+    VFI_REQUIRE((long)p.NQ * p.NY + 2048 < (1L << 24) && p.R < (1 << 24), "conv_wino %s: too many work items for the kernel's float work decode", name);
+    p.inv_NY = 1.0f / (float)p.NY, p.inv_per = 1.0f / (float)(p.rx * p.ry), p.inv_rx = 1.0f / (float)p.rx;
     int dev = 0;
     VFI_CHECK_HIP(hipGetDevice(&dev));
     VFI_REQUIRE(dev >= 0 && dev < kMaxDevices, "conv_wino %s: device index %d out of range", name, dev);
@@ -543,6 +621,9 @@ int conv_wino_launch(const ConvArgs& a, int variant, hipStream_t s, const char* 
         if (abl == 15) return wino_launch_t<8, false, 15>(p, s, name);
         if (abl == 31) return wino_launch_t<8, false, 31>(p, s, name);
         if (abl == 127) return wino_launch_t<8, false, 127>(p, s, name);
+        if (abl == 0x80) return wino_launch_t<8, false, 0x80>(p, s, name);
+        if (abl == 0x100) return wino_launch_t<8, false, 0x100>(p, s, name);
+        if (abl == 0x200) return wino_launch_t<8, false, 0x200>(p, s, name);
     }
     return ext ? wino_launch_t<8, true>(p, s, name) : wino_launch_t<8, false>(p, s, name);
 }
