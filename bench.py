@@ -14,9 +14,14 @@ outputs written to HBM.  N>1: every rank runs its own stream (weak scaling, pair
 and the new frames are all-gathered over RCCL/xGMI, overlapped with the next step.
 
 Rank 0 prints ONE JSON line.  Extra objects:
-  roofline     — dominant kernel (block3 ResConv 3x3, 64->64 ch @272x480, fp32 MFMA): algorithmic FLOP
+  roofline     — dominant kernel (block3 ResConv 3x3, 64->64 ch @272x480, fp32 MFMA): algorithmic (direct-form) FLOP
                  per launch / average launch duration measured with HIP events on the launch stream
-                 (library-side tracing, second pass of the same K steps); peak = 157.3 TFLOP/s.
+                 (library-side tracing, second pass of the same K steps); peak = 157.3 TFLOP/s.  The kernel is the Winograd
+                 F(2x2,3x3) form (csrc/conv_wino.hip): it issues 2.25x fewer MFMA FLOP than the direct form the algorithmic
+                 count assumes, so `frac` may exceed 1; `executed` states the matrix-pipe utilisation (MFMA FLOP issued / peak).
+  roofline_hbm — the HBM-class kernels (transitions with their warps, final blend; M2M's summation splat and cost volume):
+                 algorithmic bytes per launch / HIP-event launch duration, against 8.0 TB/s spec and
+                 the 6.29 TB/s a float4 copy reaches on this chip.
   cpu_baseline — the oracle (torch-CPU restatement, bit-exact vs the reference in the build container)
                  timed on this host's cores on a bounded sample (N=1, rank 0 only); host CPU model and core count stated.
   e2e          — SURVEY 8(d) config 2, PCIe-inclusive (never `value`): a host clip [33,1080,1920,3] fp32
@@ -39,6 +44,17 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, chip table
+
+
+HBM_SPEC_TBPS = 8.0        # MI355X_MICROARCH.md: HBM3E peak (spec)
+HBM_COPY_TBPS = 6.29       # ... measured by a float4 copy on this chip (79 %)
+
+
+def hbm_entry(kernel, bytes_per_launch, ms_per_launch, launches):
+    tbps = bytes_per_launch / (ms_per_launch * 1e-3) / 1e12 if ms_per_launch else float("nan")
+    return {"kernel": kernel, "bound": "hbm", "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(ms_per_launch, 4),
+            "launches": launches, "achieved": round(tbps, 3), "unit": "TB/s", "peak": HBM_SPEC_TBPS, "frac": round(tbps / HBM_SPEC_TBPS, 4),
+            "frac_of_copy_rate": round(tbps / HBM_COPY_TBPS, 4)}
 
 
 def clip_frames(B):
@@ -170,6 +186,34 @@ def other_paths(dev, H, W):
     tr = timed(lambda: eng.render(0.5), 10)
     out["m2m"] = {"prepare_ms_per_pair": round(tp * 1e3, 3), "render_ms_per_frame": round(tr * 1e3, 3),
                   "frames_per_s_2x": round(1 / (tp + tr), 1), "frames_per_s_8x": round(7 / (tp + 7 * tr), 1)}
+    # M2M's HBM-class kernels by HIP events (one traced prepare + 4 renders): the summation splat (8 splats of [Hp,Wp,4] per
+    # launch: input 16 + flow 8 + output 16 B per pixel and splat) and the 9x9 cost volume (per level and direction: two
+    # 32-channel feature maps in, 81 channels out)
+    from cfi_amd import _lib
+    lib = _lib.load()
+    lib.vfi_trace_reset()
+    lib.vfi_trace_enable(1)
+    eng.prepare(x0, x1)
+    for _ in range(4):
+        eng.render(0.5)
+    torch.cuda.synchronize(dev)
+    lib.vfi_trace_enable(0)
+    rep = _lib.trace_report()
+    lib.vfi_trace_reset()
+    hp, wp = -(-H // 64) * 64, -(-W // 64) * 64
+    hbm = []
+    if "softsplat_sum" in rep:
+        calls, ms = rep["softsplat_sum"]
+        hbm.append(hbm_entry("softsplat_sum (M2M render: 8 summation splats [%d,%d,4] per launch, list-gather kernel)" % (hp, wp),
+                             8 * 40.0 * hp * wp, ms / calls, calls))
+    if "costvol9x9" in rep:
+        calls, ms = rep["costvol9x9"]
+        levels = [(hp >> k, wp >> k) for k in range(2, 7)]             # 272x480 ... 17x30, both directions in one launch
+        tot = sum(2 * (2 * 32 * 4 + 81 * 4) * h * w for h, w in levels)
+        e = hbm_entry("costvol9x9 (M2M prepare: 5 pyramid levels %s, 32 channels, both directions per launch; bytes and time summed over "
+                      "the levels)" % "/".join(f"{h}x{w}" for h, w in levels), tot, ms / calls * 5, calls // 5)
+        hbm.append(e)
+    out["roofline_hbm"] = hbm
     eng.close()
     return out
 
@@ -350,16 +394,40 @@ def result_line(args, world, elapsed, traced, rep, eng, collective):
     flop_per_launch = 2.0 * B * (hp // 4) * (wp // 4) * 64 * 64 * 9
     avg_ms = ms / calls if calls else float("nan")
     achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12 if calls else float("nan")
-    traffic = None
+    wino = os.environ.get("VFI_CONV_WINOGRAD", "1") != "0"
+    exec_div = 2.25 if wino else 1.0
+    # HBM traffic of the dominant kernel comes from PMC counters, which need their own rocprofv3 passes (--pmc cannot share a run
+    # with this timing): the figure is the one tools/profile_round.sh measured for THIS kernel at the recorded batch, scaled to the
+    # batch of this run, and `traffic_source` says so.  None when no measurement of the kernel in use is on file.
+    traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            traffic = tj.get(dom)
-            if traffic is not None:   # measured per launch at the batch recorded in the file; linear in the batch
-                traffic = int(traffic * B / float(tj.get("_detail", {}).get("batch", B)))
+            key = dom + ("_winograd" if wino else "")
+            if tj.get(key) is not None:   # measured per launch at the batch recorded in the file; linear in the batch
+                traffic = int(tj[key] * B / float(tj.get("_detail", {}).get("batch", B)))
+                traffic_src = f"profiles/roofline_traffic.json ({tj.get('_detail', {}).get('source', 'rocprofv3 --pmc passes')}), not measured in this run"
         except Exception:
             traffic = None
+    # HBM-class kernels of the RIFE step (algorithmic bytes per task; `full` = padded pixels): the flow F is
+    # 16 B per full-resolution pixel (read + written), a block output T 2 planes x 16 B per block-resolution pixel, a warp touches
+    # both frame packs (2 frames x (image + feature plane) x 16 B) at the pixels the next block keeps (all of them at scales 1 and 2,
+    # the centre 2x2 of every 4x4 cell at scale 4), the next block's input X is 24 channels x 4 B per pixel of its resolution
+    full = float(hp * wp)
+    hbm_bytes = {
+        "stage_trans4": ("block 0->1 transition (no previous flow): T(1/8) in, warps on 4/16 of the pixels, F out, X(1/4) out",
+                         (32 / 64 + 64 * 4 / 16 + 16 + 96 / 16) * full),
+        "stage_trans2": ("block 1->2 transition: T(1/4) + F in, warps, F out, X(1/2) out", (32 / 16 + 16 + 64 + 16 + 96 / 4) * full),
+        "trans1_conv0a": ("block 2->3 transition fused into block 3's conv0.0: T(1/2) + F in, warps, F out, A0 (32 ch at 1/2) out; X never stored",
+                          (32 / 4 + 16 + 64 + 16 + 128 / 4) * full),
+        "final_blend": ("last warp x2 + sigmoid blend + crop + clamp: T + F + image planes in, RGB frame out", (32 + 16 + 32) * full + 12.0 * H * W),
+    }
+    roofline_hbm = []
+    for name, (what, per_task) in hbm_bytes.items():
+        if name in rep and rep[name][0]:
+            c, m = rep[name]
+            roofline_hbm.append(hbm_entry(f"{name}: {what}; {B} tasks per launch", per_task * B, m / c, c))
     total_ms = sum(v[1] for v in rep.values())
     kernels = {k: {"calls": v[0], "ms": round(v[1], 3), "share": round(v[1] / total_ms, 4)} for k, v in rep.items()}
     return {
@@ -387,18 +455,29 @@ def result_line(args, world, elapsed, traced, rep, eng, collective):
             "target_frames_per_s_per_gpu": 30,
         },
         "roofline": {
-            "kernel": "conv_mfma2_kernel<s1,3x3> as resconv_c64 (block3 ResConv 64->64 @%dx%d, batch %d)" % (hp // 4, wp // 4, B),
+            "kernel": ("conv_wino_kernel<8> (Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)" if wino else "conv_mfma2_kernel<s1,3x3> (direct implicit GEMM)")
+                      + " as resconv_c64 (block3 ResConv 64->64 @%dx%d, batch %d)" % (hp // 4, wp // 4, B),
             "bound": "mfma",
             "achieved": round(achieved, 3),
             "peak": PEAK_FP32_MFMA_TFLOPS,
             "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
             "traffic": traffic,
+            "traffic_source": traffic_src,
             "launches": calls,
             "avg_launch_ms": round(avg_ms, 4),
             "flop_per_launch": flop_per_launch,
+            "flop_definition": "algorithmic = the direct form: 2 * pixels * Cin * Cout * 9",
+            "executed": {
+                "note": "MFMA FLOP the kernel issues per launch (Winograd: direct / 2.25, computed on whole 16x8-pixel regions) and the "
+                        "matrix-pipe utilisation that implies" if wino else "direct form: every algorithmic FLOP is an MFMA FLOP",
+                "flop_per_launch": flop_per_launch / exec_div,
+                "achieved": round(achieved / exec_div, 3),
+                "frac": round(achieved / exec_div / PEAK_FP32_MFMA_TFLOPS, 4),
+            },
             "traced_ms_per_step": round(traced / K * 1e3, 3),
         },
+        "roofline_hbm": roofline_hbm,
         "conv_tflops_whole_net": round(conv_flop * B * K / elapsed / 1e12, 3),
         "kernels": kernels,
     }

@@ -147,6 +147,7 @@ PROTOTYPES = {
     "vfi_comm_size": (C.c_int, [C.c_void_p]),
     "vfi_comm_broadcast": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int64, C.c_int, C.POINTER(C.c_void_p)]),
     "vfi_comm_all_gather_v": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p)]),
+    "vfi_comm_plan_all_gather": (C.c_int64, [C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int64]),
 }
 
 

@@ -18,6 +18,8 @@
 
 #include <mutex>
 
+#include <vector>
+
 #include "../../include/vfi_hip.h"
 
 namespace vfi {
@@ -73,7 +75,23 @@ struct vfi_comm {
     int n = 0;
     int devices[kMaxDevices];
     ncclComm_t comms[kMaxDevices];
+    // direct (full-mesh) all-gather: one copy stream and two events per ordered device pair, made on first use
+    hipStream_t cs[kMaxDevices][kMaxDevices] = {};
+    hipEvent_t ev_src[kMaxDevices] = {}, ev_dst[kMaxDevices] = {}, ev_done[kMaxDevices][kMaxDevices] = {};
+    bool mesh_ready = false;
 };
+
+// An error between ncclGroupStart and ncclGroupEnd must still close the group: an open group queues every later collective of
+// this thread and nothing launches any more (the next synchronize hangs).
+#define VFI_NCCL_IN_GROUP(api, expr)                                                                              \
+    do {                                                                                                            \
+        ncclResult_t _r = (expr);                                                                                   \
+        if (_r != ncclSuccess) {                                                                                    \
+            (void)(api).GroupEnd();                                                                                 \
+            ::vfi::set_error("%s failed: %s (%s:%d)", #expr, rccl().GetErrorString(_r), __FILE__, __LINE__);          \
+            return -1;                                                                                              \
+        }                                                                                                           \
+    } while (0)
 
 extern "C" {
 
@@ -84,7 +102,8 @@ vfi_comm_t* vfi_comm_create(int n_devices, const int* devices) {
     }
     const RcclApi& api = rccl();
     if (!api.ok) {
-        set_error("vfi_comm_create: RCCL not available (dlopen librccl.so.1: %s)", api.handle ? "missing symbols" : dlerror());
+        const char* why = api.handle ? "missing symbols" : dlerror();
+        set_error("vfi_comm_create: RCCL not available (dlopen librccl.so.1: %s)", why ? why : "unknown error");
         return nullptr;
     }
     int visible = 0;
@@ -118,6 +137,20 @@ vfi_comm_t* vfi_comm_create(int n_devices, const int* devices) {
 void vfi_comm_destroy(vfi_comm_t* c) {
     if (!c) return;
     for (int i = 0; i < c->n; ++i) (void)rccl().CommDestroy(c->comms[i]);
+    if (c->mesh_ready) {
+        int prev = 0;
+        (void)hipGetDevice(&prev);
+        for (int r = 0; r < c->n; ++r) {
+            (void)hipSetDevice(c->devices[r]);
+            if (c->ev_src[r]) (void)hipEventDestroy(c->ev_src[r]);
+            if (c->ev_dst[r]) (void)hipEventDestroy(c->ev_dst[r]);
+            for (int i = 0; i < c->n; ++i) {
+                if (c->cs[r][i]) (void)hipStreamDestroy(c->cs[r][i]);
+                if (c->ev_done[r][i]) (void)hipEventDestroy(c->ev_done[r][i]);
+            }
+        }
+        (void)hipSetDevice(prev);
+    }
     delete c;
 }
 
@@ -129,23 +162,123 @@ int vfi_comm_broadcast(vfi_comm_t* c, float* const* bufs_dev, int64_t count, int
     const RcclApi& api = rccl();
     VFI_CHECK_NCCL(api.GroupStart());
     for (int i = 0; i < c->n; ++i)
-        VFI_CHECK_NCCL(api.Broadcast(bufs_dev[root], bufs_dev[i], (size_t)count, ncclFloat32, root, c->comms[i], (hipStream_t)streams[i]));
+        VFI_NCCL_IN_GROUP(api, api.Broadcast(bufs_dev[root], bufs_dev[i], (size_t)count, ncclFloat32, root, c->comms[i], (hipStream_t)streams[i]));
     VFI_CHECK_NCCL(api.GroupEnd());
     return 0;
 }
 
+// The copies of an in-place all-gather with per-rank counts: rank r's block [prefix[r], prefix[r] + counts[r]) goes to the same
+// place of every OTHER rank's buffer.  Pure function (no device): the direct path below executes this list, the CPU suite checks it.
+int64_t vfi_comm_plan_all_gather(int n, const int64_t* counts, int64_t* plan, int64_t cap) {
+    if (n < 1 || !counts || (!plan && cap > 0)) {
+        set_error("vfi_comm_plan_all_gather: bad arguments");
+        return -1;
+    }
+    int64_t off = 0, k = 0;
+    for (int r = 0; r < n; ++r) {
+        if (counts[r] < 0) {
+            set_error("vfi_comm_plan_all_gather: negative count for rank %d", r);
+            return -1;
+        }
+        if (counts[r] > 0)
+            for (int i = 0; i < n; ++i) {
+                if (i == r) continue;
+                if (plan) {
+                    if (4 * (k + 1) > cap) {
+                        set_error("vfi_comm_plan_all_gather: plan buffer too small");
+                        return -1;
+                    }
+                    plan[4 * k] = r, plan[4 * k + 1] = i, plan[4 * k + 2] = off, plan[4 * k + 3] = counts[r];
+                }
+                ++k;
+            }
+        off += counts[r];
+    }
+    return k;
+}
+
+static int mesh_init(vfi_comm* c) {
+    if (c->mesh_ready) return 0;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    for (int r = 0; r < c->n; ++r) {
+        VFI_CHECK_HIP(hipSetDevice(c->devices[r]));
+        VFI_CHECK_HIP(hipEventCreateWithFlags(&c->ev_src[r], hipEventDisableTiming));
+        VFI_CHECK_HIP(hipEventCreateWithFlags(&c->ev_dst[r], hipEventDisableTiming));
+        for (int i = 0; i < c->n; ++i) {
+            if (i == r) continue;
+            VFI_CHECK_HIP(hipStreamCreateWithFlags(&c->cs[r][i], hipStreamNonBlocking));
+            VFI_CHECK_HIP(hipEventCreateWithFlags(&c->ev_done[r][i], hipEventDisableTiming));
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, c->devices[r], c->devices[i]) == hipSuccess && can) {
+                const hipError_t e = hipDeviceEnablePeerAccess(c->devices[i], 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();   // copies then stage through the host
+            }
+        }
+    }
+    (void)hipSetDevice(prev);
+    c->mesh_ready = true;
+    return 0;
+}
+
+// Direct full-mesh form: xGMI is point to point, every pair of the node's 8 devices has its own link, so
+// each rank pushes its block to its 7 peers with 7 concurrent peer copies (one stream per ordered pair): shard / link rate instead
+// of a ring's (R-1) hops of shard / link rate.  Ordering: a copy r -> i starts after streams[r] (the block is computed) and after
+// streams[i] (the destination's earlier readers of that slot are done); streams[i] then waits for all its incoming copies.
+static int all_gather_direct(vfi_comm* c, float* const* bufs_dev, const int64_t* counts, void* const* streams) {
+    if (mesh_init(c)) return -1;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    for (int r = 0; r < c->n; ++r) {
+        VFI_CHECK_HIP(hipSetDevice(c->devices[r]));
+        VFI_CHECK_HIP(hipEventRecord(c->ev_src[r], (hipStream_t)streams[r]));
+        VFI_CHECK_HIP(hipEventRecord(c->ev_dst[r], (hipStream_t)streams[r]));
+    }
+    std::vector<int64_t> plan((size_t)4 * c->n * c->n);
+    const int64_t np = vfi_comm_plan_all_gather(c->n, counts, plan.data(), (int64_t)plan.size());
+    if (np < 0) return -1;
+    for (int64_t k = 0; k < np; ++k) {
+        const int r = (int)plan[4 * k], i = (int)plan[4 * k + 1];
+        const int64_t off = plan[4 * k + 2], cnt = plan[4 * k + 3];
+        VFI_CHECK_HIP(hipSetDevice(c->devices[r]));
+        VFI_CHECK_HIP(hipStreamWaitEvent(c->cs[r][i], c->ev_src[r], 0));
+        VFI_CHECK_HIP(hipStreamWaitEvent(c->cs[r][i], c->ev_dst[i], 0));
+        VFI_CHECK_HIP(hipMemcpyPeerAsync(bufs_dev[i] + off, c->devices[i], bufs_dev[r] + off, c->devices[r], (size_t)cnt * sizeof(float), c->cs[r][i]));
+        VFI_CHECK_HIP(hipEventRecord(c->ev_done[r][i], c->cs[r][i]));
+    }
+    for (int64_t k = 0; k < np; ++k) {
+        const int r = (int)plan[4 * k], i = (int)plan[4 * k + 1];
+        VFI_CHECK_HIP(hipSetDevice(c->devices[i]));
+        VFI_CHECK_HIP(hipStreamWaitEvent((hipStream_t)streams[i], c->ev_done[r][i], 0));
+        // the source must not overwrite its block before the copy has read it
+        VFI_CHECK_HIP(hipSetDevice(c->devices[r]));
+        VFI_CHECK_HIP(hipStreamWaitEvent((hipStream_t)streams[r], c->ev_done[r][i], 0));
+    }
+    (void)hipSetDevice(prev);
+    return 0;
+}
+
+static int all_gather_mode() {     // VFI_ALLGATHER = direct (default: per-link peer copies) | rccl (grouped per-root ncclBroadcast)
+    static const int mode = [] {
+        const char* e = getenv("VFI_ALLGATHER");
+        return (e && (e[0] == 'r' || e[0] == 'R')) ? 1 : 0;
+    }();
+    return mode;
+}
+
 int vfi_comm_all_gather_v(vfi_comm_t* c, float* const* bufs_dev, const int64_t* counts, void* const* streams) {
     VFI_REQUIRE(c && bufs_dev && counts && streams, "vfi_comm_all_gather_v: bad arguments");
+    for (int r = 0; r < c->n; ++r) VFI_REQUIRE(counts[r] >= 0, "vfi_comm_all_gather_v: negative count for rank %d", r);   // before any group opens
+    if (all_gather_mode() == 0) return all_gather_direct(c, bufs_dev, counts, streams);
     const RcclApi& api = rccl();
     // one group: for every root r, its block [prefix[r], prefix[r] + counts[r]) travels to the same place of every buffer
     VFI_CHECK_NCCL(api.GroupStart());
     int64_t off = 0;
     for (int r = 0; r < c->n; ++r) {
-        VFI_REQUIRE(counts[r] >= 0, "vfi_comm_all_gather_v: negative count");
         if (counts[r] > 0)
             for (int i = 0; i < c->n; ++i)
-                VFI_CHECK_NCCL(api.Broadcast(bufs_dev[r] + off, bufs_dev[i] + off, (size_t)counts[r], ncclFloat32, r, c->comms[i],
-                                             (hipStream_t)streams[i]));
+                VFI_NCCL_IN_GROUP(api, api.Broadcast(bufs_dev[r] + off, bufs_dev[i] + off, (size_t)counts[r], ncclFloat32, r, c->comms[i],
+                                                     (hipStream_t)streams[i]));
         off += counts[r];
     }
     VFI_CHECK_NCCL(api.GroupEnd());

@@ -62,12 +62,15 @@ struct vfi_m2m {
 
 namespace {
 
-int alloc_ten(vfi_m2m* m, Ten& t, int n, int h, int w, int c) {
+int alloc_ten(vfi_m2m* m, Ten& t, int n, int h, int w, int c, hipStream_t st = nullptr) {
     t.n = n, t.h = h, t.w = w, t.c = c;
     const size_t bytes = (size_t)n * h * w * c * sizeof(float);
     VFI_CHECK_HIP(hipMalloc((void**)&t.p, bytes));
     m->owned.push_back(t.p);
-    VFI_CHECK_HIP(hipMemset(t.p, 0, bytes));
+    // zero fill ordered with the forward's kernels: a NULL-stream memset is not ordered against a non-blocking side stream (torch's)
+    // and could clear a lazily allocated scratch tensor AFTER its first producer ran
+    VFI_CHECK_HIP(hipMemsetAsync(t.p, 0, bytes, st));
+    if (!st) VFI_CHECK_HIP(hipStreamSynchronize(nullptr));
     return 0;
 }
 

@@ -763,7 +763,7 @@ int stage_trans_launch(const float* Ppool, size_t pack_stride, const RifeTasks& 
     const int Hs = Hp / s_next, Ws = Wp / s_next;
     const int tiles_x = cdiv(Ws, 16), tiles_y = cdiv(Hs, 16);
     dim3 grid(tiles_x * tiles_y, B);
-    TraceScope ts("stage_trans", st);
+    TraceScope ts(s_next == 4 ? "stage_trans4" : (s_next == 2 ? "stage_trans2" : "stage_trans1"), st);   // per target scale: bench.py prices each
     if ((s_next == 2 || s_next == 4) && (stage_quad_mask() & s_next)) {
         const int qtx = cdiv(Ws, 16);
         dim3 qgrid(qtx * cdiv(Hs, 4), B);
@@ -1098,7 +1098,7 @@ int stage_trans_x_launch(const float* Ppool, size_t pack_stride, const RifeTasks
     const int Hs = Hp / s_next, Ws = Wp / s_next;
     const int tiles_x = cdiv(Ws, 16), tiles_y = cdiv(Hs, 16);
     dim3 grid(tiles_x * tiles_y, B);
-    TraceScope ts("stage_trans", st);
+    TraceScope ts(s_next == 8 ? "stage_transx8" : (s_next == 4 ? "stage_transx4" : (s_next == 2 ? "stage_transx2" : "stage_transx1")), st);
     if (s_next >= 2 && (stage_quad_mask() & s_next)) {
         const int qtx = cdiv(Ws, 16);
         dim3 qgrid(qtx * cdiv(Hs, 4), B);

@@ -85,11 +85,13 @@ def _pool(name, n):
 _ring_lock = threading.Lock()
 
 
-def _rings_acquire(device, shape, dtype=torch.float32):
-    """A set of pinned / device staging rings for this (device, frame shape), exclusively the caller's until
+def _rings_acquire(device, shape, dtype=torch.float32, role="up"):
+    """A set of pinned / device staging rings for this (device, frame shape, role), exclusively the caller's until
     ``_rings_release``; sets are kept for the life of the process (pinning costs about as much as the copies it saves) and each
-    ring only ever grows.  Concurrent pipelines on one device (two host threads) get different sets."""
-    key = (str(device), tuple(shape), dtype)
+    ring only ever grows.  Concurrent pipelines on one device (two host threads) get different sets.  ``role`` ("up" / "down")
+    keeps the uploader's and the downloader's sets apart: sharing one free list made each pick up the other's set on the next
+    call and grow the rings it lacked — twice the pinned and device staging memory in steady state."""
+    key = (str(device), tuple(shape), dtype, role)
     with _ring_lock:
         free = _ring_cache.setdefault(key, [])
         r = free.pop() if free else {"key": key, "up_host": [], "up_dev": [], "down_host": []}
@@ -107,11 +109,16 @@ def _rings_release(r):
 
 def _rings_grow(r, device, shape, n_up, n_down):
     dtype = r["key"][2]
-    while len(r["up_host"]) < n_up:
-        r["up_host"].append(torch.empty(shape, dtype=dtype, pin_memory=True))
-        r["up_dev"].append(torch.empty(shape, dtype=dtype, device=device))
-    while len(r["down_host"]) < n_down:
-        r["down_host"].append(torch.empty(shape, dtype=dtype, pin_memory=True))
+    try:
+        while len(r["up_host"]) < n_up:
+            r["up_host"].append(torch.empty(shape, dtype=dtype, pin_memory=True))
+            r["up_dev"].append(torch.empty(shape, dtype=dtype, device=device))
+        while len(r["down_host"]) < n_down:
+            r["down_host"].append(torch.empty(shape, dtype=dtype, pin_memory=True))
+    except BaseException:
+        r["up_host"] = r["up_host"][:len(r["up_dev"])]      # keep the pairs aligned, give the set back: an allocation failure must
+        _rings_release(r)                                    # not strand it outside the cache
+        raise
     return r
 
 
@@ -123,7 +130,7 @@ class Uploader:
         self.frames, self.order, self.device, self.main = frames, list(order), device, main
         H, W = frames.shape[1:3]
         self.depth = depth
-        self.rings = _rings_grow(_rings_acquire(device, (H, W, 3), frames.dtype), device, (H, W, 3), depth, 0)   # fp32 or uint8 clips
+        self.rings = _rings_grow(_rings_acquire(device, (H, W, 3), frames.dtype, "up"), device, (H, W, 3), depth, 0)   # fp32 or uint8 clips
         self.host, self.dev = self.rings["up_host"][:depth], self.rings["up_dev"][:depth]
         self.stream = torch.cuda.Stream(device)
         self.freed = [threading.Event() for _ in self.order]      # slot of item i may be overwritten
@@ -180,7 +187,7 @@ class Downloader:
 
     def __init__(self, device, shape, main, depth=16, workers=WORKERS[1], dtype=torch.float32):
         self.device, self.main, self.depth = device, main, depth
-        self.rings = _rings_grow(_rings_acquire(device, shape, dtype), device, shape, 0, depth)
+        self.rings = _rings_grow(_rings_acquire(device, shape, dtype, "down"), device, shape, 0, depth)
         self.host = self.rings["down_host"][:depth]
         self.stream = torch.cuda.Stream(device)
         self.pool = _pool(f"down{device}", workers)

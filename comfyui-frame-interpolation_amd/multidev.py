@@ -43,9 +43,11 @@ def selected_devices(default_device=None):
     bad = [d for d in ids if d < 0 or d >= n]
     if bad or len(set(ids)) != len(ids):
         raise ValueError(f"VFI_DEVICES={spec!r}: devices {bad or ids} not valid ({n} visible, ids must be distinct)")
-    if cur in ids:                      # keep the caller's device as the primary
+    # the caller's device (where the cached engine and its weight arena live) is always the primary: the RCCL broadcast root
+    # must be a member of the clique, so a device list that leaves it out gets it prepended
+    if cur in ids:
         ids.remove(cur)
-        ids.insert(0, cur)
+    ids.insert(0, cur)
     return ids
 
 
@@ -163,7 +165,9 @@ class RifeDeviceGroup:
     @classmethod
     def around(cls, primary_engine, devices):
         """Group whose first member is an existing engine (the node's cached one); devices[0] must be its device."""
-        assert devices[0] == (primary_engine.device.index or 0)
+        if not devices or devices[0] != (primary_engine.device.index or 0):
+            raise ValueError(f"RifeDeviceGroup.around: devices {list(devices)} must start with the primary engine's device "
+                             f"{primary_engine.device.index or 0} (its weight arena is the broadcast root)")
         return cls(None, primary_engine.arch_ver, devices, _primary=primary_engine)
 
     @property

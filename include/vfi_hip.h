@@ -437,6 +437,12 @@ int vfi_comm_broadcast(vfi_comm_t* comm, float* const* bufs_dev, int64_t count, 
  * counts[0] + ... + counts[r-1]; afterwards every buffer holds every block (grouped per-root broadcasts, so counts may differ). */
 int vfi_comm_all_gather_v(vfi_comm_t* comm, float* const* bufs_dev, const int64_t* counts, void* const* streams);
 
+/* The copy list of that in-place all-gather: `n` ranks, per-rank counts -> quadruples (source rank, destination rank, offset,
+ * count) into `plan` (4 int64 per copy; cap = capacity in int64; plan may be NULL to count).  Pure host function: what the direct
+ * full-mesh path (VFI_ALLGATHER=direct, the default: one hipMemcpyPeerAsync per ordered device pair on its own stream — one xGMI
+ * link each; VFI_ALLGATHER=rccl selects grouped per-root ncclBroadcast instead) executes.  Returns the number of copies or < 0. */
+int64_t vfi_comm_plan_all_gather(int n, const int64_t* counts, int64_t* plan, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

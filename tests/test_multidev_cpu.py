@@ -67,10 +67,42 @@ def test_device_selection(monkeypatch):
     monkeypatch.setenv("VFI_DEVICES", "all")
     assert multidev.selected_devices() == [2, 0, 1, 3, 4, 5, 6, 7]             # the caller's device stays the primary
     monkeypatch.setenv("VFI_DEVICES", "4,5")
-    assert multidev.selected_devices() == [4, 5]
+    assert multidev.selected_devices() == [2, 4, 5]      # the engine's device is always the primary (it holds the weight arena = broadcast root)
     monkeypatch.setenv("VFI_DEVICES", "1,1")
     with pytest.raises(ValueError):
         multidev.selected_devices()
     monkeypatch.setenv("VFI_DEVICES", "9")
     with pytest.raises(ValueError):
         multidev.selected_devices()
+
+
+def test_all_gather_plan_offsets(hip_lib):
+    """vfi_comm_plan_all_gather (the copy list the direct full-mesh all-gather executes): applied to host arrays with unequal and
+    empty shards it reproduces the in-place all-gather, and every ordered pair appears at most once (one xGMI link each)."""
+    import ctypes as C
+
+    import numpy as np
+
+    for counts in ([5, 3, 0, 7], [4, 4], [0, 0, 9], [1], [2, 0, 0, 0, 0, 0, 0, 6]):
+        n, tot = len(counts), sum(counts)
+        carr = (C.c_int64 * n)(*counts)
+        k = hip_lib.vfi_comm_plan_all_gather(n, carr, None, 0)
+        assert k == sum(n - 1 for c in counts if c > 0)
+        plan = (C.c_int64 * (4 * max(k, 1)))()
+        assert hip_lib.vfi_comm_plan_all_gather(n, carr, plan, 4 * max(k, 1)) == k
+        bufs = [np.full(tot, -1.0, np.float32) for _ in range(n)]
+        off = 0
+        for r, c in enumerate(counts):               # every rank holds its own block
+            bufs[r][off:off + c] = 100 * r + np.arange(c)
+            off += c
+        want = np.concatenate([100 * r + np.arange(c, dtype=np.float32) for r, c in enumerate(counts)]) if tot else np.zeros(0, np.float32)
+        pairs = set()
+        for j in range(k):
+            src, dst, o, c = (int(plan[4 * j + i]) for i in range(4))
+            assert src != dst and (src, dst) not in pairs
+            pairs.add((src, dst))
+            bufs[dst][o:o + c] = bufs[src][o:o + c]
+        for b in bufs:
+            assert np.array_equal(b, want)
+    bad = (C.c_int64 * 2)(3, -1)
+    assert hip_lib.vfi_comm_plan_all_gather(2, bad, None, 0) < 0
