@@ -357,7 +357,10 @@ static int n_cus_cached() {
 //   * stride 2 with Cout a multiple of 64: second generation 16x8x64; the other stride-2 shapes and the
 //     grouped transposed conv: first-generation small tiles.
 int conv_pick_variant(const ConvArgs& a, int stride, bool grouped) {
-    const long px = (long)a.N * a.Hout * a.Wout;
+    // The layer objects (split_ok: FILM / M2M / ..., batch fixed by the model) size the choice by the launch; the RIFE network, whose
+    // launches carry 1..32 tasks, by the image at a nominal 8 tasks: tile variants differ in K-chunk size, i.e. in fp32 summation
+    // order, and a frame's result must not depend on how many tasks shared its launch (tests/test_gpu_rife.py: bit-equal).
+    const long px = (long)(a.split_ok ? a.N : 8) * a.Hout * a.Wout;
     if (!grouped && stride == 2 && a.ntaps == 4) return kConv2Base + (a.Cout_p % 64 == 0 ? 21 : 20);
     if (!grouped && stride == 1 && a.ntaps != 9) {  // 2x2 'same' / 1x1 convs (FILM): second generation only
         const bool big = px * (a.Cout_p / 32) >= 256L * 4 * n_cus_cached();
