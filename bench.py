@@ -218,6 +218,52 @@ def other_paths(dev, H, W):
     return out
 
 
+def other_paths_dist(dev, H, W, world, rank, backend):
+    """N > 1 (one process per GPU): FILM 2x and M2M 2x with the frame PAIRS sharded over the ranks (each rank interpolates its own
+    pair stream — weak scaling, like the headline metric — and the new frames are all-gathered over RCCL), timed
+    between barriers, max over ranks.  Gives the driver's multi-GPU run the FILM / M2M curves next to RIFE's."""
+    import torch.distributed as dist
+
+    from cfi_amd import synth
+    from cfi_amd.film import FilmEngine
+    from cfi_amd.m2m import M2MEngine
+
+    fr = synth.smooth_frames(2, H, W, seed=2 + rank, shift=4.0)
+    x0, x1 = fr[0].to(dev).contiguous(), fr[1].to(dev).contiguous()
+    gathered = torch.empty((world, H, W, 3), dtype=torch.float32, device=dev) if backend == "nccl" else None
+
+    def timed(fn, n):
+        fn()
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = fn()
+            if gathered is not None:
+                dist.all_gather_into_tensor(gathered, out.view(1, H, W, 3))
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()) / n
+
+    out = {}
+    eng = FilmEngine(synth.film_synth_state_dict(1234))
+    t = timed(lambda: eng.forward(x0, x1), 3)
+    out["film_2x"] = {"frames_per_s": round(world / t, 2), "ms_per_pair_per_gpu": round(t * 1e3, 2), "sharding": "frame pairs over ranks, all-gather of new frames"}
+    eng.close()
+    eng = M2MEngine(synth.m2m_synth_state_dict(1234))
+
+    def m2m_pair():
+        eng.prepare(x0, x1)
+        return eng.render(0.5)
+
+    t = timed(m2m_pair, 5)
+    out["m2m_2x"] = {"frames_per_s": round(world / t, 1), "ms_per_pair_per_gpu": round(t * 1e3, 3), "sharding": "frame pairs over ranks, all-gather of new frames"}
+    eng.close()
+    return out
+
+
 def cpu_baseline(sd, H, W, budget_s=25.0):
     """Oracle on the host cores, bounded sample: for a few thread counts (all cores is often NOT the fastest
     on a many-core host), 1 warm-up + 3 timed 1080p forwards each; report the best median."""
@@ -608,11 +654,17 @@ def main():
     rep = _lib.trace_report()
     lib.vfi_trace_reset()
 
+    dist_extras = None
+    if world > 1 and not args.no_extras:
+        eng.release() if hasattr(eng, "release") else None
+        dist_extras = other_paths_dist(dev, H, W, world, rank, args.backend)
     if rank == 0:
         res = result_line(args, world, elapsed, traced, rep, eng,
                           "none" if world == 1 or args.no_gather else
                           ("all_gather(RCCL), overlapped" if gathered is not None else "all_gather(gloo, host)"))
         res["config"]["launch"] = "one process per GPU (torch.distributed)" if world > 1 else "one process, one GPU"
+        if dist_extras is not None:
+            res["other_paths"] = dist_extras
         if world == 1:
             eng.close()
             if not args.no_e2e:

@@ -18,7 +18,10 @@ STAMP = LIB + ".stamp"
 ARCH = "gfx950"
 # per-file flags.  conv_wino.hip: hipcc's SLP vectoriser packs the input-transform adds into v_pk_add_f32 with v_mov shuffles
 # — packed f32 VALU beside MFMAs is an anti-lever on gfx950 (MI355X_MICROARCH.md, per-instruction constants) and costs registers
-EXTRA_FLAGS = {"conv_wino.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"conv_wino.hip": ["-fno-slp-vectorize"],
+               # cost volume: SLP turned |a - b| accumulation (v_sub + v_add with the |x| source modifier, 2 ops) into v_pk_add + 2 v_and +
+               # v_pk_add + moves (~3 per element)
+               "m2m_ops.hip": ["-fno-slp-vectorize"]}
 
 
 def _sources():

@@ -591,6 +591,9 @@ constexpr int CV_TW = CV_T + 8;     // + 4-pixel halo each side
 constexpr int CV_CK = 16;           // channels per LDS pass
 constexpr int CV_S = CV_CK + 4;     // LDS pixel stride (floats)
 
+// FULL: C is a multiple of the 16-channel LDS pass (M2M: 32): no per-element channel guards in the 81 x 16 inner loop (they were
+// 1296 scalar branches per pass and cost 3/4 of the kernel's time)
+template <bool FULL>
 __global__ __launch_bounds__(256) void costvol_kernel(const float* __restrict__ one, int one_cs,
                                                       const float* __restrict__ two, int two_cs, int two_swap,
                                                       float* __restrict__ out, int N, int H, int W, int C, int out_cs,
@@ -641,10 +644,10 @@ __global__ __launch_bounds__(256) void costvol_kernel(const float* __restrict__ 
 #pragma unroll
                 for (int q = 0; q < CV_CK / 4; ++q) {
                     const float4 v = *(const float4*)(t + q * 4);
-                    if (4 * q + 0 < nc) a = __fadd_rn(a, fabsf(__fsub_rn(o[4 * q + 0], v.x)));
-                    if (4 * q + 1 < nc) a = __fadd_rn(a, fabsf(__fsub_rn(o[4 * q + 1], v.y)));
-                    if (4 * q + 2 < nc) a = __fadd_rn(a, fabsf(__fsub_rn(o[4 * q + 2], v.z)));
-                    if (4 * q + 3 < nc) a = __fadd_rn(a, fabsf(__fsub_rn(o[4 * q + 3], v.w)));
+                    if (FULL || 4 * q + 0 < nc) a = __fadd_rn(a, fabsf(__fsub_rn(o[4 * q + 0], v.x)));
+                    if (FULL || 4 * q + 1 < nc) a = __fadd_rn(a, fabsf(__fsub_rn(o[4 * q + 1], v.y)));
+                    if (FULL || 4 * q + 2 < nc) a = __fadd_rn(a, fabsf(__fsub_rn(o[4 * q + 2], v.z)));
+                    if (FULL || 4 * q + 3 < nc) a = __fadd_rn(a, fabsf(__fsub_rn(o[4 * q + 3], v.w)));
                 }
                 acc[dy * 9 + dx] = a;
             }
@@ -661,8 +664,12 @@ int costvol_launch(const float* one, int one_cs, const float* two, int two_cs, i
                    int C, int out_cs, int out_coff, hipStream_t s) {
     const int tiles_x = cdiv(W, CV_T), tiles_y = cdiv(H, CV_T);
     TraceScope ts("costvol9x9", s);
-    hipLaunchKernelGGL(costvol_kernel, dim3(N * tiles_x * tiles_y), dim3(256), 0, s, one, one_cs, two, two_cs, two_swap, out, N,
-                       H, W, C, out_cs, out_coff, tiles_x, tiles_y);
+    if (C % CV_CK == 0)
+        hipLaunchKernelGGL(costvol_kernel<true>, dim3(N * tiles_x * tiles_y), dim3(256), 0, s, one, one_cs, two, two_cs, two_swap, out, N,
+                           H, W, C, out_cs, out_coff, tiles_x, tiles_y);
+    else
+        hipLaunchKernelGGL(costvol_kernel<false>, dim3(N * tiles_x * tiles_y), dim3(256), 0, s, one, one_cs, two, two_cs, two_swap, out, N,
+                           H, W, C, out_cs, out_coff, tiles_x, tiles_y);
     VFI_CHECK_HIP(hipGetLastError());
     return 0;
 }

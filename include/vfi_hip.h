@@ -119,6 +119,15 @@ int vfi_film_forward(vfi_film_t* net, const float* x0_dev, const float* x1_dev, 
                      void* stream);
 int vfi_film_release_workspace(vfi_film_t* net);
 
+/* The whole FILM node call for a HOST clip, replacing FILM_VFI.vfi's body, vfi_models/film/__init__.py:63-113:
+ * frames_host [N,H,W,C] fp32 (C >= 3; alpha dropped) -> out_host [*n_out,H,W,3].  Per kept pair: frame_i, then the m-1 new frames
+ * of the greedy bisection (:12-42; every model call returns the midpoint of two known frames, clamped to [0,1], and later calls
+ * consume earlier outputs); a skipped pair is DROPPED, frame included (:89-90); the clip's last frame is appended.
+ * multipliers == NULL: `multiplier` for every pair; else the list (n_multipliers entries) padded with 2 (:84-87).  skip: [N-1]
+ * flags or NULL.  out_host == NULL only computes *n_out.  Synchronous, own stream. */
+int vfi_film_run(vfi_film_t* net, const float* frames_host, int N, int H, int W, int C, int multiplier, const int* multipliers,
+                 int n_multipliers, const uint8_t* skip, float* out_host, int64_t* n_out);
+
 /* ---- M2M custom ops ---------------------------------------------------------------------- */
 
 /* Summation splat (forward warp): out[n, y', x', c] += in[n,y,x,c] * bilinear weight at the 4 integer
@@ -194,6 +203,16 @@ void vfi_m2m_destroy(vfi_m2m_t* net);
 int vfi_m2m_prepare(vfi_m2m_t* net, const float* frame0_dev, const float* frame1_dev, int C, int H, int W, void* stream);
 int vfi_m2m_render(vfi_m2m_t* net, float t, float* out_dev, void* stream);
 int vfi_m2m_release_workspace(vfi_m2m_t* net);
+
+/* The whole M2M node call for a HOST clip, replacing M2M_VFI.vfi + generic_frame_loop in timestep mode
+ * (vfi_models/m2m/__init__.py:33-60, vfi_utils.py:149-389): frames_host [N,H,W,C] fp32, N >= 2 -> out_host [*n_out,H,W,3].
+ * multipliers == NULL ("int multiplier"): frame_i, its multiplier-1 new frames at t = k/m (none when skip[i]), ..., last frame.
+ * multipliers != NULL ("list multiplier", n_multipliers entries padded with 2): every pair runs as its own 2-frame loop — m == 0
+ * drops the pair INCLUDING its first frame (and the clip's last frame when it is the last pair), m == 1 keeps the frame, and the
+ * skip list is consulted with the pair's LOCAL index, i.e. skip[0], for every pair (vfi_utils.py:364-386): reproduced as is.
+ * New frames are not clamped (like the reference).  out_host == NULL only computes *n_out.  Synchronous, own stream. */
+int vfi_m2m_run(vfi_m2m_t* net, const float* frames_host, int N, int H, int W, int C, int multiplier, const int* multipliers,
+                int n_multipliers, const uint8_t* skip, float* out_host, int64_t* n_out);
 
 /* ---- RIFE arch 4.0 building blocks (sudo_rife4 checkpoint; rife40.py drives them with the layer objects above) -- */
 

@@ -38,6 +38,12 @@ int64_t vfi_rife_debug_read(vfi_rife_t* net, int what, int stage, float* host_bu
 int vfi_rife_debug_keep(vfi_rife_t* net, int on);
 
 
+/* The call order of FILM's greedy bisection for `inter_frames` new frames (film/__init__.py:17-40) as the C side computes it:
+ * (left, right, new) grid positions, 3 ints per call; returns the number of calls or < 0.  Host only. */
+int vfi_test_film_schedule(int inter_frames, int* triples, int cap);
+/* ... and the float32 grid it is computed on: torch.linspace(0, 1, n) restated (n floats to `out`). */
+int vfi_test_linspace01(int n, float* out);
+
 /* FILM: the synthesised flow pyramid of the last vfi_film_forward — direction d (0 forward, 1 backward), pyramid level l,
  * [h_l, w_l, 2] floats to host.  Returns the number of floats or < 0. */
 int64_t vfi_film_debug_read_flow(vfi_film_t* net, int d, int level, float* host_buf, int64_t cap);

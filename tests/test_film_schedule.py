@@ -25,3 +25,28 @@ def test_film_spec_matches_survey():
         n += k
     assert n == 34436667
     assert [film_spec.feat_channels(l) for l in range(5)] == [64, 192, 448, 960, 960]
+
+
+def test_c_side_schedule_equals_python(hip_lib):
+    """vfi_film_run's bisection order (csrc/clip_run.hip: torch.linspace and the fp32 distance matrix restated in C) equals the
+    Python node's film_schedule — which is pinned against the reference's inference() — for 0..24 new frames per pair."""
+    import ctypes as C
+
+    from cfi_amd.film import film_schedule
+
+    for inter in range(0, 25):
+        buf = (C.c_int * (3 * max(inter, 1)))()
+        n = hip_lib.vfi_test_film_schedule(inter, buf, 3 * max(inter, 1))
+        assert n == inter
+        got = [(buf[3 * i], buf[3 * i + 1], buf[3 * i + 2]) for i in range(n)]
+        assert got == [tuple(int(v) for v in c) for c in film_schedule(inter)], inter
+
+
+def test_c_side_linspace_equals_torch(hip_lib):
+    import numpy as np
+    import torch
+
+    for n in range(2, 200):
+        out = np.zeros(n, np.float32)
+        assert hip_lib.vfi_test_linspace01(n, out.ctypes.data) == n
+        assert np.array_equal(out, torch.linspace(0, 1, n).numpy()), n
