@@ -60,7 +60,8 @@ struct WinoGeom {
     static constexpr int BUF_FLOATS = 4 * A_FLOATS + B_FLOATS;
     static constexpr int TAB_FLOATS = 4 * NA * 64;       // per wave: the DMA cursor's NA byte offsets per lane (kept in LDS, not in VGPRs)
     static constexpr int NBUF = 3;                       // LDS chunk buffers: the DMA queue runs two chunks ahead of the MFMAs
-    static constexpr int LDS_BYTES = (NBUF * BUF_FLOATS + TAB_FLOATS) * 4;
+    static constexpr int MAXCO = 1024;                   // output channels whose epilogue constants (bias, beta, PReLU slope) sit in LDS
+    static constexpr int LDS_BYTES = (NBUF * BUF_FLOATS + TAB_FLOATS + 3 * MAXCO) * 4;
     static_assert(NITEM % 4 == 0 && PW % 2 == 0, "swizzle stays inside the image and inside a row");
 };
 
@@ -68,6 +69,12 @@ struct WinoGeom {
 // bits XORed by a row-pair key.  A wave's ds_read_b128 of one patch position touches tiles 2 px apart = slots 4 apart, i.e.
 // only every fourth 16-byte bank group; the key spreads the four tile rows over the four groups (conflict-free for 8x4 tiles).
 __device__ __forceinline__ int wino_key(int py) { return (py >> 1) & 3; }
+
+// s_waitcnt immediate of gfx9 / CDNA: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14 (expcnt 7, lgkmcnt 15 = no wait).
+// The builtin, not inline asm: hipcc's own wait-count pass then KNOWS the counters' state (behind an opaque asm it assumed the
+// B-fragment / offset reads of the previous sub-step could still be outstanding and stalled the boundary's first MFMA / first
+// DMA piece on the oldest of the 16 patch reads issued in between).
+constexpr int wino_waitcnt(int vm, int lgkm) { return (vm & 15) | (7 << 4) | ((lgkm & 15) << 8) | ((vm >> 4) << 14); }
 
 // n / d for 0 <= n < 2^24 with the host's 1.0f / d: float product, one fix-up step.  (hipcc's own integer division keeps a hoisted
 // reciprocal in a VGPR for the whole kernel — one more register to spill, and its reload in the per-item code sat behind
@@ -86,13 +93,11 @@ __device__ __forceinline__ int wino_div(int n, int d, float inv_d) {
 // no per-value branches.  MODE 0: the hot form (no residual, none / LeakyReLU with a slope in [0,1]: lrelu(v) = max(v, v*slope));
 // MODE 10 + act: the general form (residual, any activation of ConvArgs::act, post affine).
 template <int RTX, int MODE>
-__device__ __forceinline__ void wino_epilogue(const f32x16 (&acc)[16], const ConvArgs& a, int n, int oy0, int ox0, int co, int coc, int half) {
+__device__ __forceinline__ void wino_epilogue(const f32x16 (&acc)[16], const ConvArgs& a, int n, int oy0, int ox0, int co, int coc, int half, float bs,
+                                              float bt, float pre) {
     const int H = a.Hin, W = a.Win;
-    const float bs = a.bias[coc];
-    const float bt = a.beta ? a.beta[coc] : 1.f;
     const float uslope = a.act == 1 ? a.slope : 1.0f;
     const float ps = a.post_scale != 0.f ? a.post_scale : 1.0f, sh = a.post_scale != 0.f ? a.post_shift : 0.0f;
-    const float pre = MODE == 13 ? a.prelu[coc] : 0.f;
     const __amdgpu_buffer_rsrc_t orsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)n * H * W * a.out_cs), 0, H * W * a.out_cs * 4, 0x00020000);
     const bool has_res = MODE >= 10 && a.res != nullptr;
@@ -264,23 +269,29 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
     f32x16 acc[16];
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-    // patch read offsets (floats inside the wave's A image): 4 lane-dependent bases (index (dx & 1) * 2 + (dy >> 1), recomputed per
-    // chunk: cheaper than four registers held through the loop) + compile-time (dy, dx) offsets
-    auto read_patch = [&](int buf) {
-        const float* sA = smem + buf * G::BUF_FLOATS + wave * G::A_FLOATS;
+    // patch read addresses: 4 lane-dependent bases (index (dx & 1) * 2 + (dy >> 1)) + compile-time (dy, dx) offsets.  The bases are
+    // recomputed per chunk (cheaper than four registers held through the loop) — UNDER the MFMAs of the sub-step before the chunk
+    // boundary (patch_bases), pinned there: computed after the barrier they are ~35 VALU in front of the boundary's first MFMA.
+    int pb[4];
+    auto patch_bases = [&](int buf) {
         const int ol = opaque_lane();
         const int half = ol >> 5, ty = (ol & 31) / RTX, tx = (ol & 31) % RTX;
         const int base = (2 * ty * PW + 2 * tx) * 2;     // multiple of 4
-        int pb[4];
+        const int abase = (buf * G::BUF_FLOATS + wave * G::A_FLOATS) / 4;      // in 16-byte slots: keeps the reads provably aligned (ds_read_b128)
 #pragma unroll
         for (int dxp = 0; dxp < 2; ++dxp)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) pb[dxp * 2 + kk] = (base + ((half + 2 * dxp) ^ ((ty + kk) & 3))) * 4;
+            for (int kk = 0; kk < 2; ++kk) {
+                pb[dxp * 2 + kk] = abase + base + ((half + 2 * dxp) ^ ((ty + kk) & 3));
+                asm volatile("" : "+v"(pb[dxp * 2 + kk]));      // keep the computation here (LLVM would sink it to the reads)
+            }
+    };
+    auto read_patch = [&]() {
 #pragma unroll
         for (int dy = 0; dy < 4; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 4; ++dx)
-                P[dy * 4 + dx] = *(const f32x4*)(sA + pb[(dx & 1) * 2 + (dy >> 1)] + ((((dy * PW + dx) * 2) & ~3) * 4));
+                P[dy * 4 + dx] = ((const f32x4*)smem)[pb[(dx & 1) * 2 + (dy >> 1)] + (((dy * PW + dx) * 2) & ~3)];
     };
     auto read_b = [&](int buf, int j, f32x4(&B)[4]) {
         const float* sB = smem + buf * G::BUF_FLOATS + 4 * G::A_FLOATS + opaque_lane() * 4;
@@ -288,7 +299,16 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
         for (int q = 0; q < 4; ++q) B[q] = *(const f32x4*)(sB + (j * 4 + q) * 256);
     };
 
-    // ---- prologue: two chunks of DMA in flight, first patch transformed
+    // ---- per-channel epilogue constants in LDS (bias | beta | PReLU slope, padded channels: 0 | 1 | 0).  A global load in the
+    // epilogue would be waited for with s_waitcnt vmcnt(0) — behind every LDS-DMA piece in flight, 1-2 us per work item.
+    float* const cst = smem + G::NBUF * G::BUF_FLOATS + G::TAB_FLOATS;
+    for (int c = tid; c < a.Cout_p; c += 256) {
+        const bool real = c < a.Cout;
+        cst[c] = real ? a.bias[c] : 0.f;
+        cst[G::MAXCO + c] = (real && a.beta) ? a.beta[c] : 1.f;
+        cst[2 * G::MAXCO + c] = (real && EXT && a.act == 3) ? a.prelu[c] : 0.f;
+    }
+    // ---- prologue: three chunks of DMA in flight
     Cur dcur, ccur;
     int d_it = 0, d_k = 0;
     bool d_ok = item(0, dcur);
@@ -329,7 +349,7 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
     dma_advance();
     dma_issue_all(2);
     dma_advance();
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPC) : "memory");      // chunk 0 has landed, chunks 1 and 2 stay in flight
+    __builtin_amdgcn_s_waitcnt(wino_waitcnt(2 * NPC, 0));       // chunk 0 has landed (and the constants are written), chunks 1 and 2 stay in flight
     __builtin_amdgcn_s_barrier();
 
 #define WINO_TRANSFORM(J, V)                                                              \
@@ -403,13 +423,13 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
 #define WINO_BOUNDARY(NEXTBUF, RELBUF)                                                                              \
     {                                                                                                               \
         float t_[16];                                                                                               \
-        int av_[NA];                                                                                                \
         _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) {                                                         \
             __builtin_amdgcn_sched_barrier(0);                                                                      \
             acc[e_] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vc[e_], Bc[e_ >> 2][e_ & 3], acc[e_], 0, 0, 0);          \
-            if (e_ == 0) {                                                                                          \
+            if (e_ == 0) { /* behind the first MFMA: hipcc cannot see that the boundary's own s_waitcnt emptied lgkmcnt and */ \
+                /* would stall the MFMA on the two oldest of 16 reads issued in front of it (lgkmcnt(14))          */ \
+                if (!(ABL & 64)) read_patch();                                                                      \
                 if (!(ABL & 32)) read_b(NEXTBUF, 0, Bn);                                                            \
-                load_avoff(av_);                                                                                    \
             }                                                                                                       \
             if (e_ >= 1 && e_ <= NA && !(ABL & 1)) issue_a(drsrc, e_ - 1, av_[e_ - 1], d_k, RELBUF);                \
             if (e_ >= NA + 1 && e_ <= NA + 4 && !(ABL & 2)) issue_b(dwrsrc, e_ - NA - 1, dcur.nb, d_k, RELBUF);     \
@@ -438,12 +458,14 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) Bc[i_] = Bn[i_];                                           \
     }
 
+    int av_[NA];                         // the DMA cursor's byte offsets of the chunk about to be issued (from the LDS table)
     unsigned gchunk = 0;                 // chunk counter of this workgroup's stream: LDS buffer = gchunk % 3
     for (int it = 0; item(it, ccur); ++it) {
         // An item starts from LDS: nothing but the accumulators is live across the previous item's epilogue (holding the next
         // item's patch / operands in registers through it made hipcc spill ~100 registers per item).  Its first chunk has landed:
         // the boundary that ended the previous item (or the prologue) waited for it.
-        read_patch((int)(gchunk % G::NBUF));
+        patch_bases((int)(gchunk % G::NBUF));
+        read_patch();
         read_b((int)(gchunk % G::NBUF), 0, Bc);
 #pragma unroll
         for (int x = 0; x < 16; ++x)
@@ -454,16 +476,17 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
             const int buf = (int)(gchunk % G::NBUF), nbuf = (int)((gchunk + 1) % G::NBUF);
             WINO_SUBSTEP(1, buf, (void)0, (void)0, false);
             WINO_SUBSTEP(2, buf, (void)0, (void)0, false);
-            WINO_SUBSTEP(3, buf, (void)0, (void)0, false);
+            WINO_SUBSTEP(3, buf, load_avoff(av_), patch_bases(nbuf), false);      // (the cursor's byte offsets: requested a sub-step ahead of the DMA pieces)
             // Chunk boundary.  Every wave has pulled chunk k into registers (lgkmcnt(0): its LDS reads are complete) and its own
             // pieces of chunk k+1 have landed; the pieces of chunk k+2 stay in flight (in-order completion: vmcnt(NPC)).  Spelled
             // out with a bare s_barrier: __syncthreads() would drain vmcnt to what hipcc thinks the ds_reads need (it does not
             // know that the LDS-DMA feeds them).
             if (!(ABL & 8)) {
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NPC) : "memory");
+                __builtin_amdgcn_s_waitcnt(wino_waitcnt(NPC, 0));
                 __builtin_amdgcn_s_barrier();
             }
-            if (k + 1 < C8 && !(ABL & 64)) read_patch(nbuf);
+            // (the patch of chunk k + 1 is read behind the boundary sub-step's first MFMA — unconditionally, also at an item's last chunk
+            // where it is not used: a branch gives LLVM's code sinking a block to move the previous transform into)
             // last 16 MFMAs of chunk k; underneath: chunk gchunk + 3 into the buffer just released, B fragments and transform
             // of (k + 1, j = 0)
             WINO_BOUNDARY(nbuf, buf);
@@ -476,15 +499,15 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
             const int co = ccur.nb * 32 + (ole & 31);
             const int coc = co < a.Cout ? co : a.Cout - 1;
             if (!EXT) {
-                wino_epilogue<RTX, 0>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half);
+                wino_epilogue<RTX, 0>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half, cst[co], cst[G::MAXCO + co], cst[2 * G::MAXCO + co]);
             } else {
                 switch (a.act) {
-                    case 0: wino_epilogue<RTX, 10>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half); break;
-                    case 1: wino_epilogue<RTX, 11>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half); break;
-                    case 2: wino_epilogue<RTX, 12>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half); break;
-                    case 3: wino_epilogue<RTX, 13>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half); break;
-                    case 4: wino_epilogue<RTX, 14>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half); break;
-                    default: wino_epilogue<RTX, 15>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half); break;
+                    case 0: wino_epilogue<RTX, 10>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half, cst[co], cst[G::MAXCO + co], cst[2 * G::MAXCO + co]); break;
+                    case 1: wino_epilogue<RTX, 11>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half, cst[co], cst[G::MAXCO + co], cst[2 * G::MAXCO + co]); break;
+                    case 2: wino_epilogue<RTX, 12>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half, cst[co], cst[G::MAXCO + co], cst[2 * G::MAXCO + co]); break;
+                    case 3: wino_epilogue<RTX, 13>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half, cst[co], cst[G::MAXCO + co], cst[2 * G::MAXCO + co]); break;
+                    case 4: wino_epilogue<RTX, 14>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half, cst[co], cst[G::MAXCO + co], cst[2 * G::MAXCO + co]); break;
+                    default: wino_epilogue<RTX, 15>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half, cst[co], cst[G::MAXCO + co], cst[2 * G::MAXCO + co]); break;
                 }
             }
         }
@@ -552,7 +575,7 @@ bool conv_wino_eligible(const ConvArgs& a) {
     const int mode = conv_wino_mode(-1);
     if (mode == 1) return false;
     if (a.ntaps != 9 || a.Hout != a.Hin || a.Wout != a.Win || a.in_plane || a.out_mode != 0) return false;
-    if (a.Cin_p % 8 || a.Cout_p % 32) return false;
+    if (a.Cin_p % 8 || a.Cout_p % 32 || a.Cout_p > 1024) return false;
     if ((long)a.Hin * a.Win * a.in_cs * 4 >= 0x7fffffffL || (long)a.Hin * a.Win * a.out_cs * 4 >= 0x7fffffffL) return false;
     if (a.res && (long)a.Hin * a.Win * a.res_cs * 4 >= 0x7fffffffL) return false;
     if (mode == 2) return true;
@@ -595,7 +618,7 @@ static int wino_launch_t(WinoArgs& p, hipStream_t s, const char* name) {
 int conv_wino_launch(const ConvArgs& a, int variant, hipStream_t s, const char* name) {
     VFI_REQUIRE(a.ntaps == 9 && a.Hout == a.Hin && a.Wout == a.Win && !a.in_plane && a.out_mode == 0,
                 "conv_wino %s: 3x3 stride-1 NHWC layers only", name);
-    VFI_REQUIRE(a.Cin_p % 8 == 0 && a.Cout_p % 32 == 0 && a.in_cs >= a.Cin_p && a.in_cs % 4 == 0, "conv_wino %s: bad channel padding Cin_p=%d Cout_p=%d in_cs=%d",
+    VFI_REQUIRE(a.Cin_p % 8 == 0 && a.Cout_p % 32 == 0 && a.Cout_p <= 1024 && a.in_cs >= a.Cin_p && a.in_cs % 4 == 0, "conv_wino %s: bad channel padding Cin_p=%d Cout_p=%d in_cs=%d",
                 name, a.Cin_p, a.Cout_p, a.in_cs);
     VFI_REQUIRE(((uintptr_t)a.in & 15) == 0 && ((uintptr_t)a.w & 15) == 0, "conv_wino %s: unaligned pointers", name);
     VFI_REQUIRE((long)a.Hin * a.Win * a.in_cs * 4 < 0x7fffffffL, "conv_wino %s: image larger than 2 GiB", name);
