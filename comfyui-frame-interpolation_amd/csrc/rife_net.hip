@@ -430,6 +430,14 @@ static int load_frame_impl(vfi_rife_t* net, int slot, const float* f32, const un
     hipStream_t st = (hipStream_t)stream;
     float* P = net->Ppool.p + (size_t)slot * net->pack_stride();
     const int Hp = net->Hp, Wp = net->Wp;
+    // arch 4.7 (encode = Conv(3,16,s2) -> Deconv(16,4), no activation, no mid convs): the whole pack in one launch, the half-resolution
+    // tensor E never reaches HBM.  VFI_RIFE_FUSE_ENCODE=0 keeps the three kernels (A/B measurements, the bit-identity test).
+    static const bool fuse_encode = [] {
+        const char* e = getenv("VFI_RIFE_FUSE_ENCODE");
+        return !(e && e[0] == '0');
+    }();
+    if (fuse_encode && net->n_mid == 0 && net->CM == 16 && net->CF == 4 && !net->enc_act && net->NF == 1)
+        return encode47_fused_launch(f32, u8, P, net->enc_w0.p, net->enc_b0.p, net->enc_w1.p, net->enc_b1.p, net->H, net->W, C, Hp, Wp, st);
     if (u8 ? prep_frame_u8_launch(u8, P, net->H, net->W, C, Hp, Wp, st) : prep_frame_launch(f32, P, net->H, net->W, C, Hp, Wp, st))
         return -1;
     if (encode_conv_launch(P, net->E.p, net->enc_w0.p, net->enc_b0.p, net->CM, net->enc_act, Hp, Wp, st)) return -1;

@@ -228,6 +228,138 @@ __global__ void encode_deconv_kernel(const float* __restrict__ E, const float* _
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// arch 4.7 frame pack in ONE launch: clamp / pad + encode.0 (Conv 3->16, 3x3 s2) + encode.1 (ConvTranspose 16->4, 4x4 s2)
+// ---------------------------------------------------------------------------------------
+// The three kernels above move the frame through HBM three times (plane 0 out and back in, the 16-channel half-resolution tensor E
+// out and back in: 75 us per 1080p frame, 2.45 ms per 33-frame bench step).  Here a workgroup owns a 32x32 tile of the pack:
+//   phase 0: its 37x37 source pixels (the tile, + the halo the two convolutions reach) -> LDS, clamped, zero outside the frame;
+//            plane 0 of the tile is written from there;
+//   phase 1: the 18x18 E pixels the transposed convolution needs (16 channels) -> LDS, zero outside the half-resolution image
+//            (that is the transposed convolution's padding, not conv(zeros) + bias);
+//   phase 2: one thread per E pixel of the 16x16 centre = one 2x2 output quad, plane 1 written.
+// Same fmaf order as encode_conv_kernel / encode_deconv_kernel: the pack is bit-identical to the three-kernel path
+// (tests/test_gpu_rife.py::test_fused_frame_pack_is_bit_identical).  E never exists in HBM; HBM traffic 25 + 67 MB per frame.
+constexpr int ENC_T = 32;                      // output tile
+constexpr int ENC_TE = ENC_T / 2 + 2;          // E tile (18)
+constexpr int ENC_TI = 2 * ENC_TE + 1;         // source tile (37)
+
+template <typename SRC>
+__global__ __launch_bounds__(256) void encode47_fused_kernel(const SRC* __restrict__ src, float* __restrict__ P, const float* __restrict__ w0,
+                                                             const float* __restrict__ b0, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                             int H, int W, int C, int Hp, int Wp, int tiles_x) {
+    constexpr int CM = 16, CF = 4;
+    __shared__ __attribute__((aligned(16))) float4 sI[ENC_TI * ENC_TI];
+    __shared__ __attribute__((aligned(16))) float sE[ENC_TE * ENC_TE * CM];
+    const int tid = threadIdx.x;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int Y0 = ty * ENC_T, X0 = tx * ENC_T;            // first output pixel of the tile
+    const int ey0 = Y0 / 2 - 1, ex0 = X0 / 2 - 1;          // first E pixel of the E tile
+    const int iy0 = 2 * ey0 - 1, ix0 = 2 * ex0 - 1;        // first source pixel of the source tile
+    const int He = Hp / 2, We = Wp / 2;
+    // ---- phase 0
+    for (int i = tid; i < ENC_TI * ENC_TI; i += 256) {
+        const int py = i / ENC_TI, px = i - py * ENC_TI;
+        const int Y = iy0 + py, X = ix0 + px;
+        float4 v = {0.f, 0.f, 0.f, 0.f};
+        if (Y >= 0 && Y < H && X >= 0 && X < W) {
+            const SRC* sp = src + ((size_t)Y * W + X) * C;
+            if (sizeof(SRC) == 1) {
+                v.x = __fdiv_rn((float)sp[0], 255.0f);
+                v.y = __fdiv_rn((float)sp[1], 255.0f);
+                v.z = __fdiv_rn((float)sp[2], 255.0f);
+            } else {
+                v.x = fminf(fmaxf((float)sp[0], 0.f), 1.f);
+                v.y = fminf(fmaxf((float)sp[1], 0.f), 1.f);
+                v.z = fminf(fmaxf((float)sp[2], 0.f), 1.f);
+            }
+        }
+        sI[i] = v;
+        // plane 0 of this tile (source-tile offset 3: iy0 = Y0 - 3)
+        if (py >= 3 && py < 3 + ENC_T && px >= 3 && px < 3 + ENC_T && Y < Hp && X < Wp) *(float4*)(P + ((size_t)Y * Wp + X) * 4) = v;
+    }
+    __syncthreads();
+    // ---- phase 1: E tile
+    for (int i = tid; i < ENC_TE * ENC_TE; i += 256) {
+        const int py = i / ENC_TE, px = i - py * ENC_TE;
+        const int ey = ey0 + py, ex = ex0 + px;
+        float acc[CM];
+#pragma unroll
+        for (int co = 0; co < CM; ++co) acc[co] = 0.f;
+        const bool in_img = ey >= 0 && ey < He && ex >= 0 && ex < We;
+        if (in_img) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float4 v = sI[(2 * py + ky) * ENC_TI + 2 * px + kx];      // source pixel (2 ey - 1 + ky, 2 ex - 1 + kx)
+                    const float* wt = w0 + (ky * 3 + kx) * 3 * CM;
+#pragma unroll
+                    for (int co = 0; co < CM; ++co) acc[co] = fmaf(v.z, wt[2 * CM + co], fmaf(v.y, wt[CM + co], fmaf(v.x, wt[co], acc[co])));
+                }
+#pragma unroll
+            for (int co = 0; co < CM; ++co) acc[co] += b0[co];
+        }
+#pragma unroll
+        for (int q = 0; q < CM / 4; ++q) *(float4*)&sE[i * CM + 4 * q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    }
+    __syncthreads();
+    // ---- phase 2: one E pixel of the 16x16 centre per thread -> its 2x2 output quad
+    {
+        const int lx = tid & 15, ly = tid >> 4;
+        const int y = Y0 / 2 + ly, x = X0 / 2 + lx;      // E pixel
+        if (y >= He || x >= We) return;
+        float acc[4][CF];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int co = 0; co < CF; ++co) acc[g][co] = b1[co];
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const float* e = &sE[((ly + 1 + dy) * ENC_TE + lx + 1 + dx) * CM];
+#pragma unroll
+                for (int q = 0; q < CM / 4; ++q) {
+                    const float4 t = *(const float4*)(e + 4 * q);
+                    const float ev[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                    for (int py = 0; py < 2; ++py) {
+                        if (dy < py - 1 || dy > py) continue;
+                        const int ky = py + 1 - 2 * dy;
+#pragma unroll
+                        for (int px = 0; px < 2; ++px) {
+                            if (dx < px - 1 || dx > px) continue;
+                            const int kx = px + 1 - 2 * dx;
+                            const float* wt = w1 + ((ky * 4 + kx) * CM + 4 * q) * CF;
+#pragma unroll
+                            for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+                                for (int co = 0; co < CF; ++co) acc[py * 2 + px][co] = fmaf(ev[ci], wt[ci * CF + co], acc[py * 2 + px][co]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int Y = 2 * y + (g >> 1), X = 2 * x + (g & 1);
+            *(float4*)(P + (size_t)Hp * Wp * 4 + ((size_t)Y * Wp + X) * 4) = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
+        }
+    }
+}
+
+int encode47_fused_launch(const float* f32, const unsigned char* u8, float* P, const float* w0, const float* b0, const float* w1, const float* b1,
+                          int H, int W, int C, int Hp, int Wp, hipStream_t s) {
+    const int tiles_x = cdiv(Wp, ENC_T), tiles_y = cdiv(Hp, ENC_T);
+    TraceScope ts("encode_fused", s);
+    if (u8)
+        hipLaunchKernelGGL(encode47_fused_kernel<unsigned char>, dim3(tiles_x * tiles_y), dim3(256), 0, s, u8, P, w0, b0, w1, b1, H, W, C, Hp, Wp, tiles_x);
+    else
+        hipLaunchKernelGGL(encode47_fused_kernel<float>, dim3(tiles_x * tiles_y), dim3(256), 0, s, f32, P, w0, b0, w1, b1, H, W, C, Hp, Wp, tiles_x);
+    VFI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 int prep_frame_launch(const float* src, float* P, int H, int W, int C, int Hp, int Wp, hipStream_t s) {
     TraceScope ts("prep_frame", s);
     hipLaunchKernelGGL(prep_frame_kernel<float>, dim3(cdiv(Hp * Wp, 256)), dim3(256), 0, s, src, P, H, W, C, Hp, Wp);

@@ -751,3 +751,41 @@ def test_fused_last_transition_matches_unfused(hip_lib, sd, h, w, bs):
             want = torch.cat([rife_oracle.ifnet47_forward(sd, x[p:p + 1], x[p + 1:p + 2], torch.tensor([t]).view(1, 1, 1, 1)) for p, t in tasks])
         want = want.permute(0, 2, 3, 1).clamp(0, 1)
         assert (fused - want).abs().max().item() <= 1e-3, describe_diff(fused, want, "fused path vs oracle")
+
+
+def _pack_dump(path, h, w, u8):
+    """(child-process helper) frame pack of a seeded frame -> file"""
+    from cfi_amd.rife import RifeEngine
+
+    sd_ = synth.rife47_synth_state_dict(1234)
+    eng = RifeEngine(sd_, "4.7")
+    try:
+        eng.configure(h, w, 1, 2, 1.0)
+        fr = synth.smooth_frames(1, h, w, seed=9, shift=1.0, c=4)[0] * 1.3 - 0.15        # RGBA, values outside [0,1]: the clamp
+        if u8:
+            fr = (fr.clamp(0, 1) * 255).round().to(torch.uint8)
+        eng.load_frame(1, fr.cuda().contiguous())
+        hp, wp = -(-h // 64) * 64, -(-w // 64) * 64
+        pk = eng.debug_read(2, 1, hp * wp * 8)
+        np.save(path, pk.numpy())
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("h,w,u8", [(70, 90, False), (1080, 1920, False), (200, 330, True)])
+def test_fused_frame_pack_is_bit_identical(hip_lib, tmp_path, h, w, u8):
+    """arch 4.7: prep + encode.0 + encode.1 in one launch (encode47_fused_kernel, E never in HBM) gives BIT-IDENTICAL frame packs
+    to the three-kernel path (VFI_RIFE_FUSE_ENCODE=0; the switch is read once per process, so each side runs in its own)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ("1", "0"):
+        path = str(tmp_path / f"pack{flag}.npy")
+        code = (f"import sys; sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r}); import conftest, test_gpu_rife as t; "
+                f"t._pack_dump({path!r}, {h}, {w}, {u8})")
+        subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, VFI_RIFE_FUSE_ENCODE=flag), timeout=300)
+        outs.append(np.load(path))
+    assert outs[0].shape == outs[1].shape and np.array_equal(outs[0], outs[1]), float(np.abs(outs[0] - outs[1]).max())
+    assert np.abs(outs[0]).max() > 0.1
