@@ -31,8 +31,9 @@ MODEL_TYPE = "rife"
 DTYPE_OPTIONS = ["float32", "float16", "bfloat16"]
 DTYPE_MAP = {"float32": torch.float32, "float16": torch.float16, "bfloat16": torch.bfloat16}   # rife/__init__.py:23-27
 MAX_LIB_BATCH = 32  # kMaxTasks in csrc/rife_ops.h
-# Tasks are independent and every task's arithmetic is the same whatever it is batched with (only the conv tile variant,
-# i.e. the fp32 summation order, may depend on the launch size: differences ~1e-6), so the node's `batch_size` widget (default 1, rife/__init__.py:68-71) only trades memory for speed.  288 GB of HBM make
+# Tasks are independent and every task's arithmetic is the same whatever it is batched with (bit-exact since round 3: the conv
+# tile variant is chosen from the image, not from the launch), so the node's `batch_size` widget (default 1,
+# rife/__init__.py:68-71) only trades memory for speed.  288 GB of HBM make
 # that trade moot: the node runs at least this many tasks per launch (8 below 4K, 4 from 4K up; 0 = honour the widget).
 MIN_NODE_BATCH = int(os.environ.get("VFI_RIFE_MIN_BATCH", "8"))
 
