@@ -155,7 +155,9 @@ __device__ __forceinline__ void wino_epilogue(const f32x16 (&acc)[16], const Con
 }
 
 // ABL: compile-time ablations for timing experiments only (results become wrong): 1 no activation DMA, 2 no weight DMA, 4 no epilogue,
-// 8 no chunk barrier, 16 no input transform, 32 no B-fragment reads, 64 no patch reads.  The product kernels are ABL = 0.
+// 8 no chunk barrier, 16 no input transform, 32 no B-fragment reads, 64 no patch reads.  0x400 / 0x800 are SCHEDULE variants (results stay
+// right): 0x400 = all DMA pieces of a chunk behind the boundary's MFMAs instead of spread over the sub-steps (r3: 717 vs 749 frames/s);
+// 0x800 = the boundary's 20 LDS reads in one burst behind its first MFMA instead of four per MFMA.
 template <int RTX, bool EXT, int ABL = 0>
 __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -286,12 +288,13 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
                 asm volatile("" : "+v"(pb[dxp * 2 + kk]));      // keep the computation here (LLVM would sink it to the reads)
             }
     };
+    auto read_patch_row = [&](int dy) {
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) P[dy * 4 + dx] = ((const f32x4*)smem)[pb[(dx & 1) * 2 + (dy >> 1)] + (((dy * PW + dx) * 2) & ~3)];
+    };
     auto read_patch = [&]() {
 #pragma unroll
-        for (int dy = 0; dy < 4; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 4; ++dx)
-                P[dy * 4 + dx] = ((const f32x4*)smem)[pb[(dx & 1) * 2 + (dy >> 1)] + (((dy * PW + dx) * 2) & ~3)];
+        for (int dy = 0; dy < 4; ++dy) read_patch_row(dy);
     };
     auto read_b = [&](int buf, int j, f32x4(&B)[4]) {
         const float* sB = smem + buf * G::BUF_FLOATS + 4 * G::A_FLOATS + opaque_lane() * 4;
@@ -343,13 +346,16 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
     };
     // DMA pieces a wave issues per chunk; LDS-DMA completes in order, so "chunk g+1 landed, chunk g+2 may still fly" is vmcnt(NPC)
     constexpr int NPC = ((ABL & 1) ? 0 : NA) + ((ABL & 2) ? 0 : 4);
+    constexpr bool SPREAD = (ABL & 0x400) == 0;     // chunk g + 2 is issued piece by piece DURING chunk g (0x400: chunk g + 3 at g's boundary, all at once)
     dma_issue_all(0);
     dma_advance();
     dma_issue_all(1);
     dma_advance();
-    dma_issue_all(2);
-    dma_advance();
-    __builtin_amdgcn_s_waitcnt(wino_waitcnt(2 * NPC, 0));       // chunk 0 has landed (and the constants are written), chunks 1 and 2 stay in flight
+    if (!SPREAD) {
+        dma_issue_all(2);
+        dma_advance();
+    }
+    __builtin_amdgcn_s_waitcnt(wino_waitcnt(SPREAD ? NPC : 2 * NPC, 0));       // chunk 0 has landed (and the constants are written), the rest stays in flight
     __builtin_amdgcn_s_barrier();
 
 #define WINO_TRANSFORM(J, V)                                                              \
@@ -374,13 +380,14 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
     // its transform (channel JN of the patch in registers) runs behind groups 2 and 3 — at a chunk boundary that leaves the
     // freshly requested patch two MFMA groups to arrive.  sched_barrier(0) pins the groups (left alone hipcc clusters the VALU in
     // front of the MFMAs); PRE is extra work issued behind group 0 / 1 (the chunk DMA at a boundary).
-#define WINO_SUBSTEP(JN, NEXTBUF, PRE0, PRE1, FIRST)                                                                       \
+#define WINO_SUBSTEP(JN, NEXTBUF, PRE0, PRE1, FIRST, SS, IBUF)                                                                     \
     {                                                                                                               \
         float t_[16];                                                                                               \
         _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                          \
             __builtin_amdgcn_sched_barrier(0);                                                                      \
             _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_)                                                        \
                 acc[g_ * 4 + e_] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vc[g_ * 4 + e_], Bc[g_][e_], FIRST ? zero16 : acc[g_ * 4 + e_], 0, 0, 0); \
+            if (SPREAD) dma_slot(SS * 4 + g_, IBUF);                                                                \
             if (g_ == 0) {                                                                                          \
                 if (!(ABL & 32)) read_b(NEXTBUF, JN, Bn);                                                           \
                 PRE0;                                                                                               \
@@ -418,7 +425,7 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
 
     // The sub-step that ends a chunk (its last 16 MFMAs), one step per MFMA, every step pinned: behind MFMA 0 the B fragments of
     // the next sub-step and the cursor's byte offsets are requested; behind MFMAs 1.. ONE LDS-DMA piece each (activation pieces, then
-    // weight pieces) of chunk +3 into the buffer just released; then the cursor advance; the transform of (k + 1, j = 0) rides
+    // weight pieces) of chunk +3 into the buffer just released; the transform of (k + 1, j = 0) rides
     // behind MFMAs 8 .. 15 as in the other sub-steps.
 #define WINO_BOUNDARY(NEXTBUF, RELBUF)                                                                              \
     {                                                                                                               \
@@ -426,14 +433,20 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
         _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) {                                                         \
             __builtin_amdgcn_sched_barrier(0);                                                                      \
             acc[e_] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vc[e_], Bc[e_ >> 2][e_ & 3], acc[e_], 0, 0, 0);          \
-            if (e_ == 0) { /* behind the first MFMA: hipcc cannot see that the boundary's own s_waitcnt emptied lgkmcnt and */ \
-                /* would stall the MFMA on the two oldest of 16 reads issued in front of it (lgkmcnt(14))          */ \
-                if (!(ABL & 64)) read_patch();                                                                      \
-                if (!(ABL & 32)) read_b(NEXTBUF, 0, Bn);                                                            \
+            /* the next chunk's patch (16 reads) and first B fragments (4): four reads behind each of the first five MFMAs.  In one */ \
+            /* burst they overflow the 15-deep LDS queue: the wave cannot issue its next MFMA before the sixth read has returned,  */ \
+            /* with all four waves of the workgroup (just released by the barrier) reading 80 KiB at the same time                 */ \
+            if (ABL & 0x800) {                                                                                      \
+                if (e_ == 0) {                                                                                      \
+                    if (!(ABL & 64)) read_patch();                                                                  \
+                    if (!(ABL & 32)) read_b(NEXTBUF, 0, Bn);                                                        \
+                }                                                                                                   \
+            } else {                                                                                                \
+                if (e_ < 4 && !(ABL & 64)) read_patch_row(e_);                                                      \
+                if (e_ == 4 && !(ABL & 32)) read_b(NEXTBUF, 0, Bn);                                                 \
             }                                                                                                       \
-            if (e_ >= 1 && e_ <= NA && !(ABL & 1)) issue_a(drsrc, e_ - 1, av_[e_ - 1], d_k, RELBUF);                \
-            if (e_ >= NA + 1 && e_ <= NA + 4 && !(ABL & 2)) issue_b(dwrsrc, e_ - NA - 1, dcur.nb, d_k, RELBUF);     \
-            if (e_ == 12) dma_advance();                                                                            \
+            if (!SPREAD && e_ >= 1 && e_ <= NA && !(ABL & 1)) issue_a(drsrc, e_ - 1, av_[e_ - 1], d_k, RELBUF);     \
+            if (!SPREAD && e_ >= NA + 1 && e_ <= NA + 4 && !(ABL & 2)) issue_b(dwrsrc, e_ - NA - 1, dcur.nb, d_k, RELBUF); \
             if (!(ABL & 16)) {                                                                                      \
                 if (e_ >= 8 && e_ < 12) {                                                                           \
                     const int c_ = e_ - 8;                                                                          \
@@ -454,11 +467,21 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
             }                                                                                                       \
         }                                                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                                          \
+        /* the transform's results are consumed HERE: LLVM's code sinking otherwise moves the whole transform below the */ \
+        /* cursor-advance branch that follows, i.e. out from under the MFMAs                                            */ \
+        _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) asm volatile("" : "+v"(Vn[i_]));                          \
         _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) Vc[i_] = Vn[i_];                                          \
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) Bc[i_] = Bn[i_];                                           \
     }
 
     int av_[NA];                         // the DMA cursor's byte offsets of the chunk about to be issued (from the LDS table)
+    // SPREAD: slot = 4 * sub-step + MFMA group (0 .. 11) of the chunk being computed; slot 0 requests the offsets, then one piece per slot
+    auto dma_slot = [&](int slot, int ibuf) {
+        constexpr int S0 = NA <= 6 ? 2 : 1;
+        if (slot == 0) load_avoff(av_);
+        if (slot >= S0 && slot < S0 + NA && !(ABL & 1)) issue_a(drsrc, slot - S0, av_[slot - S0], d_k, ibuf);
+        if (slot >= S0 + NA && slot < S0 + NA + 4 && !(ABL & 2)) issue_b(dwrsrc, slot - S0 - NA, dcur.nb, d_k, ibuf);
+    };
     unsigned gchunk = 0;                 // chunk counter of this workgroup's stream: LDS buffer = gchunk % 3
     for (int it = 0; item(it, ccur); ++it) {
         // An item starts from LDS: nothing but the accumulators is live across the previous item's epilogue (holding the next
@@ -473,10 +496,11 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
             for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
         WINO_TRANSFORM(0, Vc);
         for (int k = 0; k < C8; ++k, ++gchunk) {
-            const int buf = (int)(gchunk % G::NBUF), nbuf = (int)((gchunk + 1) % G::NBUF);
-            WINO_SUBSTEP(1, buf, (void)0, (void)0, false);
-            WINO_SUBSTEP(2, buf, (void)0, (void)0, false);
-            WINO_SUBSTEP(3, buf, load_avoff(av_), patch_bases(nbuf), false);      // (the cursor's byte offsets: requested a sub-step ahead of the DMA pieces)
+            const int buf = (int)(gchunk % G::NBUF), nbuf = buf == G::NBUF - 1 ? 0 : buf + 1;
+            const int ibuf = 3 - buf - nbuf;      // the third buffer (NBUF == 3): released by the previous boundary
+            WINO_SUBSTEP(1, buf, (void)0, (void)0, false, 0, ibuf);
+            WINO_SUBSTEP(2, buf, (void)0, (void)0, false, 1, ibuf);
+            WINO_SUBSTEP(3, buf, if (!SPREAD) load_avoff(av_), patch_bases(nbuf), false, 2, ibuf);      // (the cursor's byte offsets: requested a sub-step ahead of the DMA pieces)
             // Chunk boundary.  Every wave has pulled chunk k into registers (lgkmcnt(0): its LDS reads are complete) and its own
             // pieces of chunk k+1 have landed; the pieces of chunk k+2 stay in flight (in-order completion: vmcnt(NPC)).  Spelled
             // out with a bare s_barrier: __syncthreads() would drain vmcnt to what hipcc thinks the ds_reads need (it does not
@@ -490,6 +514,9 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
             // last 16 MFMAs of chunk k; underneath: chunk gchunk + 3 into the buffer just released, B fragments and transform
             // of (k + 1, j = 0)
             WINO_BOUNDARY(nbuf, buf);
+            // the cursor's advance (a branch: an item change decodes the next item and rewrites the offset table) AFTER the boundary's
+            // straight-line block: inside it, LLVM sank the first half of the transform below the branch, behind 12 bare MFMAs
+            dma_advance();
         }
 
         // ---- epilogue: Y = A^T M A per tile in registers, + bias, * beta, (+ residual), activation, NHWC store
@@ -650,6 +677,8 @@ int conv_wino_launch(const ConvArgs& a, int variant, hipStream_t s, const char* 
         if (abl == 0x80) return wino_launch_t<8, false, 0x80>(p, s, name);
         if (abl == 0x100) return wino_launch_t<8, false, 0x100>(p, s, name);
         if (abl == 0x200) return wino_launch_t<8, false, 0x200>(p, s, name);
+        if (abl == 0x400) return wino_launch_t<8, false, 0x400>(p, s, name);
+        if (abl == 0x800) return wino_launch_t<8, false, 0x800>(p, s, name);
     }
     return ext ? wino_launch_t<8, true>(p, s, name) : wino_launch_t<8, false>(p, s, name);
 }
