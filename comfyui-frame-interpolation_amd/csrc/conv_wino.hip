@@ -92,7 +92,9 @@ __device__ __forceinline__ int wino_div(int n, int d, float inv_d) {
 // image: an out-of-image pixel (or a padded output channel) gets offset 0x80000000 and the hardware drops / zero-fills it —
 // no per-value branches.  MODE 0: the hot form (no residual, none / LeakyReLU with a slope in [0,1]: lrelu(v) = max(v, v*slope));
 // MODE 10 + act: the general form (residual, any activation of ConvArgs::act, post affine).
-template <int RTX, int MODE>
+// FULL: the region lies completely inside the image (wave-uniform, true for all but the last row / column of regions): no
+// row branches and no per-store column test (they were ~260 of the epilogue's 1350 instructions).
+template <int RTX, int MODE, bool FULL = false>
 __device__ __forceinline__ void wino_epilogue(const f32x16 (&acc)[16], const ConvArgs& a, int n, int oy0, int ox0, int co, int coc, int half, float bs,
                                               float bt, float pre) {
     const int H = a.Hin, W = a.Win;
@@ -105,7 +107,7 @@ __device__ __forceinline__ void wino_epilogue(const f32x16 (&acc)[16], const Con
         (void*)(has_res ? a.res + (size_t)n * H * W * a.res_cs : a.out), 0, has_res ? H * W * a.res_cs * 4 : 0, 0x00020000);
     const int xlane = ox0 + 8 * half;          // this lane's first output column; + xq per store
     const bool cok = co < a.Cout;
-    const bool interior = ox0 + 2 * RTX <= W;  // every column of the region is inside the image (wave-uniform)
+    const bool interior = FULL || ox0 + 2 * RTX <= W;  // every column of the region is inside the image (wave-uniform)
     // lane part of the byte offsets in a VGPR (0x80000000 = dropped by the descriptor's range check), per-store part scalar
     const int lane_o = cok ? (xlane * a.out_cs + co) * 4 : (int)0x80000000;
     const int lane_r = cok ? (xlane * a.res_cs + co) * 4 : (int)0x80000000;
@@ -128,12 +130,12 @@ __device__ __forceinline__ void wino_epilogue(const f32x16 (&acc)[16], const Con
 #pragma unroll
         for (int ey = 0; ey < 2; ++ey) {
             const int oy = oy0 + 2 * tyy + ey;          // wave-uniform
-            if (oy < H) {
+            if (FULL || oy < H) {
                 const int rowo = oy * W * a.out_cs * 4, rowr = oy * W * a.res_cs * 4;
 #pragma unroll
                 for (int ex = 0; ex < 2; ++ex) {
                     const int xq = (txx0 >> 3) * 16 + 2 * (txx0 & 7) + ex;     // column inside the region = xq + 8 * half (txx = txx0 + 4 * half)
-                    const bool ok = interior || xlane + xq < W;
+                    const bool ok = FULL || interior || xlane + xq < W;
                     float v = (y[ey * 2 + ex] + bs) * bt;
                     if (MODE == 0) {
                         v = fmaxf(v, v * uslope);
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
                     Vn[r_ * 4 + 3] = t_[r_ * 4 + 1] - t_[r_ * 4 + 3];                                               \
                 }                                                                                                   \
             }                                                                                                       \
-            if (g_ >= 2 && !(ABL & 16)) { /* 16 VALU of the transform: 4 behind each MFMA, not 16 behind the first */               \
+            if (g_ >= 2 && !(ABL & 16) && (ABL & 0x1000)) { /* 0x1000: 4 VALU of the transform behind each MFMA (default: a burst of 16) */ \
                 _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                                  \
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                              \
                     __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                              \
@@ -447,7 +449,25 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
             }                                                                                                       \
             if (!SPREAD && e_ >= 1 && e_ <= NA && !(ABL & 1)) issue_a(drsrc, e_ - 1, av_[e_ - 1], d_k, RELBUF);     \
             if (!SPREAD && e_ >= NA + 1 && e_ <= NA + 4 && !(ABL & 2)) issue_b(dwrsrc, e_ - NA - 1, dcur.nb, d_k, RELBUF); \
-            if (!(ABL & 16)) {                                                                                      \
+            if (!(ABL & 16) && !(ABL & 0x1000)) { /* two bursts of 16 VALU (behind MFMA 8 and MFMA 12): a VALU instruction behind an MFMA */ \
+                /* costs the matrix pipe ~15 cycles once plus ~4 per instruction (tools/micro/mfma_shadow.hip)          */ \
+                if (e_ == 8) {                                                                                      \
+                    _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) {                                              \
+                        const float d0 = P[c_][0], d1 = P[4 + c_][0], d2 = P[8 + c_][0], d3 = P[12 + c_][0];        \
+                        t_[c_] = d0 - d2;                                                                           \
+                        t_[4 + c_] = d1 + d2;                                                                       \
+                        t_[8 + c_] = d2 - d1;                                                                       \
+                        t_[12 + c_] = d1 - d3;                                                                      \
+                    }                                                                                               \
+                } else if (e_ == 12) {                                                                              \
+                    _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                              \
+                        Vn[r_ * 4 + 0] = t_[r_ * 4] - t_[r_ * 4 + 2];                                               \
+                        Vn[r_ * 4 + 1] = t_[r_ * 4 + 1] + t_[r_ * 4 + 2];                                           \
+                        Vn[r_ * 4 + 2] = t_[r_ * 4 + 2] - t_[r_ * 4 + 1];                                           \
+                        Vn[r_ * 4 + 3] = t_[r_ * 4 + 1] - t_[r_ * 4 + 3];                                           \
+                    }                                                                                               \
+                }                                                                                                   \
+            } else if (!(ABL & 16)) {                                                                               \
                 if (e_ >= 8 && e_ < 12) {                                                                           \
                     const int c_ = e_ - 8;                                                                          \
                     const float d0 = P[c_][0], d1 = P[4 + c_][0], d2 = P[8 + c_][0], d3 = P[12 + c_][0];            \
@@ -526,7 +546,10 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
             const int co = ccur.nb * 32 + (ole & 31);
             const int coc = co < a.Cout ? co : a.Cout - 1;
             if (!EXT) {
-                wino_epilogue<RTX, 0>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half, cst[co], cst[G::MAXCO + co], cst[2 * G::MAXCO + co]);
+                if (ccur.Ry0 + RH <= H && ccur.Rx0 + RW <= W)
+                    wino_epilogue<RTX, 0, true>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half, cst[co], cst[G::MAXCO + co], cst[2 * G::MAXCO + co]);
+                else
+                    wino_epilogue<RTX, 0>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half, cst[co], cst[G::MAXCO + co], cst[2 * G::MAXCO + co]);
             } else {
                 switch (a.act) {
                     case 0: wino_epilogue<RTX, 10>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half, cst[co], cst[G::MAXCO + co], cst[2 * G::MAXCO + co]); break;
@@ -679,6 +702,7 @@ int conv_wino_launch(const ConvArgs& a, int variant, hipStream_t s, const char* 
         if (abl == 0x200) return wino_launch_t<8, false, 0x200>(p, s, name);
         if (abl == 0x400) return wino_launch_t<8, false, 0x400>(p, s, name);
         if (abl == 0x800) return wino_launch_t<8, false, 0x800>(p, s, name);
+        if (abl == 0x1000) return wino_launch_t<8, false, 0x1000>(p, s, name);
     }
     return ext ? wino_launch_t<8, true>(p, s, name) : wino_launch_t<8, false>(p, s, name);
 }
