@@ -160,9 +160,10 @@ __device__ __forceinline__ void wino_epilogue(const f32x16 (&acc)[16], const Con
 // 8 no chunk barrier, 16 no input transform, 32 no B-fragment reads, 64 no patch reads.  0x400 / 0x800 are SCHEDULE variants (results stay
 // right): 0x400 = all DMA pieces of a chunk behind the boundary's MFMAs instead of spread over the sub-steps (r3: 717 vs 749 frames/s);
 // 0x800 = the boundary's 20 LDS reads in one burst behind its first MFMA instead of four per MFMA.
-template <int RTX, bool EXT, int ABL = 0>
+template <int RTX, int MODE, int ABL = 0>
 __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    constexpr bool EXT = MODE != 0;      // a general epilogue (wino_epilogue's MODE 10 + act): one kernel per activation, no switch in the item loop
     using G = WinoGeom<RTX>;
     constexpr int PW = G::PW, RW = G::RW, RH = G::RH, NA = G::NA;
     const ConvArgs& a = p.a;
@@ -353,11 +354,12 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
     dma_advance();
     dma_issue_all(1);
     dma_advance();
-    if (!SPREAD) {
+    constexpr bool PK = (ABL & 0x2000) == 0;        // the packed-transform loop (below); 0x2000 = the round-3 scalar loop kept for A/B
+    if (!SPREAD || PK) {
         dma_issue_all(2);
         dma_advance();
     }
-    __builtin_amdgcn_s_waitcnt(wino_waitcnt(SPREAD ? NPC : 2 * NPC, 0));       // chunk 0 has landed (and the constants are written), the rest stays in flight
+    __builtin_amdgcn_s_waitcnt(wino_waitcnt((SPREAD && !PK) ? NPC : 2 * NPC, 0));       // chunk 0 has landed (and the constants are written), the rest stays in flight
     __builtin_amdgcn_s_barrier();
 
 #define WINO_TRANSFORM(J, V)                                                              \
@@ -494,6 +496,184 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) Bc[i_] = Bn[i_];                                           \
     }
 
+
+    if constexpr (PK) {
+        // ================================================================================================================
+        // The K loop with the input transform in PACKED fp32 (v_pk_add_f32 over channel pairs).  In a one-wave-per-SIMD kernel a
+        // VALU instruction is not hidden by the wave's own MFMAs: behind an MFMA it costs the matrix pipe ~15 cycles once plus ~4
+        // cycles per instruction (tools/micro/mfma_shadow.hip; LDS reads, DMA issue and SALU are free).  So: half the transform
+        // instructions (a lane's patch entry is a float4 of 4 channels = two aligned register pairs: channels (0,1) and (2,3) are
+        // transformed together, and the MFMA of channel j takes its A operand straight from the pair's half), in four bursts of 16
+        // per chunk, no register copies (operands ping-pong by name), lane-only address parts held in registers.
+        //   chunk k, sub-step j (16 MFMAs on channel j, A operands VA.x VA.y VB.x VB.y):
+        //     0: B fragments of j=1 | pair (2,3) of chunk k -> VB (from P)       | activation pieces 0,1 of chunk k+3
+        //     1: wait: own activation pieces of chunk k+1 landed | B of j=2 | patch of chunk k+1 -> P | pieces 2..4
+        //     2: B of j=3 | piece 5 (6) | pair (0,1) of chunk k+1 -> VA (from P)
+        //     3: wait: own weight pieces of chunk k+1 landed; BARRIER | B of (k+1, j=0) | weight pieces of chunk k+3
+        //   LDS buffer k % 3 is the target of chunk k+3: its activation image (wave-private) is free since the patch of chunk k
+        //   was read in chunk k-1, its weight tile (shared) once every wave has passed chunk k's barrier with its reads complete.
+        //   LDS-DMA completes in order, so "landed" is a compile-time vmcnt: what was issued after the pieces in question.
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 VA[16], VB[16], t2[16];
+        f32x4 Be[4], Bo[4];
+        int avp[NA];
+        constexpr int NAe = (ABL & 1) ? 0 : NA, NBe = (ABL & 2) ? 0 : 4;
+        constexpr int W1 = NBe + NAe + NBe + (NAe < 2 ? NAe : 2);      // sub-step 1: newer than the activation pieces of chunk k+1
+        constexpr int W3 = NAe + NBe + NAe;                            // sub-step 3: newer than the weight pieces of chunk k+1
+        // lane-only parts, once: patch read slots (4), the weight pieces' lane offset, the offset table's lane address
+        // (the general-epilogue kernels recompute them per chunk: four more registers live through their epilogue were a scratch
+        // reload there — behind s_waitcnt vmcnt(0), i.e. behind all LDS-DMA in flight)
+        int plane[4];
+        auto lane_bases = [&](int(&out)[4]) {
+            const int ol = opaque_lane();
+            const int half = ol >> 5, ty = (ol & 31) / RTX, tx = (ol & 31) % RTX;
+            const int base = (2 * ty * PW + 2 * tx) * 2;
+#pragma unroll
+            for (int dxp = 0; dxp < 2; ++dxp)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) out[dxp * 2 + kk] = wave * (G::A_FLOATS / 4) + base + ((half + 2 * dxp) ^ ((ty + kk) & 3));
+        };
+        if (!EXT) lane_bases(plane);
+        auto pk_bases = [&](int buf) {
+            if (EXT) {
+                lane_bases(pb);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    pb[i] += buf * (G::BUF_FLOATS / 4);
+                    asm volatile("" : "+v"(pb[i]));
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pb[i] = plane[i] + buf * (G::BUF_FLOATS / 4);
+            }
+        };
+        // v_pk_add_f32 by hand: LLVM scalarises every <2 x float> fsub (and folds fma(b, -1, a) back into one)
+        auto pk_add = [](f32x2 x, f32x2 y) {
+            f32x2 r;
+            asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+            return r;
+        };
+        auto pk_sub = [](f32x2 x, f32x2 y) {
+            f32x2 r;
+            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y));
+            return r;
+        };
+        auto tf1 = [&](int hi) {       // rows: t = B^T d, for the channel pair (0,1) (hi = 0) or (2,3) (hi = 1)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x2 d0 = hi ? P[c].hi : P[c].lo, d1 = hi ? P[4 + c].hi : P[4 + c].lo, d2 = hi ? P[8 + c].hi : P[8 + c].lo,
+                            d3 = hi ? P[12 + c].hi : P[12 + c].lo;
+                t2[c] = pk_sub(d0, d2);
+                t2[4 + c] = pk_add(d1, d2);
+                t2[8 + c] = pk_sub(d2, d1);
+                t2[12 + c] = pk_sub(d1, d3);
+            }
+        };
+        auto tf2 = [&](f32x2(&V)[16]) {       // columns: V = t B
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                V[r * 4 + 0] = pk_sub(t2[r * 4], t2[r * 4 + 2]);
+                V[r * 4 + 1] = pk_add(t2[r * 4 + 1], t2[r * 4 + 2]);
+                V[r * 4 + 2] = pk_sub(t2[r * 4 + 2], t2[r * 4 + 1]);
+                V[r * 4 + 3] = pk_sub(t2[r * 4 + 1], t2[r * 4 + 3]);
+            }
+        };
+#define WINO_MF4(G_, V_, C_, B_)                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_)                                                                    \
+        acc[(G_) * 4 + e_] = __builtin_amdgcn_mfma_f32_32x32x2f32(V_[(G_) * 4 + e_].C_, B_[G_][e_], acc[(G_) * 4 + e_], 0, 0, 0);
+#define WINO_A(I_) if (!(ABL & 1) && (I_) < NA) issue_a(drsrc, (I_), avp[(I_) < NA ? (I_) : 0], d_k, buf)
+#define WINO_B(I_) if (!(ABL & 2)) issue_b(dwrsrc, (I_), dcur.nb, d_k, buf)
+        unsigned gchunk = 0;                 // chunk counter of this workgroup's stream: LDS buffer = gchunk % 3
+        for (int it = 0; item(it, ccur); ++it) {
+            // An item starts from LDS (nothing but the accumulators crosses the previous item's epilogue): its first chunk landed and
+            // became visible in the previous chunk's sub-steps 1 / 3 (or the prologue).
+            pk_bases((int)(gchunk % G::NBUF));
+            read_patch();
+            read_b((int)(gchunk % G::NBUF), 0, Be);
+#pragma unroll
+            for (int x = 0; x < 16; ++x)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+            tf1(0);
+            tf2(VA);
+            for (int k = 0; k < C8; ++k, ++gchunk) {
+                const int buf = (int)(gchunk % G::NBUF), nbuf = buf == G::NBUF - 1 ? 0 : buf + 1;
+                // ---- sub-step 0
+                WINO_MF4(0, VA, x, Be);
+                if (!(ABL & 32)) read_b(buf, 1, Bo);
+                load_avoff(avp);
+                WINO_MF4(1, VA, x, Be);
+                if (!(ABL & 16)) tf1(1);
+                WINO_MF4(2, VA, x, Be);
+                if (!(ABL & 16)) tf2(VB);
+                WINO_MF4(3, VA, x, Be);
+                WINO_A(0);
+                WINO_A(1);
+                pk_bases(nbuf);
+                // ---- sub-step 1
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(wino_waitcnt(W1, 15));
+                WINO_MF4(0, VA, y, Bo);
+                if (!(ABL & 32)) read_b(buf, 2, Be);
+                if (!(ABL & 64)) read_patch_row(0);
+                WINO_MF4(1, VA, y, Bo);
+                if (!(ABL & 64)) read_patch_row(1);
+                WINO_A(2);
+                WINO_MF4(2, VA, y, Bo);
+                if (!(ABL & 64)) read_patch_row(2);
+                WINO_A(3);
+                WINO_MF4(3, VA, y, Bo);
+                if (!(ABL & 64)) read_patch_row(3);
+                WINO_A(4);
+                // ---- sub-step 2
+                WINO_MF4(0, VB, x, Be);
+                if (!(ABL & 32)) read_b(buf, 3, Bo);
+                WINO_A(5);
+                WINO_MF4(1, VB, x, Be);
+                if (!(ABL & 16)) tf1(0);
+                WINO_MF4(2, VB, x, Be);
+                if (!(ABL & 16)) tf2(VA);
+                WINO_MF4(3, VB, x, Be);
+                WINO_A(6);
+                // ---- sub-step 3
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(ABL & 8)) {
+                    __builtin_amdgcn_s_waitcnt(wino_waitcnt(W3, 0));
+                    __builtin_amdgcn_s_barrier();
+                }
+                WINO_MF4(0, VB, y, Bo);
+                if (!(ABL & 32)) read_b(nbuf, 0, Be);
+                WINO_B(0);
+                WINO_MF4(1, VB, y, Bo);
+                WINO_B(1);
+                WINO_MF4(2, VB, y, Bo);
+                WINO_B(2);
+                WINO_MF4(3, VB, y, Bo);
+                WINO_B(3);
+                __builtin_amdgcn_sched_barrier(0);
+                // the next chunk's operands are consumed HERE: LLVM's code sinking otherwise moves their computation below the
+                // cursor-advance branch that follows, out from under the MFMAs
+#pragma unroll
+                for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(VA[i]));
+                dma_advance();
+            }
+        // ---- epilogue: Y = A^T M A per tile in registers, + bias, * beta, (+ residual), activation, NHWC store
+            if (ccur.valid && !(ABL & 4)) {
+                const int ole = opaque_lane();
+                const int half = ole >> 5;
+                const int co = ccur.nb * 32 + (ole & 31);
+                const int coc = co < a.Cout ? co : a.Cout - 1;
+                if (ccur.Ry0 + RH <= H && ccur.Rx0 + RW <= W)
+                    wino_epilogue<RTX, MODE, true>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half, cst[co], cst[G::MAXCO + co], cst[2 * G::MAXCO + co]);
+                else
+                    wino_epilogue<RTX, MODE, false>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half, cst[co], cst[G::MAXCO + co], cst[2 * G::MAXCO + co]);
+            }
+        }
+#undef WINO_MF4
+#undef WINO_A
+#undef WINO_B
+    } else {
     int av_[NA];                         // the DMA cursor's byte offsets of the chunk about to be issued (from the LDS table)
     // SPREAD: slot = 4 * sub-step + MFMA group (0 .. 11) of the chunk being computed; slot 0 requests the offsets, then one piece per slot
     auto dma_slot = [&](int slot, int ibuf) {
@@ -545,22 +725,12 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
             const int half = ole >> 5;
             const int co = ccur.nb * 32 + (ole & 31);
             const int coc = co < a.Cout ? co : a.Cout - 1;
-            if (!EXT) {
-                if (ccur.Ry0 + RH <= H && ccur.Rx0 + RW <= W)
-                    wino_epilogue<RTX, 0, true>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half, cst[co], cst[G::MAXCO + co], cst[2 * G::MAXCO + co]);
-                else
-                    wino_epilogue<RTX, 0>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half, cst[co], cst[G::MAXCO + co], cst[2 * G::MAXCO + co]);
-            } else {
-                switch (a.act) {
-                    case 0: wino_epilogue<RTX, 10>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half, cst[co], cst[G::MAXCO + co], cst[2 * G::MAXCO + co]); break;
-                    case 1: wino_epilogue<RTX, 11>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half, cst[co], cst[G::MAXCO + co], cst[2 * G::MAXCO + co]); break;
-                    case 2: wino_epilogue<RTX, 12>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half, cst[co], cst[G::MAXCO + co], cst[2 * G::MAXCO + co]); break;
-                    case 3: wino_epilogue<RTX, 13>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half, cst[co], cst[G::MAXCO + co], cst[2 * G::MAXCO + co]); break;
-                    case 4: wino_epilogue<RTX, 14>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half, cst[co], cst[G::MAXCO + co], cst[2 * G::MAXCO + co]); break;
-                    default: wino_epilogue<RTX, 15>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half, cst[co], cst[G::MAXCO + co], cst[2 * G::MAXCO + co]); break;
-                }
-            }
+            if (ccur.Ry0 + RH <= H && ccur.Rx0 + RW <= W)
+                wino_epilogue<RTX, MODE, true>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half, cst[co], cst[G::MAXCO + co], cst[2 * G::MAXCO + co]);
+            else
+                wino_epilogue<RTX, MODE, false>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half, cst[co], cst[G::MAXCO + co], cst[2 * G::MAXCO + co]);
         }
+    }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the tail's dummy pieces write (zeros) into this workgroup's LDS: drain before exit
 #undef WINO_BOUNDARY
@@ -633,7 +803,7 @@ bool conv_wino_eligible(const ConvArgs& a) {
     return regions / 4 * (a.Cout_p / 32) >= 192;
 }
 
-template <int RTX, bool EXT, int ABL = 0>
+template <int RTX, int MODE, int ABL = 0>
 static int wino_launch_t(WinoArgs& p, hipStream_t s, const char* name) {
     using G = WinoGeom<RTX>;
     ConvArgs& a = p.a;
@@ -649,7 +819,7 @@ static int wino_launch_t(WinoArgs& p, hipStream_t s, const char* name) {
     VFI_REQUIRE(dev >= 0 && dev < kMaxDevices, "conv_wino %s: device index %d out of range", name, dev);
     static std::atomic<int> attr_set[kMaxDevices];
     if (!attr_set[dev].load(std::memory_order_acquire)) {
-        VFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<RTX, EXT, ABL>),
+        VFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<RTX, MODE, ABL>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
         attr_set[dev].store(1, std::memory_order_release);
     }
@@ -660,7 +830,7 @@ static int wino_launch_t(WinoArgs& p, hipStream_t s, const char* name) {
     static const int xcd = [] { const char* e = getenv("VFI_WINO_XCD"); return (e && e[0] == '0') ? 0 : 1; }();     // A/B hook
     p.xcd_map = xcd;
     TraceScope ts(name, s);
-    hipLaunchKernelGGL((conv_wino_kernel<RTX, EXT, ABL>), dim3(grid), dim3(256), G::LDS_BYTES, s, p);
+    hipLaunchKernelGGL((conv_wino_kernel<RTX, MODE, ABL>), dim3(grid), dim3(256), G::LDS_BYTES, s, p);
     VFI_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -689,22 +859,28 @@ int conv_wino_launch(const ConvArgs& a, int variant, hipStream_t s, const char* 
                 "conv_wino %s: output / residual image larger than 2 GiB", name);
     // the hot epilogue: no residual, no post affine, none / LeakyReLU with a slope in [0,1]
     const bool ext = a.res != nullptr || a.post_scale != 0.f || !(a.act == 0 || (a.act == 1 && a.slope >= 0.f && a.slope <= 1.f));
-    if (variant == 16) return ext ? wino_launch_t<16, true>(p, s, name) : wino_launch_t<16, false>(p, s, name);
-    if (!ext) {     // timing experiments: VFI_WINO_ABLATE selects a compile-time ablated copy of the hot kernel (see ABL above)
+    VFI_REQUIRE(a.act >= 0 && a.act <= 5, "conv_wino %s: activation code %d", name, a.act);
+    const int mode = ext ? 10 + a.act : 0;      // wino_epilogue's MODE: one kernel per general activation
+    if (!ext && variant == 8) {     // A/B hook: VFI_WINO_ABLATE selects a compile-time variant of the hot kernel (see ABL above)
         static const int abl = [] { const char* e = getenv("VFI_WINO_ABLATE"); return e ? atoi(e) : 0; }();
-        if (abl == 1) return wino_launch_t<8, false, 1>(p, s, name);
-        if (abl == 4) return wino_launch_t<8, false, 4>(p, s, name);
-        if (abl == 15) return wino_launch_t<8, false, 15>(p, s, name);
-        if (abl == 31) return wino_launch_t<8, false, 31>(p, s, name);
-        if (abl == 127) return wino_launch_t<8, false, 127>(p, s, name);
-        if (abl == 0x80) return wino_launch_t<8, false, 0x80>(p, s, name);
-        if (abl == 0x100) return wino_launch_t<8, false, 0x100>(p, s, name);
-        if (abl == 0x200) return wino_launch_t<8, false, 0x200>(p, s, name);
-        if (abl == 0x400) return wino_launch_t<8, false, 0x400>(p, s, name);
-        if (abl == 0x800) return wino_launch_t<8, false, 0x800>(p, s, name);
-        if (abl == 0x1000) return wino_launch_t<8, false, 0x1000>(p, s, name);
+        if (abl == 4) return wino_launch_t<8, 0, 4>(p, s, name);
+        if (abl == 0x2000) return wino_launch_t<8, 0, 0x2000>(p, s, name);
     }
-    return ext ? wino_launch_t<8, true>(p, s, name) : wino_launch_t<8, false>(p, s, name);
+#define WINO_DISPATCH(R_)                                              \
+    switch (mode) {                                                    \
+        case 0: return wino_launch_t<R_, 0>(p, s, name);               \
+        case 10: return wino_launch_t<R_, 10>(p, s, name);             \
+        case 11: return wino_launch_t<R_, 11>(p, s, name);             \
+        case 12: return wino_launch_t<R_, 12>(p, s, name);             \
+        case 13: return wino_launch_t<R_, 13>(p, s, name);             \
+        case 14: return wino_launch_t<R_, 14>(p, s, name);             \
+        default: return wino_launch_t<R_, 15>(p, s, name);             \
+    }
+    if (variant == 16) {
+        WINO_DISPATCH(16)
+    }
+    WINO_DISPATCH(8)
+#undef WINO_DISPATCH
 }
 
 }  // namespace vfi
