@@ -19,8 +19,11 @@
 //     B operands of 4 MFMAs;
 //   * the output transform A^T M A runs in registers on the accumulator layout (lane = output channel, register = tile),
 //     fused with bias, beta, residual, activation and the NHWC store (32 lanes = 128 contiguous bytes per pixel);
-//   * K pipeline: 8-channel chunks, three LDS buffers, the DMA queue two chunks ahead across work-item boundaries; the patch
-//     of chunk k+1 is read right after the chunk barrier and transformed UNDER the last 16 MFMAs of chunk k;
+//   * K pipeline: 8-channel chunks, three LDS buffers, the DMA queue three chunks ahead across work-item boundaries.  A wave's own
+//     VALU work is NOT hidden by its MFMAs (one wave per SIMD: ~15 cycles of matrix-pipe time per VALU burst + ~4 per
+//     instruction, tools/micro/mfma_shadow.hip — LDS reads, DMA issue and SALU are free), so the transform runs in packed fp32
+//     (v_pk_add_f32 over channel pairs: half the instructions) in four bursts per chunk, operands ping-pong by name (no
+//     copies), and the one barrier per chunk sits only in front of the shared weight reads;
 //   * regions are wave-private (each wave DMA's its own halo'd patch: only the weight tile is shared by the workgroup), so
 //     image sizes quantise to 16x8 (or 32x4) pixels instead of a 4-wave tile;
 //   * persistent workgroups, XCD-aware work order: the Cout/32 siblings of one region quad run on the SAME XCD at the same
@@ -157,9 +160,7 @@ __device__ __forceinline__ void wino_epilogue(const f32x16 (&acc)[16], const Con
 }
 
 // ABL: compile-time ablations for timing experiments only (results become wrong): 1 no activation DMA, 2 no weight DMA, 4 no epilogue,
-// 8 no chunk barrier, 16 no input transform, 32 no B-fragment reads, 64 no patch reads.  0x400 / 0x800 are SCHEDULE variants (results stay
-// right): 0x400 = all DMA pieces of a chunk behind the boundary's MFMAs instead of spread over the sub-steps (r3: 717 vs 749 frames/s);
-// 0x800 = the boundary's 20 LDS reads in one burst behind its first MFMA instead of four per MFMA.
+// 8 no chunk barrier, 16 no input transform, 32 no B-fragment reads, 64 no patch reads.  The product kernels are ABL = 0.
 template <int RTX, int MODE, int ABL = 0>
 __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -239,10 +240,10 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
     auto make_rsrc = [&](int n) {
         return __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)n * img_floats), 0, img_floats * 4, 0x00020000);
     };
-    // One DMA piece per call, so that the chunk boundary can put ONE piece behind each MFMA (a piece costs the issuing wave tens of
-    // cycles; ten in a row idle the matrix pipe of a one-wave-per-SIMD kernel).  At the stream's tail the cursor's descriptors are
-    // null (num_records 0: zero fill, no memory traffic): the piece count per chunk — and with it the vmcnt arithmetic of the
-    // boundary — never changes, and no branch is needed.
+    // One DMA piece per call: the K loop spreads a chunk's pieces over its MFMA groups (ten in a row back up the texture
+    // addresser, which all four waves of the workgroup share, and stall the issuing wave).  At the stream's tail the cursor's
+    // descriptors are null (num_records 0: zero fill, no memory traffic): the piece count per chunk — and with it the vmcnt
+    // arithmetic of the loop — never changes, and no branch is needed.
     auto issue_a = [&](const __amdgpu_buffer_rsrc_t& rsrc, int i, int voff, int k, int buf) {
         float* abuf = smem + buf * G::BUF_FLOATS + wave * G::A_FLOATS;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(abuf + i * 256), 16, voff, k * 32, 0, 0);
@@ -256,41 +257,14 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
         const int ol = opaque_lane();
 #pragma unroll
         for (int i = 0; i < NA; ++i) av[i] = avtab[i * 64 + ol];
-        if (ABL & 0x380) {   // access-pattern experiments (same piece count, wrong data): 0x80 fully contiguous pieces, 0x100 / 0x200: 64 / 128
-                             // contiguous bytes per pixel (what a 16- / 32-channel activation chunk would fetch)
-            const int per = (ABL & 0x80) ? 64 : ((ABL & 0x100) ? 4 : 8);
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const int first = __builtin_amdgcn_readfirstlane(av[i]) & 0x7fffffff;
-                av[i] = first + (ol / per) * a.in_cs * 4 + (ol % per) * 16;
-            }
-        }
     };
 
     // ---- patch read offsets (floats inside the wave's A image): 4 lane-dependent bases + compile-time (dy, dx) offsets
     f32x4 P[16];
-    f32x4 Bc[4], Bn[4];
-    float Vc[16], Vn[16];
     f32x16 acc[16];
-    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-
-    // patch read addresses: 4 lane-dependent bases (index (dx & 1) * 2 + (dy >> 1)) + compile-time (dy, dx) offsets.  The bases are
-    // recomputed per chunk (cheaper than four registers held through the loop) — UNDER the MFMAs of the sub-step before the chunk
-    // boundary (patch_bases), pinned there: computed after the barrier they are ~35 VALU in front of the boundary's first MFMA.
+    // patch read addresses (16-byte slots, provably aligned for ds_read_b128): 4 lane-dependent bases (index (dx & 1) * 2 + (dy >> 1),
+    // set per chunk by pk_bases below) + compile-time (dy, dx) offsets
     int pb[4];
-    auto patch_bases = [&](int buf) {
-        const int ol = opaque_lane();
-        const int half = ol >> 5, ty = (ol & 31) / RTX, tx = (ol & 31) % RTX;
-        const int base = (2 * ty * PW + 2 * tx) * 2;     // multiple of 4
-        const int abase = (buf * G::BUF_FLOATS + wave * G::A_FLOATS) / 4;      // in 16-byte slots: keeps the reads provably aligned (ds_read_b128)
-#pragma unroll
-        for (int dxp = 0; dxp < 2; ++dxp)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                pb[dxp * 2 + kk] = abase + base + ((half + 2 * dxp) ^ ((ty + kk) & 3));
-                asm volatile("" : "+v"(pb[dxp * 2 + kk]));      // keep the computation here (LLVM would sink it to the reads)
-            }
-    };
     auto read_patch_row = [&](int dy) {
 #pragma unroll
         for (int dx = 0; dx < 4; ++dx) P[dy * 4 + dx] = ((const f32x4*)smem)[pb[(dx & 1) * 2 + (dy >> 1)] + (((dy * PW + dx) * 2) & ~3)];
@@ -349,155 +323,16 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
     };
     // DMA pieces a wave issues per chunk; LDS-DMA completes in order, so "chunk g+1 landed, chunk g+2 may still fly" is vmcnt(NPC)
     constexpr int NPC = ((ABL & 1) ? 0 : NA) + ((ABL & 2) ? 0 : 4);
-    constexpr bool SPREAD = (ABL & 0x400) == 0;     // chunk g + 2 is issued piece by piece DURING chunk g (0x400: chunk g + 3 at g's boundary, all at once)
     dma_issue_all(0);
     dma_advance();
     dma_issue_all(1);
     dma_advance();
-    constexpr bool PK = (ABL & 0x2000) == 0;        // the packed-transform loop (below); 0x2000 = the round-3 scalar loop kept for A/B
-    if (!SPREAD || PK) {
-        dma_issue_all(2);
-        dma_advance();
-    }
-    __builtin_amdgcn_s_waitcnt(wino_waitcnt((SPREAD && !PK) ? NPC : 2 * NPC, 0));       // chunk 0 has landed (and the constants are written), the rest stays in flight
+    dma_issue_all(2);
+    dma_advance();
+    __builtin_amdgcn_s_waitcnt(wino_waitcnt(2 * NPC, 0));       // chunk 0 has landed (and the constants are written), chunks 1 and 2 stay in flight
     __builtin_amdgcn_s_barrier();
 
-#define WINO_TRANSFORM(J, V)                                                              \
-    {                                                                                     \
-        float t_[16];                                                                     \
-        _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) {                                \
-            const float d0 = P[c_][J], d1 = P[4 + c_][J], d2 = P[8 + c_][J], d3 = P[12 + c_][J]; \
-            t_[c_] = d0 - d2;                                                             \
-            t_[4 + c_] = d1 + d2;                                                         \
-            t_[8 + c_] = d2 - d1;                                                         \
-            t_[12 + c_] = d1 - d3;                                                        \
-        }                                                                                 \
-        _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                \
-            V[r_ * 4 + 0] = t_[r_ * 4] - t_[r_ * 4 + 2];                                  \
-            V[r_ * 4 + 1] = t_[r_ * 4 + 1] + t_[r_ * 4 + 2];                              \
-            V[r_ * 4 + 2] = t_[r_ * 4 + 2] - t_[r_ * 4 + 1];                              \
-            V[r_ * 4 + 3] = t_[r_ * 4 + 1] - t_[r_ * 4 + 3];                              \
-        }                                                                                 \
-    }
-    // One sub-step = the 16 MFMAs of (chunk, j) in 4 groups, with the NEXT sub-step's operands prepared underneath: its B
-    // fragments are requested behind group 0 (hipcc waits lgkmcnt(0) before a fragment's first use: they get 3/4 of a sub-step),
-    // its transform (channel JN of the patch in registers) runs behind groups 2 and 3 — at a chunk boundary that leaves the
-    // freshly requested patch two MFMA groups to arrive.  sched_barrier(0) pins the groups (left alone hipcc clusters the VALU in
-    // front of the MFMAs); PRE is extra work issued behind group 0 / 1 (the chunk DMA at a boundary).
-#define WINO_SUBSTEP(JN, NEXTBUF, PRE0, PRE1, FIRST, SS, IBUF)                                                                     \
-    {                                                                                                               \
-        float t_[16];                                                                                               \
-        _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                          \
-            __builtin_amdgcn_sched_barrier(0);                                                                      \
-            _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_)                                                        \
-                acc[g_ * 4 + e_] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vc[g_ * 4 + e_], Bc[g_][e_], FIRST ? zero16 : acc[g_ * 4 + e_], 0, 0, 0); \
-            if (SPREAD) dma_slot(SS * 4 + g_, IBUF);                                                                \
-            if (g_ == 0) {                                                                                          \
-                if (!(ABL & 32)) read_b(NEXTBUF, JN, Bn);                                                           \
-                PRE0;                                                                                               \
-            } else if (g_ == 1) {                                                                                   \
-                PRE1;                                                                                               \
-            } else if (ABL & 16) {                                                                                  \
-                if (g_ == 2) { _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) Vn[i_] = P[i_][JN]; }              \
-            } else if (g_ == 2) {                                                                                   \
-                _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) {                                                  \
-                    const float d0 = P[c_][JN], d1 = P[4 + c_][JN], d2 = P[8 + c_][JN], d3 = P[12 + c_][JN];        \
-                    t_[c_] = d0 - d2;                                                                               \
-                    t_[4 + c_] = d1 + d2;                                                                           \
-                    t_[8 + c_] = d2 - d1;                                                                           \
-                    t_[12 + c_] = d1 - d3;                                                                          \
-                }                                                                                                   \
-            } else {                                                                                                \
-                _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                                  \
-                    Vn[r_ * 4 + 0] = t_[r_ * 4] - t_[r_ * 4 + 2];                                                   \
-                    Vn[r_ * 4 + 1] = t_[r_ * 4 + 1] + t_[r_ * 4 + 2];                                               \
-                    Vn[r_ * 4 + 2] = t_[r_ * 4 + 2] - t_[r_ * 4 + 1];                                               \
-                    Vn[r_ * 4 + 3] = t_[r_ * 4 + 1] - t_[r_ * 4 + 3];                                               \
-                }                                                                                                   \
-            }                                                                                                       \
-            if (g_ >= 2 && !(ABL & 16) && (ABL & 0x1000)) { /* 0x1000: 4 VALU of the transform behind each MFMA (default: a burst of 16) */ \
-                _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                                  \
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                              \
-                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                              \
-                }                                                                                                   \
-            }                                                                                                       \
-        }                                                                                                           \
-        __builtin_amdgcn_sched_barrier(0);                                                                          \
-        _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) Vc[i_] = Vn[i_];                                          \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) Bc[i_] = Bn[i_];                                           \
-    }
-
-    // The sub-step that ends a chunk (its last 16 MFMAs), one step per MFMA, every step pinned: behind MFMA 0 the B fragments of
-    // the next sub-step and the cursor's byte offsets are requested; behind MFMAs 1.. ONE LDS-DMA piece each (activation pieces, then
-    // weight pieces) of chunk +3 into the buffer just released; the transform of (k + 1, j = 0) rides
-    // behind MFMAs 8 .. 15 as in the other sub-steps.
-#define WINO_BOUNDARY(NEXTBUF, RELBUF)                                                                              \
-    {                                                                                                               \
-        float t_[16];                                                                                               \
-        _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) {                                                         \
-            __builtin_amdgcn_sched_barrier(0);                                                                      \
-            acc[e_] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vc[e_], Bc[e_ >> 2][e_ & 3], acc[e_], 0, 0, 0);          \
-            /* the next chunk's patch (16 reads) and first B fragments (4): four reads behind each of the first five MFMAs.  In one */ \
-            /* burst they overflow the 15-deep LDS queue: the wave cannot issue its next MFMA before the sixth read has returned,  */ \
-            /* with all four waves of the workgroup (just released by the barrier) reading 80 KiB at the same time                 */ \
-            if (ABL & 0x800) {                                                                                      \
-                if (e_ == 0) {                                                                                      \
-                    if (!(ABL & 64)) read_patch();                                                                  \
-                    if (!(ABL & 32)) read_b(NEXTBUF, 0, Bn);                                                        \
-                }                                                                                                   \
-            } else {                                                                                                \
-                if (e_ < 4 && !(ABL & 64)) read_patch_row(e_);                                                      \
-                if (e_ == 4 && !(ABL & 32)) read_b(NEXTBUF, 0, Bn);                                                 \
-            }                                                                                                       \
-            if (!SPREAD && e_ >= 1 && e_ <= NA && !(ABL & 1)) issue_a(drsrc, e_ - 1, av_[e_ - 1], d_k, RELBUF);     \
-            if (!SPREAD && e_ >= NA + 1 && e_ <= NA + 4 && !(ABL & 2)) issue_b(dwrsrc, e_ - NA - 1, dcur.nb, d_k, RELBUF); \
-            if (!(ABL & 16) && !(ABL & 0x1000)) { /* two bursts of 16 VALU (behind MFMA 8 and MFMA 12): a VALU instruction behind an MFMA */ \
-                /* costs the matrix pipe ~15 cycles once plus ~4 per instruction (tools/micro/mfma_shadow.hip)          */ \
-                if (e_ == 8) {                                                                                      \
-                    _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) {                                              \
-                        const float d0 = P[c_][0], d1 = P[4 + c_][0], d2 = P[8 + c_][0], d3 = P[12 + c_][0];        \
-                        t_[c_] = d0 - d2;                                                                           \
-                        t_[4 + c_] = d1 + d2;                                                                       \
-                        t_[8 + c_] = d2 - d1;                                                                       \
-                        t_[12 + c_] = d1 - d3;                                                                      \
-                    }                                                                                               \
-                } else if (e_ == 12) {                                                                              \
-                    _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) {                                              \
-                        Vn[r_ * 4 + 0] = t_[r_ * 4] - t_[r_ * 4 + 2];                                               \
-                        Vn[r_ * 4 + 1] = t_[r_ * 4 + 1] + t_[r_ * 4 + 2];                                           \
-                        Vn[r_ * 4 + 2] = t_[r_ * 4 + 2] - t_[r_ * 4 + 1];                                           \
-                        Vn[r_ * 4 + 3] = t_[r_ * 4 + 1] - t_[r_ * 4 + 3];                                           \
-                    }                                                                                               \
-                }                                                                                                   \
-            } else if (!(ABL & 16)) {                                                                               \
-                if (e_ >= 8 && e_ < 12) {                                                                           \
-                    const int c_ = e_ - 8;                                                                          \
-                    const float d0 = P[c_][0], d1 = P[4 + c_][0], d2 = P[8 + c_][0], d3 = P[12 + c_][0];            \
-                    t_[c_] = d0 - d2;                                                                               \
-                    t_[4 + c_] = d1 + d2;                                                                           \
-                    t_[8 + c_] = d2 - d1;                                                                           \
-                    t_[12 + c_] = d1 - d3;                                                                          \
-                } else if (e_ >= 12) {                                                                              \
-                    const int r_ = e_ - 12;                                                                         \
-                    Vn[r_ * 4 + 0] = t_[r_ * 4] - t_[r_ * 4 + 2];                                                   \
-                    Vn[r_ * 4 + 1] = t_[r_ * 4 + 1] + t_[r_ * 4 + 2];                                               \
-                    Vn[r_ * 4 + 2] = t_[r_ * 4 + 2] - t_[r_ * 4 + 1];                                               \
-                    Vn[r_ * 4 + 3] = t_[r_ * 4 + 1] - t_[r_ * 4 + 3];                                               \
-                }                                                                                                   \
-            } else if (e_ == 8) {                                                                                   \
-                _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) Vn[i_] = P[i_][0];                                \
-            }                                                                                                       \
-        }                                                                                                           \
-        __builtin_amdgcn_sched_barrier(0);                                                                          \
-        /* the transform's results are consumed HERE: LLVM's code sinking otherwise moves the whole transform below the */ \
-        /* cursor-advance branch that follows, i.e. out from under the MFMAs                                            */ \
-        _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) asm volatile("" : "+v"(Vn[i_]));                          \
-        _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) Vc[i_] = Vn[i_];                                          \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) Bc[i_] = Bn[i_];                                           \
-    }
-
-
-    if constexpr (PK) {
+    {
         // ================================================================================================================
         // The K loop with the input transform in PACKED fp32 (v_pk_add_f32 over channel pairs).  In a one-wave-per-SIMD kernel a
         // VALU instruction is not hidden by the wave's own MFMAs: behind an MFMA it costs the matrix pipe ~15 cycles once plus ~4
@@ -673,69 +508,8 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
 #undef WINO_MF4
 #undef WINO_A
 #undef WINO_B
-    } else {
-    int av_[NA];                         // the DMA cursor's byte offsets of the chunk about to be issued (from the LDS table)
-    // SPREAD: slot = 4 * sub-step + MFMA group (0 .. 11) of the chunk being computed; slot 0 requests the offsets, then one piece per slot
-    auto dma_slot = [&](int slot, int ibuf) {
-        constexpr int S0 = NA <= 6 ? 2 : 1;
-        if (slot == 0) load_avoff(av_);
-        if (slot >= S0 && slot < S0 + NA && !(ABL & 1)) issue_a(drsrc, slot - S0, av_[slot - S0], d_k, ibuf);
-        if (slot >= S0 + NA && slot < S0 + NA + 4 && !(ABL & 2)) issue_b(dwrsrc, slot - S0 - NA, dcur.nb, d_k, ibuf);
-    };
-    unsigned gchunk = 0;                 // chunk counter of this workgroup's stream: LDS buffer = gchunk % 3
-    for (int it = 0; item(it, ccur); ++it) {
-        // An item starts from LDS: nothing but the accumulators is live across the previous item's epilogue (holding the next
-        // item's patch / operands in registers through it made hipcc spill ~100 registers per item).  Its first chunk has landed:
-        // the boundary that ended the previous item (or the prologue) waited for it.
-        patch_bases((int)(gchunk % G::NBUF));
-        read_patch();
-        read_b((int)(gchunk % G::NBUF), 0, Bc);
-#pragma unroll
-        for (int x = 0; x < 16; ++x)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
-        WINO_TRANSFORM(0, Vc);
-        for (int k = 0; k < C8; ++k, ++gchunk) {
-            const int buf = (int)(gchunk % G::NBUF), nbuf = buf == G::NBUF - 1 ? 0 : buf + 1;
-            const int ibuf = 3 - buf - nbuf;      // the third buffer (NBUF == 3): released by the previous boundary
-            WINO_SUBSTEP(1, buf, (void)0, (void)0, false, 0, ibuf);
-            WINO_SUBSTEP(2, buf, (void)0, (void)0, false, 1, ibuf);
-            WINO_SUBSTEP(3, buf, if (!SPREAD) load_avoff(av_), patch_bases(nbuf), false, 2, ibuf);      // (the cursor's byte offsets: requested a sub-step ahead of the DMA pieces)
-            // Chunk boundary.  Every wave has pulled chunk k into registers (lgkmcnt(0): its LDS reads are complete) and its own
-            // pieces of chunk k+1 have landed; the pieces of chunk k+2 stay in flight (in-order completion: vmcnt(NPC)).  Spelled
-            // out with a bare s_barrier: __syncthreads() would drain vmcnt to what hipcc thinks the ds_reads need (it does not
-            // know that the LDS-DMA feeds them).
-            if (!(ABL & 8)) {
-                __builtin_amdgcn_s_waitcnt(wino_waitcnt(NPC, 0));
-                __builtin_amdgcn_s_barrier();
-            }
-            // (the patch of chunk k + 1 is read behind the boundary sub-step's first MFMA — unconditionally, also at an item's last chunk
-            // where it is not used: a branch gives LLVM's code sinking a block to move the previous transform into)
-            // last 16 MFMAs of chunk k; underneath: chunk gchunk + 3 into the buffer just released, B fragments and transform
-            // of (k + 1, j = 0)
-            WINO_BOUNDARY(nbuf, buf);
-            // the cursor's advance (a branch: an item change decodes the next item and rewrites the offset table) AFTER the boundary's
-            // straight-line block: inside it, LLVM sank the first half of the transform below the branch, behind 12 bare MFMAs
-            dma_advance();
-        }
-
-        // ---- epilogue: Y = A^T M A per tile in registers, + bias, * beta, (+ residual), activation, NHWC store
-        if (ccur.valid && !(ABL & 4)) {
-            const int ole = opaque_lane();
-            const int half = ole >> 5;
-            const int co = ccur.nb * 32 + (ole & 31);
-            const int coc = co < a.Cout ? co : a.Cout - 1;
-            if (ccur.Ry0 + RH <= H && ccur.Rx0 + RW <= W)
-                wino_epilogue<RTX, MODE, true>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half, cst[co], cst[G::MAXCO + co], cst[2 * G::MAXCO + co]);
-            else
-                wino_epilogue<RTX, MODE, false>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half, cst[co], cst[G::MAXCO + co], cst[2 * G::MAXCO + co]);
-        }
-    }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the tail's dummy pieces write (zeros) into this workgroup's LDS: drain before exit
-#undef WINO_BOUNDARY
-#undef WINO_SUBSTEP
-#undef WINO_TRANSFORM
 #endif
 }
 
@@ -864,7 +638,6 @@ int conv_wino_launch(const ConvArgs& a, int variant, hipStream_t s, const char* 
     if (!ext && variant == 8) {     // A/B hook: VFI_WINO_ABLATE selects a compile-time variant of the hot kernel (see ABL above)
         static const int abl = [] { const char* e = getenv("VFI_WINO_ABLATE"); return e ? atoi(e) : 0; }();
         if (abl == 4) return wino_launch_t<8, 0, 4>(p, s, name);
-        if (abl == 0x2000) return wino_launch_t<8, 0, 0x2000>(p, s, name);
     }
 #define WINO_DISPATCH(R_)                                              \
     switch (mode) {                                                    \
