@@ -248,15 +248,21 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
         float* abuf = smem + buf * G::BUF_FLOATS + wave * G::A_FLOATS;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(abuf + i * 256), 16, voff, k * 32, 0, 0);
     };
+    // The lane's byte offset inside a 1 KiB piece / fragment row, HELD in a register through the K loop: recomputed per use it was
+    // ~12 isolated VALU instructions per chunk, and an isolated VALU behind an MFMA costs the matrix pipe ~19 cycles
+    // (tools/micro/mfma_shadow.hip).  Re-derived from an opaque lane id at every item start, so that it is not live through the
+    // epilogue: there the register allocator wants every VGPR for the accumulators' way out of the AGPRs and would spill it — and a
+    // scratch reload waits vmcnt(0), i.e. for all LDS-DMA in flight.
+    int lane16 = opaque_lane() * 16;
     auto issue_b = [&](const __amdgpu_buffer_rsrc_t& rsrc, int i, int nb, int k, int buf) {
         float* bbuf = smem + buf * G::BUF_FLOATS + 4 * G::A_FLOATS;
         const int piece = wave + 4 * i;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(bbuf + piece * 256), 16, opaque_lane() * 16, ((nb * C8 + k) * 16 + piece) * 1024, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(bbuf + piece * 256), 16, lane16, ((nb * C8 + k) * 16 + piece) * 1024, 0, 0);
     };
     auto load_avoff = [&](int(&av)[NA]) {
-        const int ol = opaque_lane();
+        const char* const avaddr = (const char*)avtab + (lane16 >> 2);       // this lane's column of the offset table
 #pragma unroll
-        for (int i = 0; i < NA; ++i) av[i] = avtab[i * 64 + ol];
+        for (int i = 0; i < NA; ++i) av[i] = *(const int*)(avaddr + i * 256);
     };
 
     // ---- patch read offsets (floats inside the wave's A image): 4 lane-dependent bases + compile-time (dy, dx) offsets
@@ -274,9 +280,9 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
         for (int dy = 0; dy < 4; ++dy) read_patch_row(dy);
     };
     auto read_b = [&](int buf, int j, f32x4(&B)[4]) {
-        const float* sB = smem + buf * G::BUF_FLOATS + 4 * G::A_FLOATS + opaque_lane() * 4;
+        const char* sB = (const char*)(smem + buf * G::BUF_FLOATS + 4 * G::A_FLOATS) + lane16;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) B[q] = *(const f32x4*)(sB + (j * 4 + q) * 256);
+        for (int q = 0; q < 4; ++q) B[q] = *(const f32x4*)(sB + (j * 4 + q) * 1024);
     };
 
     // ---- per-channel epilogue constants in LDS (bias | beta | PReLU slope, padded channels: 0 | 1 | 0).  A global load in the
@@ -356,8 +362,9 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
         constexpr int W1 = NBe + NAe + NBe + (NAe < 2 ? NAe : 2);      // sub-step 1: newer than the activation pieces of chunk k+1
         constexpr int W3 = NAe + NBe + NAe;                            // sub-step 3: newer than the weight pieces of chunk k+1
         // lane-only parts, once: patch read slots (4), the weight pieces' lane offset, the offset table's lane address
-        // (the general-epilogue kernels recompute them per chunk: four more registers live through their epilogue were a scratch
+        // (the general-epilogue kernels and the 32x4-region form recompute them per chunk: four more registers live through their epilogue were a scratch
         // reload there — behind s_waitcnt vmcnt(0), i.e. behind all LDS-DMA in flight)
+        constexpr bool HOLD = !EXT && RTX == 8;
         int plane[4];
         auto lane_bases = [&](int(&out)[4]) {
             const int ol = opaque_lane();
@@ -368,9 +375,8 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) out[dxp * 2 + kk] = wave * (G::A_FLOATS / 4) + base + ((half + 2 * dxp) ^ ((ty + kk) & 3));
         };
-        if (!EXT) lane_bases(plane);
         auto pk_bases = [&](int buf) {
-            if (EXT) {
+            if (!HOLD) {
                 lane_bases(pb);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -423,6 +429,8 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
         for (int it = 0; item(it, ccur); ++it) {
             // An item starts from LDS (nothing but the accumulators crosses the previous item's epilogue): its first chunk landed and
             // became visible in the previous chunk's sub-steps 1 / 3 (or the prologue).
+            lane16 = opaque_lane() * 16;
+            if (HOLD) lane_bases(plane);
             pk_bases((int)(gchunk % G::NBUF));
             read_patch();
             read_b((int)(gchunk % G::NBUF), 0, Be);
