@@ -90,6 +90,35 @@ __device__ __forceinline__ int wino_div(int n, int d, float inv_d) {
 }
 
 
+// v_pk_*_f32 by hand: LLVM scalarises every <2 x float> fsub (and folds fma(b, -1, a) back into one)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 wino_pk_add(f32x2 x, f32x2 y) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+__device__ __forceinline__ f32x2 wino_pk_sub(f32x2 x, f32x2 y) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+// x + (c.lo, c.lo) and x * (c.hi, c.hi): one register pair (bias, beta) serves both lanes of both operations (op_sel picks the half)
+__device__ __forceinline__ f32x2 wino_pk_add_lo(f32x2 x, f32x2 c) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(x), "v"(c));
+    return r;
+}
+__device__ __forceinline__ f32x2 wino_pk_mul_hi(f32x2 x, f32x2 c) {
+    f32x2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(x), "v"(c));
+    return r;
+}
+__device__ __forceinline__ f32x2 wino_pk_mul(f32x2 x, f32x2 y) {
+    f32x2 r;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+
 // Output transform + fused epilogue of one region (one wave).  acc[xi][r]: lane = output channel (l31), register r = tile
 // m = 8 * (r >> 2) + 4 * half + (r & 3) (MFMA 32x32 D layout).  Stores and residual loads go through buffer descriptors of the
 // image: an out-of-image pixel (or a padded output channel) gets offset 0x80000000 and the hardware drops / zero-fills it —
@@ -114,22 +143,27 @@ __device__ __forceinline__ void wino_epilogue(const f32x16 (&acc)[16], const Con
     // lane part of the byte offsets in a VGPR (0x80000000 = dropped by the descriptor's range check), per-store part scalar
     const int lane_o = cok ? (xlane * a.out_cs + co) * 4 : (int)0x80000000;
     const int lane_r = cok ? (xlane * a.res_cs + co) * 4 : (int)0x80000000;
+    // Two tiles (accumulator registers r, r + 1 = neighbours in x) per step, in packed fp32: the epilogue's VALU work is not hidden by
+    // anything (the wave's MFMAs are over), v_pk_* does two values per instruction in the same order of operations as the scalar form.
+    const f32x2 bsbt = {bs, bt}, sl2 = {uslope, uslope};
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m0 = 8 * (r >> 2) + (r & 3);          // tile index without the lane's half (added through xoff)
+    for (int rp = 0; rp < 8; ++rp) {
+        const int r = 2 * rp;
+        const int m0 = 8 * (r >> 2) + (r & 3);          // tile index of register r without the lane's half (added through xoff); r + 1: the next tile in x
         const int tyy = m0 / RTX, txx0 = m0 % RTX;      // RTX 8: (r >> 2, r & 3); RTX 16: (r >> 3, 8 * ((r >> 2) & 1) + (r & 3))
-        float s0[4], s1[4];
+        f32x2 s0[4], s1[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float q0 = acc[c][r], q1 = acc[4 + c][r], q2 = acc[8 + c][r], q3 = acc[12 + c][r];
-            s0[c] = (q0 + q1) + q2;
-            s1[c] = (q1 - q2) - q3;
+            const f32x2 q0 = {acc[c][r], acc[c][r + 1]}, q1 = {acc[4 + c][r], acc[4 + c][r + 1]}, q2 = {acc[8 + c][r], acc[8 + c][r + 1]},
+                        q3 = {acc[12 + c][r], acc[12 + c][r + 1]};
+            s0[c] = wino_pk_add(wino_pk_add(q0, q1), q2);
+            s1[c] = wino_pk_sub(wino_pk_sub(q1, q2), q3);
         }
-        float y[4];
-        y[0] = (s0[0] + s0[1]) + s0[2];
-        y[1] = (s0[1] - s0[2]) - s0[3];
-        y[2] = (s1[0] + s1[1]) + s1[2];
-        y[3] = (s1[1] - s1[2]) - s1[3];
+        f32x2 y[4];
+        y[0] = wino_pk_add(wino_pk_add(s0[0], s0[1]), s0[2]);
+        y[1] = wino_pk_sub(wino_pk_sub(s0[1], s0[2]), s0[3]);
+        y[2] = wino_pk_add(wino_pk_add(s1[0], s1[1]), s1[2]);
+        y[3] = wino_pk_sub(wino_pk_sub(s1[1], s1[2]), s1[3]);
 #pragma unroll
         for (int ey = 0; ey < 2; ++ey) {
             const int oy = oy0 + 2 * tyy + ey;          // wave-uniform
@@ -137,25 +171,32 @@ __device__ __forceinline__ void wino_epilogue(const f32x16 (&acc)[16], const Con
                 const int rowo = oy * W * a.out_cs * 4, rowr = oy * W * a.res_cs * 4;
 #pragma unroll
                 for (int ex = 0; ex < 2; ++ex) {
-                    const int xq = (txx0 >> 3) * 16 + 2 * (txx0 & 7) + ex;     // column inside the region = xq + 8 * half (txx = txx0 + 4 * half)
-                    const bool ok = FULL || interior || xlane + xq < W;
-                    float v = (y[ey * 2 + ex] + bs) * bt;
-                    if (MODE == 0) {
-                        v = fmaxf(v, v * uslope);
-                    } else {
-                        if (has_res) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrsrc, ok ? lane_r : (int)0x80000000, rowr + xq * a.res_cs * 4, 0));
-                        if (MODE == 11) v = v > 0.f ? v : v * a.slope;
-                        else if (MODE == 12) v = fminf(fmaxf(v, 0.f), 1.f);
-                        else if (MODE == 13) v = v > 0.f ? v : v * pre;
-                        else if (MODE == 14) v = 1.0f / (1.0f + expf(-v));
-                        else if (MODE == 15) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-                        v = v * ps + sh;
+                    f32x2 v2 = wino_pk_mul_hi(wino_pk_add_lo(y[ey * 2 + ex], bsbt), bsbt);
+                    f32x2 w2 = v2;
+                    if (MODE == 0) w2 = wino_pk_mul(v2, sl2);
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {       // tile r (tt = 0) and tile r + 1
+                        const int tx = txx0 + tt;
+                        const int xq = (tx >> 3) * 16 + 2 * (tx & 7) + ex;     // column inside the region = xq + 8 * half (txx = tx + 4 * half)
+                        const bool ok = FULL || interior || xlane + xq < W;
+                        float v = tt ? v2.y : v2.x;
+                        if (MODE == 0) {
+                            asm("v_max_f32 %0, %1, %2" : "=v"(v) : "v"(v), "v"(tt ? w2.y : w2.x));      // (fmaxf on asm results: + 2 canonicalising v_max each)
+                        } else {
+                            if (has_res) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrsrc, ok ? lane_r : (int)0x80000000, rowr + xq * a.res_cs * 4, 0));
+                            if (MODE == 11) v = v > 0.f ? v : v * a.slope;
+                            else if (MODE == 12) v = fminf(fmaxf(v, 0.f), 1.f);
+                            else if (MODE == 13) v = v > 0.f ? v : v * pre;
+                            else if (MODE == 14) v = 1.0f / (1.0f + expf(-v));
+                            else if (MODE == 15) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                            v = v * ps + sh;
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orsrc, ok ? lane_o : (int)0x80000000, rowo + xq * a.out_cs * 4, 0);
                     }
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orsrc, ok ? lane_o : (int)0x80000000, rowo + xq * a.out_cs * 4, 0);
                 }
             }
         }
-        __builtin_amdgcn_sched_barrier(0);   // one tile at a time: left alone, hipcc hoists all 256 accumulator reads (spills)
+        __builtin_amdgcn_sched_barrier(0);   // one tile pair at a time: left alone, hipcc hoists all 256 accumulator reads (spills)
     }
 }
 
@@ -179,8 +220,9 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
     // for the patch / operands.  LICM would hoist every lane-only expression out of the loops and then SPILL it (a scratch reload in
     // the hot loop waits vmcnt(0), i.e. for the LDS-DMA in flight): an opaque copy of the lane id per use keeps them local.
     auto opaque_lane = [&]() {
-        int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));    // lane id from the exec mask: no live register
-        asm volatile("" : "+v"(l));
+        int l;   // lane id from the exec mask, by volatile asm: the builtin form is CSE'd into ONE value that then lives (and, under pressure,
+                 // is spilled) through the whole kernel — its reload at the top of the epilogue sat behind s_waitcnt vmcnt(0)
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
         return l;
     };
     const int img_floats = H * W * a.in_cs;
@@ -354,7 +396,6 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
         //   LDS buffer k % 3 is the target of chunk k+3: its activation image (wave-private) is free since the patch of chunk k
         //   was read in chunk k-1, its weight tile (shared) once every wave has passed chunk k's barrier with its reads complete.
         //   LDS-DMA completes in order, so "landed" is a compile-time vmcnt: what was issued after the pieces in question.
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
         f32x2 VA[16], VB[16], t2[16];
         f32x4 Be[4], Bo[4];
         int avp[NA];
@@ -388,17 +429,8 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
                 for (int i = 0; i < 4; ++i) pb[i] = plane[i] + buf * (G::BUF_FLOATS / 4);
             }
         };
-        // v_pk_add_f32 by hand: LLVM scalarises every <2 x float> fsub (and folds fma(b, -1, a) back into one)
-        auto pk_add = [](f32x2 x, f32x2 y) {
-            f32x2 r;
-            asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
-            return r;
-        };
-        auto pk_sub = [](f32x2 x, f32x2 y) {
-            f32x2 r;
-            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y));
-            return r;
-        };
+        auto pk_add = [](f32x2 x, f32x2 y) { return wino_pk_add(x, y); };
+        auto pk_sub = [](f32x2 x, f32x2 y) { return wino_pk_sub(x, y); };
         auto tf1 = [&](int hi) {       // rows: t = B^T d, for the channel pair (0,1) (hi = 0) or (2,3) (hi = 1)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
