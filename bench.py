@@ -657,7 +657,10 @@ def main():
     dist_extras = None
     if world > 1 and not args.no_extras:
         eng.release() if hasattr(eng, "release") else None
-        dist_extras = other_paths_dist(dev, H, W, world, rank, args.backend)
+        try:
+            dist_extras = other_paths_dist(dev, H, W, world, rank, args.backend)
+        except Exception as e:      # never lose the headline line to the extra legs
+            dist_extras = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         res = result_line(args, world, elapsed, traced, rep, eng,
                           "none" if world == 1 or args.no_gather else
