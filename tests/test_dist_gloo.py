@@ -1,21 +1,11 @@
 """N>1 path on CPU: 2 ranks over gloo shard the task list, 'interpolate' with a stand-in blend and
 all-gather the new frames; the assembled result must equal the single-process result."""
 import os
-import socket
 import sys
 
 import torch
-import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
 
 
 def _blend(frames, tasks):
@@ -53,16 +43,9 @@ def _worker(rank, world, port, q):
 def test_two_rank_gloo_matches_single_process():
     from cfi_amd.schedule import rife_output_plan, rife_task_list
 
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    got = q.get(timeout=120)
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    from mp_util import run_ranks
+
+    got = run_ranks(_worker, 2, timeout=120)
     g = torch.Generator().manual_seed(3)
     frames = torch.rand(6, 8, 10, 3, generator=g)
     _, tasks = rife_task_list(6, [3, 2, 1, 4], None)

@@ -2,12 +2,10 @@
 stand-in engine that calls the oracle model, against the oracle's restatement of generic_frame_loop
 (vfi_utils.py:149-389) — int and list multipliers, skip lists, the m == 0 quirks — single process and 2 ranks (gloo)."""
 import os
-import socket
 import sys
 
 import pytest
 import torch
-import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -84,14 +82,6 @@ def test_run_plan_matches_oracle_loop(multiplier, spec):
             assert torch.equal(got[i], fr[idx])
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -119,16 +109,9 @@ def _worker(rank, world, port, q):
 def test_two_rank_gloo_matches_oracle_loop():
     from oracle import m2m_model_oracle as mo
 
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    got = q.get(timeout=300)
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    from mp_util import run_ranks
+
+    got = run_ranks(_worker, 2, timeout=300)
     sd, fr = _case()
     want = mo.m2m_vfi(sd, fr, [3, 2, 2], None)
     assert got.shape == want.shape and (got - want).abs().max().item() <= 1e-4
