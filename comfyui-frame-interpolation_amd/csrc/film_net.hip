@@ -68,7 +68,7 @@ struct vfi_film {
     // workspace for the current frame size
     int H = 0, W = 0;
     int hw[PYR][2];
-    Ten img[2][PYR], tw[2][PYR], pair[PYR], flow[2][PYR], vres[PYR], vup[PYR], al[FUS];
+    Ten img[2][PYR], tw[2][PYR], flow[2][PYR], vres[PYR], vup[PYR], al[FUS];
     std::map<std::tuple<std::string, int, int, int>, Ten> scratch;
     std::vector<float*> owned;
 };
@@ -104,9 +104,9 @@ int ensure_workspace(vfi_film* n, int H, int W) {
     for (int l = 0; l < PYR; ++l) {
         const int h = n->hw[l][0], w = n->hw[l][1], F = feat_channels(l);
         for (int k = 0; k < 2; ++k) {
-            if (alloc_ten(n, n->img[k][l], h, w, 8) || alloc_ten(n, n->tw[k][l], h, w, 4 + F) || alloc_ten(n, n->flow[k][l], h, w, 2)) return -1;
+            if (alloc_ten(n, n->img[k][l], h, w, 8) || alloc_ten(n, n->tw[k][l], h, w, 4 + 2 * F) || alloc_ten(n, n->flow[k][l], h, w, 2)) return -1;
         }
-        if (alloc_ten(n, n->pair[l], h, w, 2 * F) || alloc_ten(n, n->vres[l], h, w, 2) || alloc_ten(n, n->vup[l], h, w, 2)) return -1;
+        if (alloc_ten(n, n->vres[l], h, w, 2) || alloc_ten(n, n->vup[l], h, w, 2)) return -1;
         if (l < FUS && alloc_ten(n, n->al[l], h, w, n->cal[l] + (l < 4 ? FILTERS << std::min(l, 3) : 0))) return -1;
     }
     n->H = H, n->W = W;
@@ -166,20 +166,23 @@ int extract(vfi_film* n, int k, hipStream_t st) {
 int predict(vfi_film* n, int a, int b, int d, hipStream_t st) {
     for (int l = PYR - 1; l >= 0; --l) {
         const int h = n->hw[l][0], w = n->hw[l][1], F = feat_channels(l);
-        Ten& pair = n->pair[l];
-        if (ax(n->tw[a][l].p + 4, n->tw[a][l].c, nullptr, 0, pair.p, pair.c, h, w, F, 1.f, 0.f, st)) return -1;
+        // torch.cat([features_a, warp(features_b)]) (film_arch.py:606-611) is a channel WINDOW: pyramid a's tensor carries a slot of F
+        // channels behind its own features that the partner's warped features are written into — the flow estimator's first
+        // convolution reads [4, 4 + 2F) of it.  (r2 copied features_a next to the warp result: 14 copies per pair, ~1.5 ms at 1080p.)
+        Ten& pair = n->tw[a][l];
+        const int PO = 4;          // channel offset of the window
         if (l == PYR - 1) {
-            if (ax(n->tw[b][l].p + 4, n->tw[b][l].c, nullptr, 0, pair.p + F, pair.c, h, w, F, 1.f, 0.f, st)) return -1;
+            if (ax(n->tw[b][l].p + 4, n->tw[b][l].c, nullptr, 0, pair.p + PO + F, pair.c, h, w, F, 1.f, 0.f, st)) return -1;
         } else {
             const int h1 = n->hw[l + 1][0], w1 = n->hw[l + 1][1];
             if (vfi_resize_bilinear(n->flow[d][l + 1].p, 2, n->vup[l].p, 2, 1, h1, w1, h, w, 2, 2.0f, st)) return -1;
-            if (vfi_warp_film(n->tw[b][l].p + 4, n->tw[b][l].c, n->vup[l].p, 2, 1.0f, pair.p + F, pair.c, 1, h, w, F, st)) return -1;
+            if (vfi_warp_film(n->tw[b][l].p + 4, n->tw[b][l].c, n->vup[l].p, 2, 1.0f, pair.p + PO + F, pair.c, 1, h, w, F, st)) return -1;
         }
         const Layer* convs = n->pred[std::min(l, 3)];
         const int nf = kFlowFilters[std::min(l, 3)];
         Ten *t0, *t1, *t2;
         if (tmp(n, "fe0", h, w, nf, &t0) || tmp(n, "fe1", h, w, nf, &t1) || tmp(n, "fe2", h, w, r8(nf / 2), &t2)) return -1;
-        if (conv(convs[0], pair, 0, *t0, 0, h, w, 1, st) || conv(convs[1], *t0, 0, *t1, 0, h, w, 1, st) ||
+        if (conv(convs[0], pair, PO, *t0, 0, h, w, 1, st) || conv(convs[1], *t0, 0, *t1, 0, h, w, 1, st) ||
             conv(convs[2], *t1, 0, *t0, 0, h, w, 1, st) || conv(convs[3], *t0, 0, *t2, 0, h, w, 1, st))
             return -1;
         if (l == PYR - 1) {
