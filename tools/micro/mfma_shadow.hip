@@ -36,6 +36,8 @@ __global__ __launch_bounds__(256) void shadow(float* out, int iters, float a0, f
                 if (KIND == 0) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[(k * NV + v) & 15]) : "v"(b0));
                 if (KIND == 1) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(xp[(k * NV + v) & 15]) : "v"(bp));
                 if (KIND == 2) asm volatile("s_add_u32 %0, %0, 7" : "+s"(sx[(k * NV + v) & 7]));
+                if (KIND == 7) asm volatile("s_nop 0");
+                if (KIND == 8) asm volatile("s_nop 3");
             }
             // KIND 3 / 4: the same VALU count in bursts — 4 * NV adds behind every fourth MFMA (4: plus one s_add behind the others)
             if (KIND >= 3) {
@@ -85,7 +87,7 @@ void run() {
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
     const double flop = (double)blocks * 4 * iters * 16.0 * 4096.0;
-    printf("per MFMA: %2d %s + %d ds_read_b128 : %.3f ms  %.1f TFLOP/s (%.3f of 157.3)\n", NV, KIND == 0 ? "v_add_f32" : (KIND == 1 ? "v_pk_add_f32" : (KIND == 2 ? "s_add_u32" : (KIND == 3 ? "v_add_f32 (in bursts behind every 4th MFMA)" : "v_add_f32 (bursts behind every 4th MFMA, s_add behind the others)"))), NL, ms,
+    printf("per MFMA: %2d %s + %d ds_read_b128 : %.3f ms  %.1f TFLOP/s (%.3f of 157.3)\n", NV, KIND == 0 ? "v_add_f32" : (KIND == 1 ? "v_pk_add_f32" : (KIND == 2 ? "s_add_u32" : KIND == 7 ? "s_nop 0" : KIND == 8 ? "s_nop 3" : (KIND == 3 ? "v_add_f32 (in bursts behind every 4th MFMA)" : "v_add_f32 (bursts behind every 4th MFMA, s_add behind the others)"))), NL, ms,
            flop / ms / 1e9, flop / ms / 1e9 / 157.3);
     hipFree(out);
 }
@@ -106,6 +108,10 @@ int main() {
     run<8, 0, 1>();
     run<4, 0, 2>();
     run<8, 0, 2>();
+    run<1, 0, 2>();
+    run<1, 0, 7>();
+    run<2, 0, 7>();
+    run<1, 0, 8>();
     run<2, 0, 3>();
     run<4, 0, 3>();
     run<8, 0, 3>();
