@@ -553,6 +553,369 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
 #endif
 }
 
+// =====================================================================================================================
+// TWO WAVES PER SIMD (experimental, opt-in: VFI_WINO_2WAVE=1 / vfi_conv3x3 variant 102; hot epilogue only, Cout_p <= 256).
+// docs/design/winograd.md section 6 (b): a wave = 16 tiles (16x4 output pixels) x 32 channels x all 16 transform positions on
+// v_mfma_f32_16x16x4_f32 — two 16-channel N blocks x 4 registers x 16 positions = 128 accumulators, so eight waves fit a CU and
+// one wave's patch reads, transform and epilogue run under the other's MFMAs.  No software pipelining inside a wave: waves 0-3
+// do  barrier -> read + transform(g) -> MFMA(g) [-> epilogue],  waves 4-7  barrier -> MFMA(g-1) [-> epilogue] -> read + transform(g),
+// half a chunk out of phase by construction.
+//   lane l = (tile m = l % 16 = ty * 8 + tx, K slot kq = l / 16).  The two MFMAs of a chunk take channels {0,2,4,6} and {1,3,5,7}:
+//   lane kq feeds channels 2kq and 2kq+1 = 8 adjacent bytes of its pixel in the LDS image (ds_read_b64), transformed as ONE
+//   register pair per position (v_pk_add_f32).  The weight pack (pack_wino16) puts the 4 B operands of one position — (MFMA
+//   0/1) x (N block 0/1) — into one 16-byte lane item: 16 ds_read_b128 per chunk.
+//   LDS: activation ring 3 x 8 waves x 4 KiB (wave-private: 18x6 pixels x 32 B), weight ring 3 x 16 KiB (shared), offset table,
+//   constants: 155 KiB.  DMA per iteration g and wave: B(g+1) x 2, then A(g+2) x 4; "chunk g+1 landed" = vmcnt(4).
+struct Wino16 {
+    static constexpr int PW = 18, PH = 6, RW = 16, RH = 4;
+    static constexpr int NITEM = PW * PH * 2;                 // 216 16-byte items per wave and chunk
+    static constexpr int NA = 4;                              // DMA pieces (256 slots)
+    static constexpr int A_FLOATS = NA * 256;
+    static constexpr int B_FLOATS = 4096;
+    static constexpr int NBUF = 3;
+    static constexpr int OFF_B = NBUF * 8 * A_FLOATS;
+    static constexpr int OFF_TAB = OFF_B + NBUF * B_FLOATS;
+    static constexpr int TAB = 8 * NA * 64;
+    static constexpr int MAXCO = 256;
+    static constexpr int OFF_CST = OFF_TAB + TAB;
+    static constexpr int LDS_BYTES = (OFF_CST + 3 * MAXCO) * 4;
+};
+
+__global__ __launch_bounds__(512) void conv_wino16_kernel(const WinoArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using G = Wino16;
+    constexpr int PW = G::PW, NA = G::NA;
+    const ConvArgs& a = p.a;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Which two waves share a SIMD is the hardware's choice (measured: NOT wave % 4 — with groups by wave id the two phases did not
+    // overlap at all): each wave reads its SIMD id and takes a ticket per SIMD (group = first / second wave there: 0: transform ->
+    // MFMA; 1: MFMA(previous chunk) -> transform) and a workgroup-wide ticket for its region slot.
+    int* const tick = (int*)(smem + G::OFF_TAB);           // 5 counters, before the offset table is first written
+    if (tid < 8) tick[tid] = 0;
+    __syncthreads();
+    int grp, slot;
+    {
+        const int simd = (int)(__builtin_amdgcn_s_getreg((2 - 1) << 11 | 4 << 6 | 4)) & 3;       // HW_REG_HW_ID[5:4] = SIMD_ID
+        int g0 = 0, s0 = 0;
+        if ((tid & 63) == 0) {
+            g0 = atomicAdd(&tick[simd], 1);
+            s0 = atomicAdd(&tick[4], 1);
+        }
+        grp = __builtin_amdgcn_readfirstlane(g0) & 1;
+        slot = __builtin_amdgcn_readfirstlane(s0) & 7;
+    }
+    __syncthreads();
+    const int abl = p.xcd_map >> 4;              // timing experiments (VFI_WINO16_ABL; results wrong): 1 no patch reads / transform, 2 no MFMAs,
+                                                 // 4 no B reads, 8 no epilogue, 16 no DMA
+    const int C8 = a.Cin_p >> 3;
+    const int H = a.Hin, W = a.Win;
+    const int img_floats = H * W * a.in_cs;
+    auto lane_id = [&]() {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return l;
+    };
+    struct Cur {
+        int nb, n, Ry0, Rx0;
+        bool valid;
+    };
+    const int gsz = gridDim.x, wg = blockIdx.x;
+    auto item = [&](int i, Cur& c) -> bool {      // as conv_wino_kernel; waves w and w + 4 take the upper / lower half of 16x8 region w
+        int quad;
+        if (p.xcd_map & 1) {
+            const int x = wg & 7, slot = wg >> 3, S = gsz >> 3;
+            const int jl = slot + i * S;
+            const int nqx = x < p.NQ ? (p.NQ - x + 7) >> 3 : 0;
+            if (jl >= nqx * p.NY) return false;
+            const int q = wino_div(jl, p.NY, p.inv_NY);
+            quad = x + 8 * q;
+            c.nb = jl - q * p.NY;
+        } else {
+            const int idx = wg + i * gsz;
+            if (idx >= p.NQ * p.NY) return false;
+            quad = wino_div(idx, p.NY, p.inv_NY);
+            c.nb = idx - quad * p.NY;
+        }
+        const int rg = quad * 4 + (slot & 3);
+        c.valid = rg < p.R;
+        const int rr = c.valid ? rg : 0;
+        const int per = p.rx * p.ry;
+        c.n = wino_div(rr, per, p.inv_per);
+        const int rem = rr - c.n * per;
+        const int ryi = wino_div(rem, p.rx, p.inv_rx);
+        c.Ry0 = ryi * 8 + 4 * (slot >> 2);
+        c.Rx0 = (rem - ryi * p.rx) * 16;
+        return true;
+    };
+    int* const avtab = (int*)(smem + G::OFF_TAB) + slot * (NA * 64);
+    auto make_avoff = [&](const Cur& c) {
+        const int ol = lane_id();
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int sp = i * 64 + ol;                      // slot = stored pixel * 2 + channel quad.  A row stores its 9 even columns, then
+            const int pix = sp >> 1, q = sp & 1;             // its 9 odd ones: the 8 tiles of a row then read 8 CONSECUTIVE 32-byte pixels
+            const int py = pix / PW, pj = pix - py * PW;     // (tiles are 2 pixels apart: interleaved, a read hit every other bank group 4 times)
+            const int px = pj < PW / 2 ? 2 * pj : 2 * (pj - PW / 2) + 1;
+            const int iy = c.Ry0 - 1 + py, ix = c.Rx0 - 1 + px;
+            const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+            const bool ok = sp < G::NITEM && c.valid && (a.pad_replicate || (cy == iy && cx == ix));
+            avtab[i * 64 + ol] = ok ? ((cy * W + cx) * a.in_cs + q * 4) * 4 : (int)0x80000000;
+        }
+    };
+    auto issue_a = [&](const __amdgpu_buffer_rsrc_t& rsrc, int i, int voff, int k, int buf) {
+        float* abuf = smem + (buf * 8 + slot) * G::A_FLOATS;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(abuf + i * 256), 16, voff, k * 32, 0, 0);
+    };
+    int lane16 = lane_id() * 16;
+    auto issue_b = [&](const __amdgpu_buffer_rsrc_t& rsrc, int i, int nb, int k, int buf) {
+        float* bbuf = smem + G::OFF_B + buf * G::B_FLOATS;
+        const int piece = slot + 8 * i;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(bbuf + piece * 256), 16, lane16, ((nb * C8 + k) * 16 + piece) * 1024, 0, 0);
+    };
+    float* const cst = smem + G::OFF_CST;
+    for (int c = tid; c < a.Cout_p; c += 512) {
+        const bool real = c < a.Cout;
+        cst[c] = real ? a.bias[c] : 0.f;
+        cst[G::MAXCO + c] = (real && a.beta) ? a.beta[c] : 1.f;
+    }
+    // ---- DMA cursor (one chunk per step; null descriptors at the stream's tail keep the piece count constant)
+    Cur dcur, ccur;
+    int d_it = 0, d_k = 0;
+    bool d_ok = item(0, dcur);
+    if (!d_ok) return;
+    make_avoff(dcur);
+    auto make_wrsrc = [&](bool live) { return __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, live ? 16 * a.Cin_p * a.Cout_p * 4 : 0, 0x00020000); };
+    auto make_arsrc = [&](int n, bool live) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)n * img_floats), 0, live ? img_floats * 4 : 0, 0x00020000);
+    };
+    // two cursors: weights run one chunk ahead of the compute, activations two
+    __amdgpu_buffer_rsrc_t arsrc = make_arsrc(dcur.n, true);
+    Cur bcur = dcur;
+    int b_it = 0, b_k = 0;
+    bool b_ok = true;
+    __amdgpu_buffer_rsrc_t brsrc = make_wrsrc(true);
+    auto a_issue = [&](int buf) {
+        const int ol = lane_id();
+        int av[NA];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) av[i] = avtab[i * 64 + ol];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) issue_a(arsrc, i, av[i], d_k, buf);
+    };
+    auto a_advance = [&]() {
+        if (d_ok && ++d_k == C8) {
+            d_k = 0;
+            d_ok = item(++d_it, dcur);
+            if (d_ok) make_avoff(dcur);
+            arsrc = make_arsrc(d_ok ? dcur.n : 0, d_ok);
+        }
+    };
+    auto b_issue = [&](int buf) {
+        issue_b(brsrc, 0, bcur.nb, b_k, buf);
+        issue_b(brsrc, 1, bcur.nb, b_k, buf);
+    };
+    auto b_advance = [&]() {
+        if (b_ok && ++b_k == C8) {
+            b_k = 0;
+            b_ok = item(++b_it, bcur);
+            brsrc = make_wrsrc(b_ok);
+            if (!b_ok) bcur.nb = 0;
+        }
+    };
+    // prologue: A(0), B(0), A(1): iteration g then issues B(g+1), A(g+2)
+    a_issue(0);
+    a_advance();
+    b_issue(0);
+    b_advance();
+    a_issue(1);
+    a_advance();
+
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 P[16], V[16];
+    f32x4 acc[16][2];
+    auto read_patch = [&](int buf) {
+        const int ol = lane_id();
+        const int m = ol & 15, kq = ol >> 4;
+        const int base = (((m >> 3) * 2) * PW + (m & 7)) * 32 + kq * 8 + ((buf * 8 + slot) * G::A_FLOATS) * 4;
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx)      // column 2 tx + dx is stored at (dx & 1) * 9 + tx + (dx >> 1)
+                P[dy * 4 + dx] = *(const f32x2*)((const char*)smem + base + (dy * PW + (dx & 1) * (PW / 2) + (dx >> 1)) * 32);
+    };
+    auto transform = [&]() {       // V = B^T d B on the channel pair, row by row
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            f32x2 t[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (r == 0) t[c] = wino_pk_sub(P[c], P[8 + c]);
+                if (r == 1) t[c] = wino_pk_add(P[4 + c], P[8 + c]);
+                if (r == 2) t[c] = wino_pk_sub(P[8 + c], P[4 + c]);
+                if (r == 3) t[c] = wino_pk_sub(P[4 + c], P[12 + c]);
+            }
+            V[r * 4 + 0] = wino_pk_sub(t[0], t[2]);
+            V[r * 4 + 1] = wino_pk_add(t[1], t[2]);
+            V[r * 4 + 2] = wino_pk_sub(t[2], t[1]);
+            V[r * 4 + 3] = wino_pk_sub(t[1], t[3]);
+        }
+    };
+    // 64 MFMAs, position-major: the 4 B operands of a position are one 16-byte item per lane.  This iteration's six DMA pieces ride
+    // behind the four MFMA groups (all eight waves issuing them right behind the barrier backs up the texture addresser and stalls
+    // every wave at its first instruction): B(g+1) x 2 | A(g+2) x 2 | x 1 | x 1 — the order the vmcnt arithmetic of head() assumes.
+    auto mfma_chunk = [&](int buf, unsigned g, bool dma) {
+        const char* sB = (const char*)(smem + G::OFF_B + buf * G::B_FLOATS) + lane16;
+        int av[NA];
+        if (dma) {
+            const int ol = lane_id();
+#pragma unroll
+            for (int i = 0; i < NA; ++i) av[i] = avtab[i * 64 + ol];
+        }
+        const int bbuf = (int)((g + 1) % G::NBUF), abuf = (int)((g + 2) % G::NBUF);
+        if (abl & 16) dma = false;
+        if (abl & 2) return;
+        f32x4 Bq[2][4];                  // four positions at a time, the next four requested before this group's MFMAs (pinned: left
+                                         // alone hipcc hoists all 16 reads = 64 registers and spills)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Bq[0][e] = *(const f32x4*)(sB + e * 1024);
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (q4 < 3 && !(abl & 4)) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Bq[(q4 + 1) & 1][e] = *(const f32x4*)(sB + ((q4 + 1) * 4 + e) * 1024);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int nb2 = 0; nb2 < 2; ++nb2)
+                        acc[q4 * 4 + e][nb2] = __builtin_amdgcn_mfma_f32_16x16x4f32(h ? V[q4 * 4 + e].y : V[q4 * 4 + e].x, Bq[q4 & 1][e][h * 2 + nb2],
+                                                                                   acc[q4 * 4 + e][nb2], 0, 0, 0);
+            if (dma) {
+                if (q4 == 0) b_issue(bbuf);
+                if (q4 == 1) issue_a(arsrc, 0, av[0], d_k, abuf), issue_a(arsrc, 1, av[1], d_k, abuf);
+                if (q4 == 2) issue_a(arsrc, 2, av[2], d_k, abuf);
+                if (q4 == 3) issue_a(arsrc, 3, av[3], d_k, abuf);
+            }
+        }
+        if (dma) {
+            b_advance();
+            a_advance();
+        }
+    };
+    auto epilogue = [&](const Cur& c) {
+        if (!c.valid || (abl & 8)) return;
+        const int ol = lane_id();
+        const int n16 = ol & 15, mb = ol >> 4;
+        const float uslope = a.act == 1 ? a.slope : 1.0f;
+        const __amdgpu_buffer_rsrc_t orsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)c.n * H * W * a.out_cs), 0, H * W * a.out_cs * 4, 0x00020000);
+#pragma unroll
+        for (int nb2 = 0; nb2 < 2; ++nb2) {
+            const int co = c.nb * 32 + nb2 * 16 + n16;
+            const bool cok = co < a.Cout;
+            const float bs = cst[co < G::MAXCO ? co : 0], bt = cst[G::MAXCO + (co < G::MAXCO ? co : 0)];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = 4 * mb + r;                  // tile: ty = m >> 3, tx = m & 7
+                float s0[4], s1[4];
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const float q0 = acc[cc][nb2][r], q1 = acc[4 + cc][nb2][r], q2 = acc[8 + cc][nb2][r], q3 = acc[12 + cc][nb2][r];
+                    s0[cc] = (q0 + q1) + q2;
+                    s1[cc] = (q1 - q2) - q3;
+                }
+                float y[4];
+                y[0] = (s0[0] + s0[1]) + s0[2];
+                y[1] = (s0[1] - s0[2]) - s0[3];
+                y[2] = (s1[0] + s1[1]) + s1[2];
+                y[3] = (s1[1] - s1[2]) - s1[3];
+#pragma unroll
+                for (int ey = 0; ey < 2; ++ey)
+#pragma unroll
+                    for (int ex = 0; ex < 2; ++ex) {
+                        const int oy = c.Ry0 + 2 * (m >> 3) + ey, ox = c.Rx0 + 2 * (m & 7) + ex;
+                        float v = (y[ey * 2 + ex] + bs) * bt;
+                        v = fmaxf(v, v * uslope);
+                        const bool ok = cok && oy < H && ox < W;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orsrc, ok ? ((oy * W + ox) * a.out_cs + co) * 4 : (int)0x80000000, 0, 0);
+                    }
+            }
+        }
+    };
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int x = 0; x < 16; ++x)
+#pragma unroll
+            for (int n2 = 0; n2 < 2; ++n2) acc[x][n2] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+
+    // ---- the chunk stream: iteration g = chunk g of this workgroup's items, one barrier each.  Two separate loops (one per wave
+    // group) with the same barrier count: in one loop hipcc kept V, the patch and both groups' temporaries live together and spilled.
+    // barrier: chunk g has landed (all but this wave's newest NA pieces, A(g+1)); this iteration's DMA — B(g+1) into the buffer group 1
+    // finished with before the barrier, A(g+2) into this wave's slot of it — follows inside mfma_chunk (or here when there is none)
+    auto head = [&](unsigned g, bool dma_now) {
+        __builtin_amdgcn_s_waitcnt(wino_waitcnt(NA, 0));
+        __builtin_amdgcn_s_barrier();
+        if (dma_now) {
+            b_issue((int)((g + 1) % G::NBUF));
+            b_advance();
+            a_issue((int)((g + 2) % G::NBUF));
+            a_advance();
+        }
+    };
+    zero_acc();
+    if (grp == 0) {
+        unsigned g = 0;
+        for (int it = 0; item(it, ccur); ++it)
+            for (int k = 0; k < C8; ++k, ++g) {
+                const int buf = (int)(g % G::NBUF);
+                head(g, false);
+                if (!(abl & 1)) {
+                    read_patch(buf);
+                    transform();
+                }
+                mfma_chunk(buf, g, true);
+                if (k == C8 - 1) {
+                    epilogue(ccur);
+                    zero_acc();
+                }
+            }
+    } else {
+        unsigned g = 0;
+        bool pend = false;
+        Cur pcur;
+        for (int it = 0; item(it, ccur); ++it)
+            for (int k = 0; k < C8; ++k, ++g) {
+                const int buf = (int)(g % G::NBUF);
+                head(g, !pend);
+                if (pend) {
+                    mfma_chunk((int)((g + G::NBUF - 1) % G::NBUF), g, true);      // chunk g - 1
+                    if (k == 0) {                                         // ... was the last chunk of the previous item
+                        epilogue(pcur);
+                        zero_acc();
+                    }
+                }
+                if (!(abl & 1)) {
+                    read_patch(buf);
+                    transform();
+                }
+                pend = true;
+                pcur = ccur;
+            }
+        if (pend) {
+            mfma_chunk((int)((g + G::NBUF - 1) % G::NBUF), g, false);
+            epilogue(pcur);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------------------
 // U = G g G^T per (co, ci), laid out [Cout_p/32][Cin_p/8][j][xi/4][half][co%32][xi%4]; physical input channel
 // pc = c8 * 8 + half * 4 + j.  chan_map translates logical to physical input channels (concat windows), nullptr = identity.
@@ -572,6 +935,29 @@ void pack_wino3x3(const float* w_oihw, int Cout, int Cin, const int* chan_map, i
             const int nb = co / 32, c32 = co % 32, c8 = pc / 8, hf = (pc % 8) / 4, j = pc % 4;
             for (int xi = 0; xi < 16; ++xi) {
                 const size_t idx = ((((((size_t)nb * C8 + c8) * 4 + j) * 4 + (xi >> 2)) * 2 + hf) * 32 + c32) * 4 + (xi & 3);
+                wp[idx] += (float)U[xi >> 2][xi & 3];
+            }
+        }
+}
+
+// Pack for conv_wino16_kernel: per (co / 32, ci / 8) 16 pieces of 1 KiB, piece = transform position xi, lane l = (n = l % 16,
+// kq = l / 16), the lane's 4 floats = (MFMA h = 0/1) x (N block nb2 = 0/1):  U[xi][ci = c8 * 8 + 2 * kq + h][co = nb * 32 + nb2 * 16 + n].
+void pack_wino16(const float* w_oihw, int Cout, int Cin, const int* chan_map, int Cin_p, int Cout_p, std::vector<float>& wp) {
+    const int C8 = Cin_p / 8;
+    wp.assign((size_t)16 * Cin_p * Cout_p, 0.f);
+    static const double Gm[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    for (int co = 0; co < Cout; ++co)
+        for (int ci = 0; ci < Cin; ++ci) {
+            const int pc = chan_map ? chan_map[ci] : ci;
+            const float* g = w_oihw + ((size_t)co * Cin + ci) * 9;
+            double tmp[4][3], U[4][4];
+            for (int r = 0; r < 4; ++r)
+                for (int c = 0; c < 3; ++c) tmp[r][c] = Gm[r][0] * g[0 * 3 + c] + Gm[r][1] * g[1 * 3 + c] + Gm[r][2] * g[2 * 3 + c];
+            for (int r = 0; r < 4; ++r)
+                for (int c = 0; c < 4; ++c) U[r][c] = tmp[r][0] * Gm[c][0] + tmp[r][1] * Gm[c][1] + tmp[r][2] * Gm[c][2];
+            const int nb = co / 32, nb2 = (co % 32) / 16, n = co % 16, c8 = pc / 8, kq = (pc % 8) / 2, h = pc % 2;
+            for (int xi = 0; xi < 16; ++xi) {
+                const size_t idx = ((((size_t)nb * C8 + c8) * 16 + xi) * 64 + kq * 16 + n) * 4 + h * 2 + nb2;
                 wp[idx] += (float)U[xi >> 2][xi & 3];
             }
         }
@@ -645,6 +1031,47 @@ static int wino_launch_t(WinoArgs& p, hipStream_t s, const char* name) {
     p.xcd_map = xcd;
     TraceScope ts(name, s);
     hipLaunchKernelGGL((conv_wino_kernel<RTX, MODE, ABL>), dim3(grid), dim3(256), G::LDS_BYTES, s, p);
+    VFI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// a.w must point at pack_wino16's output (device).  Hot epilogue only (no residual, none / LeakyReLU), Cout_p <= 256.
+bool conv_wino16_eligible(const ConvArgs& a, bool any_size) {
+    const bool ext = a.res != nullptr || a.post_scale != 0.f || !(a.act == 0 || (a.act == 1 && a.slope >= 0.f && a.slope <= 1.f));
+    if (ext || a.Cout_p > Wino16::MAXCO) return false;
+    if (!any_size) return conv_wino_eligible(a);
+    return a.ntaps == 9 && a.Hout == a.Hin && a.Wout == a.Win && !a.in_plane && a.out_mode == 0 && a.Cin_p % 8 == 0 && a.Cout_p % 32 == 0 &&
+           (long)a.Hin * a.Win * a.in_cs * 4 < 0x7fffffffL && (long)a.Hin * a.Win * a.out_cs * 4 < 0x7fffffffL;
+}
+int conv_wino16_launch(const ConvArgs& a, hipStream_t s, const char* name) {
+    VFI_REQUIRE(conv_wino16_eligible(a, true), "conv_wino16 %s: layer not eligible", name);
+    VFI_REQUIRE(a.Cin_p % 8 == 0 && a.Cout_p % 32 == 0 && a.in_cs >= a.Cin_p && a.in_cs % 4 == 0 && ((uintptr_t)a.in & 15) == 0 && ((uintptr_t)a.w & 15) == 0,
+                "conv_wino16 %s: bad channel padding / alignment", name);
+    VFI_REQUIRE((long)a.Hin * a.Win * a.in_cs * 4 < 0x7fffffffL && (long)a.Hin * a.Win * a.out_cs * 4 < 0x7fffffffL, "conv_wino16 %s: image larger than 2 GiB", name);
+    WinoArgs p;
+    p.a = a;
+    p.rx = cdiv(a.Win, 16), p.ry = cdiv(a.Hin, 8);
+    p.R = a.N * p.rx * p.ry;
+    p.NQ = cdiv(p.R, 4);
+    p.NY = a.Cout_p / 32;
+    VFI_REQUIRE((long)p.NQ * p.NY + 2048 < (1L << 24) && p.R < (1 << 24), "conv_wino16 %s: too many work items", name);
+    p.inv_NY = 1.0f / (float)p.NY, p.inv_per = 1.0f / (float)(p.rx * p.ry), p.inv_rx = 1.0f / (float)p.rx;
+    int dev = 0;
+    VFI_CHECK_HIP(hipGetDevice(&dev));
+    VFI_REQUIRE(dev >= 0 && dev < kMaxDevices, "conv_wino16 %s: device index %d out of range", name, dev);
+    static std::atomic<int> attr_set[kMaxDevices];
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
+        VFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, Wino16::LDS_BYTES));
+        attr_set[dev].store(1, std::memory_order_release);
+    }
+    const int cus = wino_cus(dev);
+    const long items = (long)p.NQ * p.NY;
+    int grid = (int)(items < cus ? items : cus);
+    grid = round_up(grid, 8);
+    static const int abl16 = [] { const char* e = getenv("VFI_WINO16_ABL"); return e ? atoi(e) : 0; }();
+    p.xcd_map = 1 | (abl16 << 4);
+    TraceScope ts(name, s);
+    hipLaunchKernelGGL(conv_wino16_kernel, dim3(grid), dim3(512), Wino16::LDS_BYTES, s, p);
     VFI_CHECK_HIP(hipGetLastError());
     return 0;
 }

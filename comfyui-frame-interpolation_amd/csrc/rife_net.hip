@@ -71,6 +71,7 @@ struct ConvLayer {
     DevBuf w, ww, bias, beta;   // ww: Winograd F(2x2,3x3) pack (3x3 stride-1 layers: the ResConvs and the 4.17 / 4.26 head)
     int Cin = 0, Cin_p = 0, Cout = 0, Cout_p = 0;
     bool folded = false;  // residual folded into the centre tap (ResConv)
+    bool ww16 = false;    // ww is in pack_wino16's layout (experimental two-waves-per-SIMD Winograd kernel)
 };
 
 const int kBlockC[5] = {192, 128, 96, 64, 32};  // IFBlock widths; the fifth block exists in arch 4.26 only
@@ -129,6 +130,11 @@ static int bind_arena(vfi_rife* net, const std::vector<WeightView>& views, size_
     return 0;
 }
 
+static bool wino_2wave() {
+    static const bool on = [] { const char* e = getenv("VFI_WINO_2WAVE"); return e && e[0] == '1'; }();
+    return on;
+}
+
 static int make_conv3x3(ConvLayer& L, const float* w, const float* b, const float* beta, int Cout, int Cin,
                         int Cin_p, bool wino = false) {
     L.Cin = Cin;
@@ -155,7 +161,9 @@ static int make_conv3x3(ConvLayer& L, const float* w, const float* b, const floa
     if (upload(L.w, wp) || upload(L.bias, bp)) return -1;
     if (wino) {
         std::vector<float> wq;
-        pack_wino3x3(w, Cout, Cin, nullptr, Cin_p, L.Cout_p, wq);
+        L.ww16 = wino_2wave() && beta != nullptr;      // experimental (VFI_WINO_2WAVE=1): the ResConvs' pack in conv_wino16_kernel's layout
+        if (L.ww16) pack_wino16(w, Cout, Cin, nullptr, Cin_p, L.Cout_p, wq);
+        else pack_wino3x3(w, Cout, Cin, nullptr, Cin_p, L.Cout_p, wq);
         if (upload(L.ww, wq)) return -1;
     }
     if (beta) {
@@ -557,7 +565,10 @@ int vfi_rife_interpolate(vfi_rife_t* net, int B, const int* slot0, const int* sl
             a.slope = 0.2f;
             // Winograd F(2x2,3x3) form (conv_wino.hip) unless switched off: chosen per PROCESS, never per launch, so a frame's
             // result does not depend on how it was batched
-            if (conv_wino_mode(-1) != 1 && net->res[i][r].ww.p) {
+            if (net->res[i][r].ww16 && conv_wino_mode(-1) != 1 && conv_wino16_eligible(a)) {
+                a.w = net->res[i][r].ww.p;
+                if (conv_wino16_launch(a, st, kResName[i])) return -1;
+            } else if (!net->res[i][r].ww16 && conv_wino_mode(-1) != 1 && net->res[i][r].ww.p) {
                 a.w = net->res[i][r].ww.p;
                 if (conv_wino_launch(a, 0, st, kResName[i])) return -1;
             } else if (conv_launch(a, 1, false, -1, st, kResName[i])) {

@@ -113,6 +113,9 @@ void conv3x3_taps(ConvArgs& a);
 // logical to physical input channels (nullptr = identity).  Launch: ConvArgs as for the direct kernel with a.w = that pack;
 // variant 0 = pick the region shape, 8 / 16 = 16x8 / 32x4 output pixels per wave.
 void pack_wino3x3(const float* w_oihw, int Cout, int Cin, const int* chan_map, int Cin_p, int Cout_p, std::vector<float>& wp);
+void pack_wino16(const float* w_oihw, int Cout, int Cin, const int* chan_map, int Cin_p, int Cout_p, std::vector<float>& wp);
+bool conv_wino16_eligible(const ConvArgs& a, bool any_size = false);
+int conv_wino16_launch(const ConvArgs& a, hipStream_t s, const char* name);   // experimental two-waves-per-SIMD form (conv_wino.hip)
 bool conv_wino_eligible(const ConvArgs& a);
 int conv_wino_mode(int set);      // set < 0: query.  0 automatic, 1 direct kernel only, 2 Winograd wherever legal
 int conv_wino_launch(const ConvArgs& a, int variant, hipStream_t s, const char* trace_name);

@@ -124,6 +124,17 @@ def test_conv3x3_winograd(lib, variant, cin, cout, n, h, w, res):
     _conv_case(lib, n, h, w, cin, cout, 1, res, variant)
 
 
+# the experimental two-waves-per-SIMD form (conv_wino16_kernel: 16x4-pixel wave regions on 16x16x4 MFMAs; hot epilogue, Cout <= 256):
+# odd sizes (partial regions in both directions), one and many chunks, 1 .. 8 channel blocks, more items than workgroups
+WINO16 = [(64, 64, 2, 37, 45), (8, 32, 1, 8, 16), (24, 40, 3, 19, 33), (192, 192, 1, 34, 60), (64, 64, 1, 1, 1), (128, 128, 2, 68, 120),
+          (16, 256, 1, 5, 70), (64, 64, 9, 272, 480)]
+
+
+@pytest.mark.parametrize("cin,cout,n,h,w", WINO16)
+def test_conv3x3_winograd_two_wave(lib, cin, cout, n, h, w):
+    _conv_case(lib, n, h, w, cin, cout, 1, False, 102)
+
+
 @pytest.mark.parametrize("act,post,pad_mode,res", [(0, None, 0, False), (1, None, 0, False), (3, None, 1, False), (4, (0.8, 0.1), 0, False), (5, None, 0, False),
                                                    (3, None, 0, True), (1, (2.0, -0.5), 1, True), (2, None, 0, False)])
 def test_layer_object_winograd_matches_direct_and_torch(lib, act, post, pad_mode, res):

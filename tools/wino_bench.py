@@ -53,6 +53,8 @@ for name, n, h, w, cin, cout in LAYERS:
     t0, o0 = run(n, h, w, cin, cout, -1)
     t1, o1 = run(n, h, w, cin, cout, 100)
     t2, o2 = run(n, h, w, cin, cout, 101)
+    t3, o3 = run(n, h, w, cin, cout, 102) if cout <= 256 else (None, None)      # the experimental two-waves-per-SIMD form
     d = max((o1 - o0).abs().max().item() if o1 is not None else -1, (o2 - o0).abs().max().item() if o2 is not None else -1)
     f = lambda t: f"{flop / t / 1e9:7.1f}" if t else "   n/a"
-    print(f"{name:28s} {t0:10.4f} {f(t0)} | {t1 or 0:11.4f} {f(t1):>8s} {flop / 2.25 / t1 / 1e9 / PEAK if t1 else 0:9.3f} | {t2 or 0:11.4f} {f(t2):>8s} | {d:.2e}", flush=True)
+    d3 = (o3 - o0).abs().max().item() if o3 is not None else -1
+    print(f"{name:28s} {t0:10.4f} {f(t0)} | {t1 or 0:11.4f} {f(t1):>8s} {flop / 2.25 / t1 / 1e9 / PEAK if t1 else 0:9.3f} | {t2 or 0:11.4f} {f(t2):>8s} | {d:.2e} | 2-wave {t3 or 0:8.4f} {f(t3):>8s} max|d| {d3:.2e}", flush=True)
