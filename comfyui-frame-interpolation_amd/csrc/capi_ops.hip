@@ -122,6 +122,21 @@ int64_t vfi_test_pack_wino3x3(const float* weight_host, int Cout, int Cin, const
     return (int64_t)wp.size();
 }
 
+int64_t vfi_test_pack_wino16(const float* weight_host, int Cout, int Cin, const int* chan_map, int Cin_p, float* out_host, int64_t cap) {
+    if (!weight_host || !out_host || Cout <= 0 || Cin <= 0 || Cin_p % 8 || Cin_p < Cin) {
+        set_error("vfi_test_pack_wino16: bad arguments");
+        return -1;
+    }
+    std::vector<float> wp;
+    pack_wino16(weight_host, Cout, Cin, chan_map, Cin_p, round_up(Cout, 32), wp);
+    if ((int64_t)wp.size() > cap) {
+        set_error("vfi_test_pack_wino16: buffer too small (need %lld floats)", (long long)wp.size());
+        return -1;
+    }
+    memcpy(out_host, wp.data(), wp.size() * sizeof(float));
+    return (int64_t)wp.size();
+}
+
 int vfi_conv3x3_naive(const float* in_dev, const float* weight_host, const float* bias_host, const float* beta_host,
                       float* out_dev, int N, int H, int W, int Cin, int Cout, int stride, int act, float slope,
                       void* stream) {

@@ -29,6 +29,8 @@ int vfi_test_conv_algo(int mode);
  * [Cout_p/32][Cin_p/8][j][xi/4][half][co%32][xi%4], physical input channel = c8*8 + half*4 + j), written to a HOST buffer: lets the
  * CPU suite check the pack and emulate the kernel's addressing (tests/test_wino_emulation.py).  Returns floats written or < 0. */
 int64_t vfi_test_pack_wino3x3(const float* weight_host, int Cout, int Cin, const int* chan_map, int Cin_p, float* out_host, int64_t cap);
+/* the same for the experimental two-waves-per-SIMD kernel's layout (csrc/conv_wino.hip: pack_wino16) */
+int64_t vfi_test_pack_wino16(const float* weight_host, int Cout, int Cin, const int* chan_map, int Cin_p, float* out_host, int64_t cap);
 
 /* Debug taps for parity tests: copy internal tensors of the LAST interpolate call to host.
  * what: 0 = flow after stage `stage` [B,Hp,Wp,4];  1 = stage input X of `stage`, planar4 [B,Cx/4,Hs,Ws,4];
