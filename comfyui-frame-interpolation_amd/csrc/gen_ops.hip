@@ -203,9 +203,20 @@ vfi_conv_t* vfi_conv_create(const float* w_oihw_host, const float* bias_host, in
         vfi_conv_destroy(c);
         return nullptr;
     }
-    if (kh == 3) {
+    // Winograd F(2x2,3x3) pack: every 3x3 layer — and the 2x2 'same' layers with a long reduction (FILM's first fusion conv,
+    // 1936 -> 512): embedded in a 3x3 kernel (w3[1 + dy][1 + dx] = w[dy][dx]: 'same' for k = 2 pads bottom / right) they cost the
+    // Winograd kernel 2.25x the multiplications of the direct 2x2 form, which it wins back exactly — at its 0.78 matrix-pipe
+    // utilisation for Cin >= 512 against the direct kernel's 0.66 (measured: 2.46 -> ~2.05 ms); shorter reductions do not gain.
+    std::vector<float> w3;
+    if (kh == 2 && Cin_phys >= 1024) {
+        w3.assign((size_t)Cout * Cin * 9, 0.f);
+        for (size_t i = 0; i < (size_t)Cout * Cin; ++i)
+            for (int dy = 0; dy < 2; ++dy)
+                for (int dx = 0; dx < 2; ++dx) w3[i * 9 + (1 + dy) * 3 + 1 + dx] = w_oihw_host[i * 4 + dy * 2 + dx];
+    }
+    if (kh == 3 || !w3.empty()) {
         std::vector<float> ww;
-        pack_wino3x3(w_oihw_host, Cout, Cin, chan_map, Cin_phys, c->Cout_p, ww);
+        pack_wino3x3(w3.empty() ? w_oihw_host : w3.data(), Cout, Cin, chan_map, Cin_phys, c->Cout_p, ww);
         if (hipMalloc((void**)&c->ww, ww.size() * sizeof(float)) != hipSuccess ||
             hipMemcpy(c->ww, ww.data(), ww.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
             set_error("vfi_conv_create: device allocation/upload failed (Winograd pack)");
@@ -383,9 +394,16 @@ int vfi_conv_forward(const vfi_conv_t* c, const float* in_dev, int in_cs, float*
     static std::map<std::string, const char*> names;  // stable storage for trace names
     auto it = names.find(name);
     if (it == names.end()) it = names.emplace(name, strdup(name)).first;
-    if (c->ww && conv_wino_eligible(a)) {
-        a.w = c->ww;
-        return conv_wino_launch(a, 0, (hipStream_t)stream, it->second);
+    if (c->ww) {
+        ConvArgs b = a;
+        if (c->kh == 2) {       // the 2x2 layer as its 3x3 embedding (vfi_conv_create)
+            b.ntaps = 9;
+            b.tap_y0 = b.tap_x0 = -1;
+        }
+        if (conv_wino_eligible(b)) {
+            b.w = c->ww;
+            return conv_wino_launch(b, 0, (hipStream_t)stream, it->second);
+        }
     }
     return conv_launch(a, 1, false, -1, (hipStream_t)stream, it->second);
 }
