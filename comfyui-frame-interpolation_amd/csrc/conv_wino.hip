@@ -608,7 +608,7 @@ __global__ __launch_bounds__(512) void conv_wino16_kernel(const WinoArgs p) {
     }
     __syncthreads();
     const int abl = p.xcd_map >> 4;              // timing experiments (VFI_WINO16_ABL; results wrong): 1 no patch reads / transform, 2 no MFMAs,
-                                                 // 4 no B reads, 8 no epilogue, 16 no DMA
+                                                 // 4 no B reads, 8 no epilogue, 16 no DMA, 32 no chunk barrier
     const int C8 = a.Cin_p >> 3;
     const int H = a.Hin, W = a.Win;
     const int img_floats = H * W * a.in_cs;
@@ -860,7 +860,7 @@ __global__ __launch_bounds__(512) void conv_wino16_kernel(const WinoArgs p) {
     // finished with before the barrier, A(g+2) into this wave's slot of it — follows inside mfma_chunk (or here when there is none)
     auto head = [&](unsigned g, bool dma_now) {
         __builtin_amdgcn_s_waitcnt(wino_waitcnt(NA, 0));
-        __builtin_amdgcn_s_barrier();
+        if (!(abl & 32)) __builtin_amdgcn_s_barrier();
         if (dma_now) {
             b_issue((int)((g + 1) % G::NBUF));
             b_advance();
