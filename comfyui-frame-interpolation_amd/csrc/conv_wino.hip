@@ -658,10 +658,11 @@ __global__ __launch_bounds__(512) void conv_wino16_kernel(const WinoArgs p) {
             const int pix = sp >> 1, q = sp & 1;             // its 9 odd ones: the 8 tiles of a row then read 8 CONSECUTIVE 32-byte pixels
             const int py = pix / PW, pj = pix - py * PW;     // (tiles are 2 pixels apart: interleaved, a read hit every other bank group 4 times)
             const int px = pj < PW / 2 ? 2 * pj : 2 * (pj - PW / 2) + 1;
+            const int qs = q ^ ((py >> 1) & 1);              // the stored quad: rows 2,3 swap a pixel's two 16-byte halves (read_patch)
             const int iy = c.Ry0 - 1 + py, ix = c.Rx0 - 1 + px;
             const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
             const bool ok = sp < G::NITEM && c.valid && (a.pad_replicate || (cy == iy && cx == ix));
-            avtab[i * 64 + ol] = ok ? ((cy * W + cx) * a.in_cs + q * 4) * 4 : (int)0x80000000;
+            avtab[i * 64 + ol] = ok ? ((cy * W + cx) * a.in_cs + qs * 4) * 4 : (int)0x80000000;
         }
     };
     auto issue_a = [&](const __amdgpu_buffer_rsrc_t& rsrc, int i, int voff, int k, int buf) {
@@ -738,12 +739,17 @@ __global__ __launch_bounds__(512) void conv_wino16_kernel(const WinoArgs p) {
     auto read_patch = [&](int buf) {
         const int ol = lane_id();
         const int m = ol & 15, kq = ol >> 4;
-        const int base = (((m >> 3) * 2) * PW + (m & 7)) * 32 + kq * 8 + ((buf * 8 + slot) * G::A_FLOATS) * 4;
+        // Tile rows ty = 0 / 1 read patch rows dy / 2 + dy at the same time, 2 x 576 bytes = half a bank row apart: the same banks.
+        // Rows 2,3 are stored with a pixel's two 16-byte halves swapped (make_avoff), so the two tile rows hit different halves:
+        // the lane's half is (kq >> 1) ^ ((ty + (dy >> 1)) & 1) — one base per dy >> 1.
+        const int ty = m >> 3;
+        const int base0 = ((ty * 2) * PW + (m & 7)) * 32 + (kq & 1) * 8 + ((buf * 8 + slot) * G::A_FLOATS) * 4;
+        const int baseA = base0 + (((kq >> 1) ^ (ty & 1)) << 4), baseB = base0 + (((kq >> 1) ^ ((ty + 1) & 1)) << 4);
 #pragma unroll
         for (int dy = 0; dy < 4; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 4; ++dx)      // column 2 tx + dx is stored at (dx & 1) * 9 + tx + (dx >> 1)
-                P[dy * 4 + dx] = *(const f32x2*)((const char*)smem + base + (dy * PW + (dx & 1) * (PW / 2) + (dx >> 1)) * 32);
+                P[dy * 4 + dx] = *(const f32x2*)((const char*)smem + (dy < 2 ? baseA : baseB) + (dy * PW + (dx & 1) * (PW / 2) + (dx >> 1)) * 32);
     };
     auto transform = [&]() {       // V = B^T d B on the channel pair, row by row
 #pragma unroll

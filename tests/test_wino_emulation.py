@@ -251,12 +251,14 @@ def emulate16(x, wp, bias, cout, cout_p):
                             py, pj = divmod(pix, PW)
                             px = 2 * pj if pj < PW // 2 else 2 * (pj - PW // 2) + 1
                             iy, ix = Ry0 - 1 + py, Rx0 - 1 + px
+                            qs = q ^ ((py >> 1) & 1)          # rows 2,3 store a pixel's two 16-byte halves swapped
                             if 0 <= iy < H and 0 <= ix < W:
-                                A[sp] = x[n, iy, ix, k * 8 + q * 4:k * 8 + q * 4 + 4]
+                                A[sp] = x[n, iy, ix, k * 8 + qs * 4:k * 8 + qs * 4 + 4]
                         Af = A.reshape(-1)
-                        base = ((ty * 2) * PW + tx) * 8 + kq * 2                           # in floats (32 B per pixel, 8 B per K slot)
+                        base0 = ((ty * 2) * PW + tx) * 8 + (kq & 1) * 2                    # in floats (32 B per pixel, 8 B per K slot)
                         P = np.zeros((16, 64, 2), np.float32)
                         for dy in range(4):
+                            base = base0 + (((kq >> 1) ^ ((ty + (dy >> 1)) & 1)) << 2)
                             for dx in range(4):
                                 o = base + (dy * PW + (dx & 1) * (PW // 2) + (dx >> 1)) * 8
                                 P[dy * 4 + dx] = Af[o[:, None] + np.arange(2)[None]]
