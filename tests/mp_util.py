@@ -29,6 +29,8 @@ def run_ranks(worker, world=2, timeout=300, attempts=3):
             got = q.get(timeout=timeout)
         except queue.Empty:
             last = "no result from rank 0"
+        except Exception as e:      # a result that could not be received is a transport failure, not a wrong result: retry
+            last = f"receiving rank 0's result failed: {type(e).__name__}: {e}"
         for p in procs:
             p.join(timeout=120)
             if p.is_alive():
@@ -36,6 +38,8 @@ def run_ranks(worker, world=2, timeout=300, attempts=3):
                 p.join()
         codes = [p.exitcode for p in procs]
         if got is not None and all(c == 0 for c in codes):
-            return got
+            import torch
+
+            return torch.from_numpy(got) if not isinstance(got, torch.Tensor) else got
         last = f"{last or 'rank failure'}; exit codes {codes}"
     raise AssertionError(f"{attempts} attempts failed: {last}")

@@ -35,7 +35,7 @@ def _worker(rank, world, port, q):
     plan = rife_output_plan(6, tasks)
     out = torch.stack([frames[i] if k == "src" else new[i] for k, i in plan])
     if rank == 0:
-        q.put(out)
+        q.put(out.numpy())      # plain pickle: a torch tensor would travel through torch's shared-memory file descriptors
     dist.barrier()
     dist.destroy_process_group()
 

@@ -101,7 +101,7 @@ def _worker(rank, world, port, q):
     plan, tasks = generic_output_plan(len(fr), [3, 2, 2], None)   # 2 + 1 + 1 new frames over 3 pairs: uneven shards
     out = run_plan(OracleEngine(sd), fr, plan, tasks)
     if rank == 0:
-        q.put(out)
+        q.put(out.numpy())      # plain pickle: a torch tensor would travel through torch's shared-memory file descriptors
     dist.barrier()
     dist.destroy_process_group()
 
