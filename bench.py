@@ -440,7 +440,7 @@ def result_line(args, world, elapsed, traced, rep, eng, collective):
     flop_per_launch = 2.0 * B * (hp // 4) * (wp // 4) * 64 * 64 * 9
     avg_ms = ms / calls if calls else float("nan")
     achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12 if calls else float("nan")
-    wino = os.environ.get("VFI_CONV_WINOGRAD", "1") != "0"
+    wino = _lib.load().vfi_test_conv_algo(-1) != 1
     exec_div = 2.25 if wino else 1.0
     # HBM traffic of the dominant kernel comes from PMC counters, which need their own rocprofv3 passes (--pmc cannot share a run
     # with this timing): the figure is the one tools/profile_round.sh measured for THIS kernel at the recorded batch, scaled to the
@@ -534,7 +534,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("VFI_BENCH_BATCH", "32")), help="frame pairs per step per GPU (1..32)")
+    ap.add_argument("--batch", type=int, default=32, help="frame pairs per step per GPU (1..32)")
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -29,7 +29,8 @@ PROTOTYPES = {
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "vfi_test_conv_algo": (C.c_int, [C.c_int]),
     "vfi_test_pack_wino3x3": (C.c_int64, [C.c_void_p, C.c_int, C.c_int, c_int_p, C.c_int, C.c_void_p, C.c_int64]),
-    "vfi_test_pack_wino16": (C.c_int64, [C.c_void_p, C.c_int, C.c_int, c_int_p, C.c_int, C.c_void_p, C.c_int64]),
+    "vfi_test_set_option": (C.c_int, [C.c_char_p, C.c_int64]),
+    "vfi_test_variant_override": (C.c_int, [C.c_char_p]),
     "vfi_deconv4x4_ps2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_void_p]),
     "vfi_conv_create": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
@@ -155,7 +156,35 @@ PROTOTYPES = {
     "vfi_comm_broadcast": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int64, C.c_int, C.POINTER(C.c_void_p)]),
     "vfi_comm_all_gather_v": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p)]),
     "vfi_comm_plan_all_gather": (C.c_int64, [C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int64]),
+    "vfi_comm_all_gather_mode": (C.c_int, []),
 }
+
+
+# The runtime variables this package honours — all of them select resources or diagnostics, none changes a frame's values
+# (INTEGRATION.md "Environment").  Kernel A/B switches are NOT environment variables: include/vfi_hip_test.h, vfi_test_set_option.
+SUPPORTED_ENV = {
+    "VFI_DEVICES":        "devices one node call may use: 'current' (default) | 'all' | '0,1,2,3' (multidev.py)",
+    "VFI_ALLGATHER":      "device-side all-gather of new frames: 'rccl' (default) | 'direct' (csrc/comm.hip)",
+    "VFI_MODEL_CACHE":    "'0': do not keep engines between node calls (ckpt.py)",
+    "VFI_RIFE_MIN_BATCH": "smallest tasks-per-launch the RIFE node uses whatever its batch_size widget says (default 8)",
+    "VFI_HOST_WORKERS":   "host copy worker threads 'upload,download,...' (hostpipe.py)",
+    "VFI_HOST_THP":       "'0': no transparent-huge-page advice on the pinned staging ring (hostpipe.py)",
+    "VFI_HOST_PROFILE":   "'1': per-phase wall-clock accounting of the host pipeline (hostpipe.py)",
+    "VFI_TRACE_SHAPES":   "per-shape rows in vfi_trace_report (profiling)",
+}
+_TEST_HARNESS_ENV = {"VFI_TEST_OPTIONS", "VFI_HOSTCHECK", "VFI_CHILD"}      # read by tests/, never by the package or the library
+
+
+def audit_environment():
+    """Names of ``VFI_*`` variables in the environment that nothing in this package reads.  They are IGNORED (the library has no
+    experiment switches in its environment any more); saying so loudly beats a user believing a stale switch is in force."""
+    stray = sorted(k for k in os.environ if k.startswith("VFI_") and k not in SUPPORTED_ENV and k not in _TEST_HARNESS_ENV)
+    if stray:
+        import warnings
+
+        warnings.warn("ignored environment variable(s) " + ", ".join(stray) + ": not one of " + ", ".join(sorted(SUPPORTED_ENV)) +
+                      " (kernel A/B switches are set through vfi_test_set_option, include/vfi_hip_test.h)", RuntimeWarning, stacklevel=3)
+    return stray
 
 
 def load():
@@ -163,6 +192,7 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    audit_environment()
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run `python __graft_entry__.py build` "

@@ -56,7 +56,7 @@ int vfi_conv3x3(const float* in_dev, const float* weight_host, const float* bias
     conv3x3_taps(a);
     int v = variant;
     a.Cin_p = round_up(Cin, 8);
-    const bool wino = v == 100 || v == 101 || v == 102;      // Winograd F(2x2,3x3) form (conv_wino.hip): 16x8 / 32x4 pixel regions, 102: the two-waves-per-SIMD form
+    const bool wino = v == 100 || v == 101;      // Winograd F(2x2,3x3) form (conv_wino.hip): 16x8 / 32x4 pixel regions
     VFI_REQUIRE(!wino || stride == 1, "vfi_conv3x3: the Winograd variants are stride 1");
     if (v < 0) v = conv_pick_variant(a, stride, false);
     VFI_REQUIRE(wino || conv_variant_lookup(v), "vfi_conv3x3: bad variant %d", v);
@@ -77,8 +77,7 @@ int vfi_conv3x3(const float* in_dev, const float* weight_host, const float* bias
     }
     std::vector<float> wp, bp;
     pack_conv3x3(weight_host, bias_host, Cout, Cin, a.Cin_p, a.Cout_p, wp, bp);
-    if (wino && v != 102) pack_wino3x3(weight_host, Cout, Cin, nullptr, a.Cin_p, a.Cout_p, wp);
-    if (v == 102) pack_wino16(weight_host, Cout, Cin, nullptr, a.Cin_p, a.Cout_p, wp);
+    if (wino) pack_wino3x3(weight_host, Cout, Cin, nullptr, a.Cin_p, a.Cout_p, wp);
     Tmp dw, db, dbeta;
     if (dw.put(wp) || db.put(bp)) return -1;
     if (beta_host) {
@@ -97,10 +96,7 @@ int vfi_conv3x3(const float* in_dev, const float* weight_host, const float* bias
     a.out_cs = Cout;
     a.act = act;
     a.slope = slope;
-    if (v == 102) {
-        VFI_REQUIRE(!beta_host && conv_wino16_eligible(a, true), "vfi_conv3x3: variant 102 takes the hot epilogue only (no residual, none / LeakyReLU, Cout <= 256)");
-        if (conv_wino16_launch(a, st, "conv3x3_wino16")) return -1;
-    } else if (wino ? conv_wino_launch(a, v == 100 ? 8 : 16, st, "conv3x3_wino") : conv_launch(a, stride, false, v, st, nullptr)) return -1;
+    if (wino ? conv_wino_launch(a, v == 100 ? 8 : 16, st, "conv3x3_wino") : conv_launch(a, stride, false, v, st, nullptr)) return -1;
     VFI_CHECK_HIP(hipStreamSynchronize(st));  // temporaries are freed on return
     return 0;
 }
@@ -116,21 +112,6 @@ int64_t vfi_test_pack_wino3x3(const float* weight_host, int Cout, int Cin, const
     pack_wino3x3(weight_host, Cout, Cin, chan_map, Cin_p, round_up(Cout, 32), wp);
     if ((int64_t)wp.size() > cap) {
         set_error("vfi_test_pack_wino3x3: buffer too small (need %lld floats)", (long long)wp.size());
-        return -1;
-    }
-    memcpy(out_host, wp.data(), wp.size() * sizeof(float));
-    return (int64_t)wp.size();
-}
-
-int64_t vfi_test_pack_wino16(const float* weight_host, int Cout, int Cin, const int* chan_map, int Cin_p, float* out_host, int64_t cap) {
-    if (!weight_host || !out_host || Cout <= 0 || Cin <= 0 || Cin_p % 8 || Cin_p < Cin) {
-        set_error("vfi_test_pack_wino16: bad arguments");
-        return -1;
-    }
-    std::vector<float> wp;
-    pack_wino16(weight_host, Cout, Cin, chan_map, Cin_p, round_up(Cout, 32), wp);
-    if ((int64_t)wp.size() > cap) {
-        set_error("vfi_test_pack_wino16: buffer too small (need %lld floats)", (long long)wp.size());
         return -1;
     }
     memcpy(out_host, wp.data(), wp.size() * sizeof(float));

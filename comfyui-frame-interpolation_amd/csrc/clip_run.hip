@@ -128,13 +128,15 @@ int vfi_test_film_schedule(int inter_frames, int* triples, int cap) {
 int vfi_film_run(vfi_film_t* net, const float* frames_host, int N, int H, int W, int C, int multiplier, const int* multipliers,
                  int n_multipliers, const uint8_t* skip, float* out_host, int64_t* n_out) {
     VFI_REQUIRE(net && n_out && N >= 1 && H > 0 && W > 0 && C >= 3, "vfi_film_run: bad arguments (N=%d H=%d W=%d C=%d)", N, H, W, C);
-    VFI_REQUIRE(multipliers || multiplier >= 1, "vfi_film_run: multiplier %d", multiplier);
+    // inference(..., inter_frames = m - 1) (film/__init__.py:12-41): m in {-1, 0, 1} runs no iteration and the node emits frame_i
+    // alone (relust[:-1]); m <= -2 fails in torch.linspace(0, 1, m + 1) — the same here.
     std::vector<int> ms(N > 1 ? N - 1 : 0, 2);
     for (int p = 0; p + 1 < N; ++p) ms[p] = multipliers ? (p < n_multipliers ? multipliers[p] : 2) : multiplier;
     int64_t rows = 1;
     for (int p = 0; p + 1 < N; ++p)
         if (!(skip && skip[p])) {
-            VFI_REQUIRE(ms[p] >= 1, "vfi_film_run: multiplier %d of pair %d (the reference's loop needs >= 1)", ms[p], p);
+            VFI_REQUIRE(ms[p] >= -1, "vfi_film_run: multiplier %d of pair %d (the reference fails in torch.linspace for multipliers <= -2)", ms[p], p);
+            if (ms[p] < 1) ms[p] = 1;
             rows += ms[p];
         }
     *n_out = rows;
@@ -217,6 +219,8 @@ int vfi_m2m_run(vfi_m2m_t* net, const float* frames_host, int N, int H, int W, i
         for (int p = 0; p + 1 < N; ++p) {
             const int m = p < n_multipliers ? multipliers[p] : 2;
             if (m == 0) continue;
+            // (the reference allocates torch.zeros(m * 2, ...) for the pair, vfi_utils.py:178: a negative m raises there)
+            VFI_REQUIRE(m > 0, "vfi_m2m_run: multiplier %d of pair %d (the reference's frame loop fails on negative multipliers)", m, p);
             one_pair(p, m, skip && skip[0]);
             if (p == N - 2) plan.push_back({N - 1, N - 1, 0.f});
         }

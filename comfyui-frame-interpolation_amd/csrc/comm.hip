@@ -71,6 +71,14 @@ static const RcclApi& rccl() {
 
 using namespace vfi;
 
+// Restores the calling thread's current device on every way out (the loops below hop over the clique's devices; an early error
+// return must not leave later torch / HIP work of this thread on some rank's GPU).
+struct DeviceScope {
+    int prev = 0;
+    DeviceScope() { (void)hipGetDevice(&prev); }
+    ~DeviceScope() { (void)hipSetDevice(prev); }
+};
+
 struct vfi_comm {
     int n = 0;
     int devices[kMaxDevices];
@@ -137,9 +145,8 @@ vfi_comm_t* vfi_comm_create(int n_devices, const int* devices) {
 void vfi_comm_destroy(vfi_comm_t* c) {
     if (!c) return;
     for (int i = 0; i < c->n; ++i) (void)rccl().CommDestroy(c->comms[i]);
-    if (c->mesh_ready) {
-        int prev = 0;
-        (void)hipGetDevice(&prev);
+    {   // always walk the arrays: a mesh_init that failed half way leaves what it had created
+        DeviceScope ds;
         for (int r = 0; r < c->n; ++r) {
             (void)hipSetDevice(c->devices[r]);
             if (c->ev_src[r]) (void)hipEventDestroy(c->ev_src[r]);
@@ -149,7 +156,6 @@ void vfi_comm_destroy(vfi_comm_t* c) {
                 if (c->ev_done[r][i]) (void)hipEventDestroy(c->ev_done[r][i]);
             }
         }
-        (void)hipSetDevice(prev);
     }
     delete c;
 }
@@ -199,24 +205,28 @@ int64_t vfi_comm_plan_all_gather(int n, const int64_t* counts, int64_t* plan, in
 
 static int mesh_init(vfi_comm* c) {
     if (c->mesh_ready) return 0;
-    int prev = 0;
-    (void)hipGetDevice(&prev);
+    DeviceScope ds;
+    // (a retry after a partial failure re-uses what already exists: every handle is created only while it is null)
     for (int r = 0; r < c->n; ++r) {
         VFI_CHECK_HIP(hipSetDevice(c->devices[r]));
-        VFI_CHECK_HIP(hipEventCreateWithFlags(&c->ev_src[r], hipEventDisableTiming));
-        VFI_CHECK_HIP(hipEventCreateWithFlags(&c->ev_dst[r], hipEventDisableTiming));
+        if (!c->ev_src[r]) VFI_CHECK_HIP(hipEventCreateWithFlags(&c->ev_src[r], hipEventDisableTiming));
+        if (!c->ev_dst[r]) VFI_CHECK_HIP(hipEventCreateWithFlags(&c->ev_dst[r], hipEventDisableTiming));
         for (int i = 0; i < c->n; ++i) {
             if (i == r) continue;
-            VFI_CHECK_HIP(hipStreamCreateWithFlags(&c->cs[r][i], hipStreamNonBlocking));
-            VFI_CHECK_HIP(hipEventCreateWithFlags(&c->ev_done[r][i], hipEventDisableTiming));
+            if (!c->cs[r][i]) VFI_CHECK_HIP(hipStreamCreateWithFlags(&c->cs[r][i], hipStreamNonBlocking));
+            if (!c->ev_done[r][i]) VFI_CHECK_HIP(hipEventCreateWithFlags(&c->ev_done[r][i], hipEventDisableTiming));
             int can = 0;
             if (hipDeviceCanAccessPeer(&can, c->devices[r], c->devices[i]) == hipSuccess && can) {
-                const hipError_t e = hipDeviceEnablePeerAccess(c->devices[i], 0);
-                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();   // copies then stage through the host
+                // Any non-success return — hipErrorPeerAccessAlreadyEnabled included, the LIKELY one since RCCL's own same-process
+                // P2P setup has usually enabled it — stays in the thread's sticky error slot until it is read: the next
+                // VFI_CHECK_HIP(hipGetLastError()) behind a kernel launch would report it.  Read it away.  (A real failure only
+                // means the copies stage through the host.)
+                if (hipDeviceEnablePeerAccess(c->devices[i], 0) != hipSuccess) (void)hipGetLastError();
+            } else {
+                (void)hipGetLastError();
             }
         }
     }
-    (void)hipSetDevice(prev);
     c->mesh_ready = true;
     return 0;
 }
@@ -227,8 +237,7 @@ static int mesh_init(vfi_comm* c) {
 // streams[i] (the destination's earlier readers of that slot are done); streams[i] then waits for all its incoming copies.
 static int all_gather_direct(vfi_comm* c, float* const* bufs_dev, const int64_t* counts, void* const* streams) {
     if (mesh_init(c)) return -1;
-    int prev = 0;
-    (void)hipGetDevice(&prev);
+    DeviceScope ds;
     for (int r = 0; r < c->n; ++r) {
         VFI_CHECK_HIP(hipSetDevice(c->devices[r]));
         VFI_CHECK_HIP(hipEventRecord(c->ev_src[r], (hipStream_t)streams[r]));
@@ -254,17 +263,22 @@ static int all_gather_direct(vfi_comm* c, float* const* bufs_dev, const int64_t*
         VFI_CHECK_HIP(hipSetDevice(c->devices[r]));
         VFI_CHECK_HIP(hipStreamWaitEvent((hipStream_t)streams[r], c->ev_done[r][i], 0));
     }
-    (void)hipSetDevice(prev);
     return 0;
 }
 
-static int all_gather_mode() {     // VFI_ALLGATHER = direct (default: per-link peer copies) | rccl (grouped per-root ncclBroadcast)
+// VFI_ALLGATHER = rccl (default: grouped per-root ncclBroadcast) | direct (per-link peer copies).  The direct form has only ever run
+// on a clique of one device (no multi-GPU box has been available to this project): it stays opt-in until a 2+ device run has
+// passed tests/test_gpu_multidev.py::test_direct_all_gather_then_kernel.  One of the supported runtime variables.
+static int all_gather_mode() {
     static const int mode = [] {
         const char* e = getenv("VFI_ALLGATHER");
-        return (e && (e[0] == 'r' || e[0] == 'R')) ? 1 : 0;
+        return (e && (e[0] == 'd' || e[0] == 'D')) ? 0 : 1;
     }();
     return mode;
 }
+
+/* 0 = direct peer copies, 1 = RCCL grouped broadcasts: what vfi_comm_all_gather_v will use (bench.py reports it) */
+int vfi_comm_all_gather_mode(void) { return all_gather_mode(); }
 
 int vfi_comm_all_gather_v(vfi_comm_t* c, float* const* bufs_dev, const int64_t* counts, void* const* streams) {
     VFI_REQUIRE(c && bufs_dev && counts && streams, "vfi_comm_all_gather_v: bad arguments");

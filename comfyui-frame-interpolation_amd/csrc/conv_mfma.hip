@@ -385,14 +385,10 @@ int conv_pick_variant(const ConvArgs& a, int stride, bool grouped) {
         return 10;                       // s2_m1n1
     }
     if (n2) {   // d1_m2n2 (16x16 px tile) / d1_m1n2 (16x8): the larger M tile re-uses each weight fragment twice as often
-        static const long big_px = [] {
-            // experiment hook: pixel count from which wide layers take m2n2.  Measured on FILM / M2M at 1080p
-            // (profiles/r02_film_tile_experiment.txt): 100k is the best of {never, 1.5M, 400k, 100k, 20k} by 0.6 % only — not
-            // worth sharing the block-3 ResConv's kernel instantiation with other layers (its rocprofv3 average is the
-            // roofline cross-check), so the default stays "never"
-            const char* e = getenv("VFI_CONV_M2N2_PX");
-            return e && *e ? atol(e) : -1L;
-        }();
+        // A/B option m2n2_px: pixel count from which wide layers take m2n2.  Measured on FILM / M2M at 1080p
+        // (profiles/r02_film_tile_experiment.txt): 100k is the best of {never, 1.5M, 400k, 100k, 20k} by 0.6 % only — not
+        // worth sharing the block-3 ResConv's kernel instantiation with other layers, so the default stays "never"
+        const long big_px = option(kOptM2n2Px);
         if (a.Cout_p == 64 || (big_px >= 0 && px >= big_px)) return kConv2Base + 0;
         return kConv2Base + 2;
     }
@@ -402,27 +398,8 @@ int conv_pick_variant(const ConvArgs& a, int stride, bool grouped) {
 
 int conv_launch(const ConvArgs& a, int stride, bool grouped, int variant, hipStream_t s,
                 const char* trace_name) {
-    if (variant < 0 && grouped) {  // experiment hook: force a grouped (transposed-conv) tile variant
-        static const char* env = getenv("VFI_GROUPED_VARIANT");
-        if (env && *env) variant = atoi(env);
-    }
-    if (variant < 0 && trace_name) {  // experiment hook: VFI_VARIANT_OVERRIDE="conv0a_b3=42,resconv_c128=36" (by trace name)
-        static const std::map<std::string, int> ov = [] {
-            std::map<std::string, int> m;
-            const char* e = getenv("VFI_VARIANT_OVERRIDE");
-            std::string str = e ? e : "";
-            size_t pos = 0;
-            while (pos < str.size()) {
-                const size_t comma = str.find(',', pos), end = comma == std::string::npos ? str.size() : comma;
-                const size_t eq = str.find('=', pos);
-                if (eq != std::string::npos && eq < end) m[str.substr(pos, eq - pos)] = atoi(str.c_str() + eq + 1);
-                pos = end + 1;
-            }
-            return m;
-        }();
-        auto it = ov.find(trace_name);
-        if (it != ov.end()) variant = it->second;
-    }
+    if (variant < 0 && grouped && option(kOptGroupedVariant) >= 0) variant = (int)option(kOptGroupedVariant);   // A/B option grouped_variant
+    if (variant < 0 && trace_name) variant = variant_override(trace_name);      // A/B hook vfi_test_variant_override (by trace name)
     if (variant < 0) variant = conv_pick_variant(a, stride, grouped);
     const ConvVariant* vp = conv_variant_lookup(variant);
     VFI_REQUIRE(vp, "conv: bad variant %d", variant);

@@ -415,13 +415,7 @@ __global__ __launch_bounds__(256) void conv2_split_reduce_kernel(const ConvArgs 
     a.out[p * a.out_cs + co] = v;
 }
 
-static bool split_enabled() {
-    static const bool on = [] {
-        const char* e = getenv("VFI_CONV_SPLITK");      // experiment hook: VFI_CONV_SPLITK=0 disables split-K
-        return !(e && e[0] == '0');
-    }();
-    return on;
-}
+static bool split_enabled() { return option(kOptSplitK) != 0; }      // A/B option splitk = 0 disables split-K
 
 // partial-sum workspace and a zero bias vector, per (device, stream): grow-only, kept for the life of the process
 static int split_workspace(int dev, hipStream_t s, size_t floats, int cout_p, float** ws, float** zeros) {

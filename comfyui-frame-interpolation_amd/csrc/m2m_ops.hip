@@ -520,18 +520,12 @@ static int splat_ws(size_t n_blocks, size_t list_pixels, SplatWs** out) {
     return 0;
 }
 
-static unsigned g_splat_cap = SPLAT_OVF_CAP;
-static int g_splat_mode = -1;   // VFI_SPLAT_MODE=atomic forces the LDS-atomic tile kernel (A/B measurements, tests of the fallback)
 
 int softsplat_sum_launch(const float* in, const float* flow, float* out, int N, int H, int W, int C, hipStream_t s) {
-    if (g_splat_mode < 0) {
-        const char* e = getenv("VFI_SPLAT_MODE");
-        g_splat_mode = (e && e[0] == 'a') ? 1 : 0;
-        if (const char* c = getenv("VFI_SPLAT_SPILL_CAP")) {
-            const long v = atol(c);
-            if (v >= 0 && v < (long)SPLAT_OVF_CAP) g_splat_cap = (unsigned)v;
-        }
-    }
+    // A/B options (tests of the fallback paths): splat_atomic = 1 forces the LDS-atomic tile kernel, splat_spill_cap shrinks the spill list
+    const int g_splat_mode = option(kOptSplatAtomic) ? 1 : 0;
+    const long cap_opt = option(kOptSplatSpillCap);
+    const unsigned g_splat_cap = (cap_opt >= 0 && cap_opt < (long)SPLAT_OVF_CAP) ? (unsigned)cap_opt : SPLAT_OVF_CAP;
     const int tiles_x = cdiv(W, SPLAT_T), tiles_y = cdiv(H, SPLAT_T);
     const unsigned n_tiles = (unsigned)N * tiles_x * tiles_y;
     SplatWs* ws = nullptr;

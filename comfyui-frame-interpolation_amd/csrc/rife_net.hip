@@ -71,7 +71,6 @@ struct ConvLayer {
     DevBuf w, ww, bias, beta;   // ww: Winograd F(2x2,3x3) pack (3x3 stride-1 layers: the ResConvs and the 4.17 / 4.26 head)
     int Cin = 0, Cin_p = 0, Cout = 0, Cout_p = 0;
     bool folded = false;  // residual folded into the centre tap (ResConv)
-    bool ww16 = false;    // ww is in pack_wino16's layout (experimental two-waves-per-SIMD Winograd kernel)
 };
 
 const int kBlockC[5] = {192, 128, 96, 64, 32};  // IFBlock widths; the fifth block exists in arch 4.26 only
@@ -130,11 +129,6 @@ static int bind_arena(vfi_rife* net, const std::vector<WeightView>& views, size_
     return 0;
 }
 
-static bool wino_2wave() {
-    static const bool on = [] { const char* e = getenv("VFI_WINO_2WAVE"); return e && e[0] == '1'; }();
-    return on;
-}
-
 static int make_conv3x3(ConvLayer& L, const float* w, const float* b, const float* beta, int Cout, int Cin,
                         int Cin_p, bool wino = false) {
     L.Cin = Cin;
@@ -161,9 +155,7 @@ static int make_conv3x3(ConvLayer& L, const float* w, const float* b, const floa
     if (upload(L.w, wp) || upload(L.bias, bp)) return -1;
     if (wino) {
         std::vector<float> wq;
-        L.ww16 = wino_2wave() && beta != nullptr;      // experimental (VFI_WINO_2WAVE=1): the ResConvs' pack in conv_wino16_kernel's layout
-        if (L.ww16) pack_wino16(w, Cout, Cin, nullptr, Cin_p, L.Cout_p, wq);
-        else pack_wino3x3(w, Cout, Cin, nullptr, Cin_p, L.Cout_p, wq);
+        pack_wino3x3(w, Cout, Cin, nullptr, Cin_p, L.Cout_p, wq);
         if (upload(L.ww, wq)) return -1;
     }
     if (beta) {
@@ -439,11 +431,8 @@ static int load_frame_impl(vfi_rife_t* net, int slot, const float* f32, const un
     float* P = net->Ppool.p + (size_t)slot * net->pack_stride();
     const int Hp = net->Hp, Wp = net->Wp;
     // arch 4.7 (encode = Conv(3,16,s2) -> Deconv(16,4), no activation, no mid convs): the whole pack in one launch, the half-resolution
-    // tensor E never reaches HBM.  VFI_RIFE_FUSE_ENCODE=0 keeps the three kernels (A/B measurements, the bit-identity test).
-    static const bool fuse_encode = [] {
-        const char* e = getenv("VFI_RIFE_FUSE_ENCODE");
-        return !(e && e[0] == '0');
-    }();
+    // tensor E never reaches HBM.  Option fuse_encode = 0 keeps the three kernels (A/B measurements, the bit-identity test).
+    const bool fuse_encode = option(kOptFuseEncode) != 0;
     if (fuse_encode && net->n_mid == 0 && net->CM == 16 && net->CF == 4 && !net->enc_act && net->NF == 1)
         return encode47_fused_launch(f32, u8, P, net->enc_w0.p, net->enc_b0.p, net->enc_w1.p, net->enc_b1.p, net->H, net->W, C, Hp, Wp, st);
     if (u8 ? prep_frame_u8_launch(u8, P, net->H, net->W, C, Hp, Wp, st) : prep_frame_launch(f32, P, net->H, net->W, C, Hp, Wp, st))
@@ -508,12 +497,9 @@ int vfi_rife_interpolate(vfi_rife_t* net, int B, const int* slot0, const int* sl
     const float* feat = net->NX ? net->FEAT.p : nullptr;
     bool fused_prev = false;
     // The last transition of the standard scale list (block scales 2 -> 1) can run fused into the next block's conv0.0
-    // (trans1_conv0a_launch: X never goes to HBM; the flow then lives in the other of two buffers).  VFI_RIFE_FUSE0A=0 turns it
+    // (trans1_conv0a_launch: X never goes to HBM; the flow then lives in the other of two buffers).  Option fuse0a = 0 turns it
     // off (A/B measurements); the debug taps need X and keep the un-fused path.
-    static const bool fuse0a_enabled = [] {
-        const char* e = getenv("VFI_RIFE_FUSE0A");
-        return !(e && e[0] == '0');
-    }();
+    const bool fuse0a_enabled = option(kOptFuse0a) != 0;
     float* Fcur = net->F.p;
     float* Falt = net->F2.p;
     bool a0_ready = false;   // conv0.0 of this block has already been computed by the fused transition
@@ -565,10 +551,7 @@ int vfi_rife_interpolate(vfi_rife_t* net, int B, const int* slot0, const int* sl
             a.slope = 0.2f;
             // Winograd F(2x2,3x3) form (conv_wino.hip) unless switched off: chosen per PROCESS, never per launch, so a frame's
             // result does not depend on how it was batched
-            if (net->res[i][r].ww16 && conv_wino_mode(-1) != 1 && conv_wino16_eligible(a)) {
-                a.w = net->res[i][r].ww.p;
-                if (conv_wino16_launch(a, st, kResName[i])) return -1;
-            } else if (!net->res[i][r].ww16 && conv_wino_mode(-1) != 1 && net->res[i][r].ww.p) {
+            if (conv_wino_mode(-1) != 1 && net->res[i][r].ww.p) {
                 a.w = net->res[i][r].ww.p;
                 if (conv_wino_launch(a, 0, st, kResName[i])) return -1;
             } else if (conv_launch(a, 1, false, -1, st, kResName[i])) {

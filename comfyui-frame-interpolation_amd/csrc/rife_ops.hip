@@ -879,14 +879,8 @@ __global__ __launch_bounds__(256) void stage_trans_quad_kernel(const float* __re
     }
 }
 
-// VFI_STAGE_QUAD: bit mask of the next-block scales (2, 4, 8) that take the quad kernel; default all
-static int stage_quad_mask() {
-    static const int mask = [] {
-        const char* e = getenv("VFI_STAGE_QUAD");
-        return e && *e ? atoi(e) : 14;
-    }();
-    return mask;
-}
+// option stage_quad: bit mask of the next-block scales (2, 4, 8) that take the quad kernel; default all
+static int stage_quad_mask() { return (int)option(kOptStageQuad); }
 
 int stage_trans_launch(const float* Ppool, size_t pack_stride, const RifeTasks& tasks, int B, const float* T, float* F,
                        float* X, int Hp, int Wp, int s_prev, int s_next, int NF, bool has_prev, hipStream_t st) {

@@ -4,9 +4,14 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
+#include <cstdlib>
 #include <map>
+#include <mutex>
+#include <string>
 
 #include "../../include/vfi_hip.h"
+#include "../../include/vfi_hip_test.h"
 
 namespace vfi {
 
@@ -19,6 +24,57 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 const char* get_error() { return g_err; }
+
+// ---- A/B options (vfi_common.h: enum Option) ---------------------------------------------------------------------------------
+static const struct { const char* name; long dflt; } kOptTable[kOptCount] = {
+    {"stage_quad", 14}, {"fuse_encode", 1}, {"fuse0a", 1}, {"m2n2_px", -1}, {"grouped_variant", -1}, {"splitk", 1},
+    {"splat_atomic", 0}, {"splat_spill_cap", -1}, {"wino_xcd", 1}, {"encode_batched", 1},
+};
+static std::atomic<long> g_opt[kOptCount];
+static std::atomic<bool> g_opt_init{false};
+static std::mutex g_opt_mu;
+static std::map<std::string, int> g_variant_override;
+static std::atomic<int> g_variant_override_n{0};
+static void opt_init() {
+    if (g_opt_init.load(std::memory_order_acquire)) return;
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    if (g_opt_init.load(std::memory_order_relaxed)) return;
+    for (int i = 0; i < kOptCount; ++i) g_opt[i].store(kOptTable[i].dflt, std::memory_order_relaxed);
+    g_opt_init.store(true, std::memory_order_release);
+}
+long option(Option o) {
+    opt_init();
+    return g_opt[o].load(std::memory_order_relaxed);
+}
+int option_set(const char* name, long value) {
+    opt_init();
+    for (int i = 0; i < kOptCount; ++i)
+        if (name && !strcmp(name, kOptTable[i].name)) {
+            g_opt[i].store(value, std::memory_order_relaxed);
+            return 0;
+        }
+    set_error("vfi_test_set_option: unknown option '%s'", name ? name : "(null)");
+    return -2;
+}
+int variant_override(const char* trace_name) {
+    if (!trace_name || !g_variant_override_n.load(std::memory_order_acquire)) return -1;
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    auto it = g_variant_override.find(trace_name);
+    return it == g_variant_override.end() ? -1 : it->second;
+}
+static void variant_override_set(const char* spec) {      // "conv0a_b3=42,resconv_c128=36"; empty / null clears
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    g_variant_override.clear();
+    std::string str = spec ? spec : "";
+    size_t pos = 0;
+    while (pos < str.size()) {
+        const size_t comma = str.find(',', pos), end = comma == std::string::npos ? str.size() : comma;
+        const size_t eq = str.find('=', pos);
+        if (eq != std::string::npos && eq < end) g_variant_override[str.substr(pos, eq - pos)] = atoi(str.c_str() + eq + 1);
+        pos = end + 1;
+    }
+    g_variant_override_n.store((int)g_variant_override.size(), std::memory_order_release);
+}
 
 struct TraceRec {
     const char* name;
@@ -78,6 +134,12 @@ int vfi_device_info(char* arch_buf, int arch_buf_len, int* n_cus) {
         arch_buf[arch_buf_len - 1] = 0;
     }
     if (n_cus) *n_cus = p.multiProcessorCount;
+    return 0;
+}
+
+int vfi_test_set_option(const char* name, int64_t value) { return option_set(name, (long)value); }
+int vfi_test_variant_override(const char* spec) {
+    variant_override_set(spec);
     return 0;
 }
 

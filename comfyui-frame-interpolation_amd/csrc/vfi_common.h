@@ -44,6 +44,27 @@ struct TraceScope {
     }
 };
 
+// ---- A/B options of tools/ and tests/ (include/vfi_hip_test.h: vfi_test_set_option) ----------------------------------------
+// Every option selects between two CORRECT forms of a kernel or launch (fused / unfused, tile variant, ...).  They are set through
+// the test C entry point only — the product library reads NO experiment switch from the environment, so a stray variable cannot
+// change a frame (tests/test_gpu_env_hygiene.py).  Values are read at every launch (one relaxed atomic load).
+enum Option {
+    kOptStageQuad,       // bit mask of the next-block scales (2, 4, 8) whose transition takes the quad kernel (default 14 = all)
+    kOptFuseEncode,      // 1: RIFE 4.7 frame pack in one launch (default), 0: prep + encode.0 + encode.1 as three kernels
+    kOptFuse0a,          // 1: block 2->3 transition fused with block 3's conv0.0 (default), 0: separate
+    kOptM2n2Px,          // pixel count from which wide direct-conv layers take the m2n2 tile (default -1 = never)
+    kOptGroupedVariant,  // forced tile variant of the grouped (transposed) convolution (default -1 = heuristic)
+    kOptSplitK,          // 1: split-K allowed for layer objects (default), 0: never
+    kOptSplatAtomic,     // 1: force the LDS-atomic splat kernel (default 0: list-gather kernel with the atomic kernel as overflow fallback)
+    kOptSplatSpillCap,   // spill-list capacity of the list-gather splat (default -1 = built-in)
+    kOptWinoXcd,         // 1: XCD-aware work order of the Winograd kernel (default), 0: plain order
+    kOptEncodeBatched,   // 1: one frame-pack launch for a batch of frames where the caller offers one (default), 0: one launch per frame
+    kOptCount
+};
+long option(Option o);
+int option_set(const char* name, long value);      // 0, or -2 for an unknown name
+int variant_override(const char* trace_name);      // tile variant forced for a trace name (vfi_test_variant_override), -1 = none
+
 constexpr int kMaxDevices = 16;   // devices one process may drive (per-device caches are indexed by the HIP device id)
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -113,9 +134,6 @@ void conv3x3_taps(ConvArgs& a);
 // logical to physical input channels (nullptr = identity).  Launch: ConvArgs as for the direct kernel with a.w = that pack;
 // variant 0 = pick the region shape, 8 / 16 = 16x8 / 32x4 output pixels per wave.
 void pack_wino3x3(const float* w_oihw, int Cout, int Cin, const int* chan_map, int Cin_p, int Cout_p, std::vector<float>& wp);
-void pack_wino16(const float* w_oihw, int Cout, int Cin, const int* chan_map, int Cin_p, int Cout_p, std::vector<float>& wp);
-bool conv_wino16_eligible(const ConvArgs& a, bool any_size = false);
-int conv_wino16_launch(const ConvArgs& a, hipStream_t s, const char* name);   // experimental two-waves-per-SIMD form (conv_wino.hip)
 bool conv_wino_eligible(const ConvArgs& a);
 int conv_wino_mode(int set);      // set < 0: query.  0 automatic, 1 direct kernel only, 2 Winograd wherever legal
 int conv_wino_launch(const ConvArgs& a, int variant, hipStream_t s, const char* trace_name);

@@ -137,6 +137,13 @@ class FILM_VFI:
             else:
                 multipliers = list(map(int, multiplier))
                 multipliers += [2] * (n - len(multipliers) - 1)
+            # inference(..., inter_frames = m - 1) (film/__init__.py:12-41): m in {-1, 0, 1} runs no iteration and the pair contributes
+            # frame_i alone; m <= -2 fails in torch.linspace(0, 1, m + 1)
+            kept = [i for i in range(n - 1)
+                    if not (optional_interpolation_states is not None and optional_interpolation_states.is_frame_skipped(i))]
+            if any(multipliers[i] <= -2 for i in kept):
+                raise RuntimeError(f"FILM: multiplier {min(multipliers[i] for i in kept)} — the reference fails in torch.linspace for multipliers <= -2")
+            multipliers = [max(int(m), 1) for m in multipliers]
             dev = engine.device
             H, W = frames.shape[1:3]
             # pairs are independent (the bisection inside a pair is sequential): block-partition the kept pairs over

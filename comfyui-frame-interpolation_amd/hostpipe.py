@@ -53,7 +53,7 @@ class _T:
                 c[1] += dt
 
 
-POLL = os.environ.get("VFI_HOST_POLL", "0") == "1"
+POLL = False      # diagnostics (tools/node_e2e.py sets it): busy-poll the events instead of blocking in event.synchronize()
 
 
 def _wait(ev):

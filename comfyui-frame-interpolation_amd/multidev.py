@@ -43,10 +43,13 @@ def selected_devices(default_device=None):
     bad = [d for d in ids if d < 0 or d >= n]
     if bad or len(set(ids)) != len(ids):
         raise ValueError(f"VFI_DEVICES={spec!r}: devices {bad or ids} not valid ({n} visible, ids must be distinct)")
-    # the caller's device (where the cached engine and its weight arena live) is always the primary: the RCCL broadcast root
-    # must be a member of the clique, so a device list that leaves it out gets it prepended
-    if cur in ids:
-        ids.remove(cur)
+    # The caller's device (where the cached engine and its weight arena live) is the primary: the RCCL broadcast root must be a
+    # member of the clique.  An explicit list that leaves it out is refused — silently adding a GPU the user excluded (it may be
+    # busy or reserved) is worse than an error that says what to change.
+    if cur not in ids:
+        raise ValueError(f"VFI_DEVICES={spec!r} leaves out device {cur}, where this node's model lives (ComfyUI's current device): "
+                         f"add {cur} to the list, or make one of {ids} the current device before the node runs")
+    ids.remove(cur)
     ids.insert(0, cur)
     return ids
 

@@ -36,6 +36,7 @@ MAX_LIB_BATCH = 32  # kMaxTasks in csrc/rife_ops.h
 # rife/__init__.py:68-71) only trades memory for speed.  288 GB of HBM make
 # that trade moot: the node runs at least this many tasks per launch (8 below 4K, 4 from 4K up; 0 = honour the widget).
 MIN_NODE_BATCH = int(os.environ.get("VFI_RIFE_MIN_BATCH", "8"))
+HOST_TIMELINE = False      # diagnostics (tools/node_e2e.py sets it): print the per-launch host timeline of run_tasks
 
 
 def effective_batch(batch_size, H, W, n_tasks=None):
@@ -238,7 +239,7 @@ def run_tasks(engine, frames_cpu, tasks, batch_size, scale_factor=1.0, out_devic
     bufs8 = [torch.empty((bs, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(2)] if u8 else None
     buf_free = [None, None]
     import os, time
-    tl = [] if os.environ.get("VFI_HOST_TIMELINE") == "1" else None
+    tl = [] if HOST_TIMELINE else None
     if tl is not None:
         t_base = time.perf_counter()
         ev_base = torch.cuda.Event(enable_timing=True)

@@ -113,6 +113,8 @@ def generic_output_plan(n_frames, multiplier, states=None):
         for pair in range(n_frames - 1):
             if ms[pair] == 0:
                 continue
+            if ms[pair] < 0:       # the reference allocates torch.zeros(multiplier * 2, ...) for the pair: RuntimeError (vfi_utils.py:178)
+                raise ValueError(f"multiplier {ms[pair]} of pair {pair}: the reference's frame loop fails on negative multipliers")
             one_pair(pair, ms[pair], states is not None and states.is_frame_skipped(0))
             if pair == n_frames - 2:
                 plan.append(("src", n_frames - 1))

@@ -458,9 +458,12 @@ int vfi_comm_all_gather_v(vfi_comm_t* comm, float* const* bufs_dev, const int64_
 
 /* The copy list of that in-place all-gather: `n` ranks, per-rank counts -> quadruples (source rank, destination rank, offset,
  * count) into `plan` (4 int64 per copy; cap = capacity in int64; plan may be NULL to count).  Pure host function: what the direct
- * full-mesh path (VFI_ALLGATHER=direct, the default: one hipMemcpyPeerAsync per ordered device pair on its own stream — one xGMI
- * link each; VFI_ALLGATHER=rccl selects grouped per-root ncclBroadcast instead) executes.  Returns the number of copies or < 0. */
+ * full-mesh path (VFI_ALLGATHER=direct: one hipMemcpyPeerAsync per ordered device pair on its own stream — one xGMI link each)
+ * executes.  The default is grouped per-root ncclBroadcast (VFI_ALLGATHER=rccl): the direct form has not yet run on two or more
+ * physical devices.  Returns the number of copies or < 0. */
 int64_t vfi_comm_plan_all_gather(int n, const int64_t* counts, int64_t* plan, int64_t cap);
+/* What vfi_comm_all_gather_v uses in this process: 0 = direct peer copies, 1 = RCCL grouped broadcasts. */
+int vfi_comm_all_gather_mode(void);
 
 #ifdef __cplusplus
 }

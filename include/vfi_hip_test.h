@@ -29,8 +29,15 @@ int vfi_test_conv_algo(int mode);
  * [Cout_p/32][Cin_p/8][j][xi/4][half][co%32][xi%4], physical input channel = c8*8 + half*4 + j), written to a HOST buffer: lets the
  * CPU suite check the pack and emulate the kernel's addressing (tests/test_wino_emulation.py).  Returns floats written or < 0. */
 int64_t vfi_test_pack_wino3x3(const float* weight_host, int Cout, int Cin, const int* chan_map, int Cin_p, float* out_host, int64_t cap);
-/* the same for the experimental two-waves-per-SIMD kernel's layout (csrc/conv_wino.hip: pack_wino16) */
-int64_t vfi_test_pack_wino16(const float* weight_host, int Cout, int Cin, const int* chan_map, int Cin_p, float* out_host, int64_t cap);
+
+/* A/B options of tools/ and tests/: each selects between two CORRECT forms of a kernel or launch (csrc/vfi_common.h, enum Option):
+ *   stage_quad (bit mask, default 14), fuse_encode (1), fuse0a (1), m2n2_px (-1), grouped_variant (-1), splitk (1), splat_atomic (0),
+ *   splat_spill_cap (-1), wino_xcd (1), encode_batched (1).
+ * The product library reads NO experiment switch from the environment; this call is the only way to leave the defaults.
+ * Returns 0, or -2 for an unknown name. */
+int vfi_test_set_option(const char* name, int64_t value);
+/* Force direct-conv tile variants by trace name: "conv0a_b3=42,resconv_c128=36"; NULL / "" clears (tools/variant_sweep.sh). */
+int vfi_test_variant_override(const char* spec);
 
 /* Debug taps for parity tests: copy internal tensors of the LAST interpolate call to host.
  * what: 0 = flow after stage `stage` [B,Hp,Wp,4];  1 = stage input X of `stage`, planar4 [B,Cx/4,Hs,Ws,4];

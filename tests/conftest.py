@@ -33,6 +33,16 @@ def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
 
 
+def apply_test_options(lib):
+    """``VFI_TEST_OPTIONS="stage_quad=0,fuse_encode=0"`` — a variable of the TEST HARNESS (read here, never by the library): child
+    processes of A/B tests select the other of two correct kernel forms through ``vfi_test_set_option`` (include/vfi_hip_test.h)."""
+    for item in filter(None, os.environ.get("VFI_TEST_OPTIONS", "").split(",")):
+        name, value = item.split("=")
+        rc = lib.vfi_test_set_option(name.encode(), int(value))
+        assert rc == 0, f"vfi_test_set_option({name!r}) -> {rc}"
+    return lib
+
+
 @pytest.fixture(scope="session")
 def hip_lib():
     """The C-ABI library; builds it if the in-tree .so is missing or stale."""
@@ -41,4 +51,4 @@ def hip_lib():
     ge.build()
     from cfi_amd import _lib
 
-    return _lib.load()
+    return apply_test_options(_lib.load())

@@ -182,14 +182,15 @@ def test_softsplat_is_deterministic_and_exact_for_translations(lib):
     assert torch.equal(got, want), describe_diff(got, want, "uniform translation: bit-exact expected")
 
 
-@pytest.mark.parametrize("env", [{"VFI_SPLAT_SPILL_CAP": "64"}, {"VFI_SPLAT_MODE": "atomic"}])
-def test_softsplat_fallback_paths_in_a_fresh_process(env):
-    """the spill list overflowing (-> the LDS-atomic tile kernel redoes the launch) and the forced atomic mode: the settings are
-    read once per process, so the same tests run in a child process"""
+@pytest.mark.parametrize("opts", ["splat_spill_cap=64", "splat_atomic=1"])
+def test_softsplat_fallback_paths_in_a_fresh_process(opts):
+    """the spill list overflowing (-> the LDS-atomic tile kernel redoes the launch) and the forced atomic mode (A/B options of
+    include/vfi_hip_test.h, applied by the lib fixture from VFI_TEST_OPTIONS — a test-harness variable, not one the library reads):
+    the same tests run in a child process"""
     import subprocess
     import sys
 
-    e = dict(os.environ, **env)
+    e = dict(os.environ, VFI_TEST_OPTIONS=opts)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
                         "flow_fields or vs_c_oracle or prebuilt"], env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -116,3 +116,61 @@ def test_node_with_device_selection(hip_lib, sd, tmp_path, monkeypatch):
         for e in R._model_cache.values():
             e.close()
         R._model_cache.clear()
+
+
+_DIRECT_SNIPPET = """
+import sys
+sys.path.insert(0, {root!r})
+import torch
+from pkgload import load_package
+load_package()
+from cfi_amd import _lib, multidev
+lib = _lib.load()
+assert lib.vfi_comm_all_gather_mode() == 0, "VFI_ALLGATHER=direct not honoured"
+n = torch.cuda.device_count()
+devs = list(range(n))
+comm = multidev.Comm(devs)
+per = 1 << 18
+counts = [per + 1000 * r for r in range(n)]
+total = sum(counts)
+bufs, off = [], 0
+for r, d in enumerate(devs):
+    torch.cuda.set_device(d)
+    b = torch.full((total,), -1.0, device=f"cuda:{{d}}")
+    b[off:off + counts[r]] = float(r + 1)
+    bufs.append(b)
+    off += counts[r]
+for d in devs:
+    torch.cuda.synchronize(d)
+torch.cuda.set_device(0)
+for rep in range(2):
+    comm.all_gather_v([b.data_ptr() for b in bufs], counts)
+    # a library kernel launch on THIS thread right after the collective: a sticky HIP error left behind by the mesh set-up
+    # (hipErrorPeerAccessAlreadyEnabled) would surface in its hipGetLastError check
+    x = torch.rand(1, 8, 8, 4, device="cuda:0")
+    y = torch.empty(1, 16, 16, 4, device="cuda:0")
+    assert torch.cuda.current_device() == 0, "the collective moved the thread's current device"
+    _lib.check(lib.vfi_upsample_nearest(x.data_ptr(), 4, y.data_ptr(), 4, 1, 8, 8, 4, 2, 0, None), "kernel after all_gather_v")
+    comm.synchronize()
+want = torch.cat([torch.full((c,), float(r + 1)) for r, c in enumerate(counts)])
+for b in bufs:
+    assert torch.equal(b.cpu(), want)
+comm.close()
+print("direct all-gather ok on", n, "device(s)")
+"""
+
+
+def test_direct_all_gather_then_kernel(hip_lib):
+    """The direct full-mesh all-gather (VFI_ALLGATHER=direct; opt-in until this test has passed on two or more devices) on EVERY
+    visible device, unequal blocks, twice, with a library kernel launch right behind it on the issuing thread (the mesh
+    set-up must not leave hipErrorPeerAccessAlreadyEnabled in the thread's sticky error slot, nor move its current device).  On the
+    one-GPU test box the clique has one member (no peer pair: only the plumbing runs); the driver's 8-GPU node runs the real thing."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _DIRECT_SNIPPET.format(root=root)], env=dict(os.environ, VFI_ALLGATHER="direct"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "direct all-gather ok" in r.stdout

@@ -124,17 +124,6 @@ def test_conv3x3_winograd(lib, variant, cin, cout, n, h, w, res):
     _conv_case(lib, n, h, w, cin, cout, 1, res, variant)
 
 
-# the experimental two-waves-per-SIMD form (conv_wino16_kernel: 16x4-pixel wave regions on 16x16x4 MFMAs; hot epilogue, Cout <= 256):
-# odd sizes (partial regions in both directions), one and many chunks, 1 .. 8 channel blocks, more items than workgroups
-WINO16 = [(64, 64, 2, 37, 45), (8, 32, 1, 8, 16), (24, 40, 3, 19, 33), (192, 192, 1, 34, 60), (64, 64, 1, 1, 1), (128, 128, 2, 68, 120),
-          (16, 256, 1, 5, 70), (64, 64, 9, 272, 480)]
-
-
-@pytest.mark.parametrize("cin,cout,n,h,w", WINO16)
-def test_conv3x3_winograd_two_wave(lib, cin, cout, n, h, w):
-    _conv_case(lib, n, h, w, cin, cout, 1, False, 102)
-
-
 @pytest.mark.parametrize("act,post,pad_mode,res", [(0, None, 0, False), (1, None, 0, False), (3, None, 1, False), (4, (0.8, 0.1), 0, False), (5, None, 0, False),
                                                    (3, None, 0, True), (1, (2.0, -0.5), 1, True), (2, None, 0, False)])
 def test_layer_object_winograd_matches_direct_and_torch(lib, act, post, pad_mode, res):
@@ -197,21 +186,14 @@ def test_layer_object_winograd_matches_direct_and_torch(lib, act, post, pad_mode
 
 @pytest.mark.parametrize("gvariant", [None, 12, 13, 43, 44])
 @pytest.mark.parametrize("cin,h,w", [(64, 17, 30), (192, 9, 15), (96, 34, 60)])
-def test_deconv4x4_pixelshuffle(lib, cin, h, w, gvariant, monkeypatch):
-    import os
-    import subprocess
-    import sys
-
-    if gvariant is not None:
-        # the variant hook is read once per process: run this case in a child process
-        env = dict(os.environ, VFI_GROUPED_VARIANT=str(gvariant), VFI_CHILD="1")
-        code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import conftest, test_gpu_ops as t; "
-                "import cfi_amd._lib as L; lib=L.load(); L.check(lib.vfi_init(0),'init'); "
-                "t._deconv_case(lib, %d, %d, %d)" % (os.path.dirname(__file__), os.path.dirname(os.path.dirname(__file__)), cin, h, w))
-        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-        return
-    _deconv_case(lib, cin, h, w)
+def test_deconv4x4_pixelshuffle(lib, cin, h, w, gvariant):
+    # A/B option grouped_variant forces a tile variant of the transposed convolution (read at every launch)
+    try:
+        if gvariant is not None:
+            assert lib.vfi_test_set_option(b"grouped_variant", gvariant) == 0
+        _deconv_case(lib, cin, h, w)
+    finally:
+        lib.vfi_test_set_option(b"grouped_variant", -1)
 
 
 def _deconv_case(lib, cin, h, w):

@@ -638,9 +638,10 @@ import sys, torch
 sys.path.insert(0, {root!r})
 from pkgload import load_package
 load_package()
-from cfi_amd import synth
+from cfi_amd import _lib, synth
 from cfi_amd.rife import RifeEngine, run_tasks
 torch.cuda.set_device(0)
+assert _lib.load().vfi_test_set_option(b"stage_quad", {mask}) == 0
 outs = []
 for arch, mk in (("4.7", synth.rife47_synth_state_dict), ("4.17", synth.rife417_synth_state_dict)):
     e = RifeEngine(mk(77), arch)
@@ -653,7 +654,7 @@ torch.save(outs, {out!r})
 
 
 def test_quad_transition_matches_cell_kernel(hip_lib, tmp_path):
-    """stage_trans_quad_kernel restates stage_trans_kernel expression for expression: VFI_STAGE_QUAD=0 (cell kernel
+    """stage_trans_quad_kernel restates stage_trans_kernel expression for expression: option stage_quad = 0 (cell kernel
     for every transition) and the default (quad kernel for the 8->4 and 4->2 transitions) must agree to rounding
     noise, including frames whose padded size leaves partial 16x4-cell tiles.  Not to the bit: HIP's __fmul_rn /
     __fadd_rn are plain operators, so hipcc picks the FMA contractions of the bilinear expressions per kernel
@@ -665,8 +666,7 @@ def test_quad_transition_matches_cell_kernel(hip_lib, tmp_path):
     res = {}
     for mask in ("0", "6"):
         out = str(tmp_path / f"quad{mask}.pt")
-        env = dict(os.environ, VFI_STAGE_QUAD=mask)
-        subprocess.run([sys.executable, "-c", _QUAD_SNIPPET.format(root=root, out=out)], check=True, env=env, timeout=300)
+        subprocess.run([sys.executable, "-c", _QUAD_SNIPPET.format(root=root, out=out, mask=mask)], check=True, timeout=300)
         res[mask] = torch.load(out)
     for a, b in zip(res["0"], res["6"]):
         assert (a - b).abs().max().item() <= 5e-5, describe_diff(a, b, "quad vs cell transition")
@@ -753,8 +753,8 @@ def test_fused_last_transition_matches_unfused(hip_lib, sd, h, w, bs):
         assert (fused - want).abs().max().item() <= 1e-3, describe_diff(fused, want, "fused path vs oracle")
 
 
-def _pack_dump(path, h, w, u8):
-    """(child-process helper) frame pack of a seeded frame -> file"""
+def _frame_pack(h, w, u8):
+    """frame pack (planar4 rgb | encode features) of a seeded frame"""
     from cfi_amd.rife import RifeEngine
 
     sd_ = synth.rife47_synth_state_dict(1234)
@@ -766,26 +766,21 @@ def _pack_dump(path, h, w, u8):
             fr = (fr.clamp(0, 1) * 255).round().to(torch.uint8)
         eng.load_frame(1, fr.cuda().contiguous())
         hp, wp = -(-h // 64) * 64, -(-w // 64) * 64
-        pk = eng.debug_read(2, 1, hp * wp * 8)
-        np.save(path, pk.numpy())
+        return eng.debug_read(2, 1, hp * wp * 8).numpy()
     finally:
         eng.close()
 
 
 @pytest.mark.parametrize("h,w,u8", [(70, 90, False), (1080, 1920, False), (200, 330, True)])
-def test_fused_frame_pack_is_bit_identical(hip_lib, tmp_path, h, w, u8):
+def test_fused_frame_pack_is_bit_identical(hip_lib, h, w, u8):
     """arch 4.7: prep + encode.0 + encode.1 in one launch (encode47_fused_kernel, E never in HBM) gives BIT-IDENTICAL frame packs
-    to the three-kernel path (VFI_RIFE_FUSE_ENCODE=0; the switch is read once per process, so each side runs in its own)."""
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    to the three-kernel path (A/B option fuse_encode = 0, include/vfi_hip_test.h: vfi_test_set_option)."""
     outs = []
-    for flag in ("1", "0"):
-        path = str(tmp_path / f"pack{flag}.npy")
-        code = (f"import sys; sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r}); import conftest, test_gpu_rife as t; "
-                f"t._pack_dump({path!r}, {h}, {w}, {u8})")
-        subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, VFI_RIFE_FUSE_ENCODE=flag), timeout=300)
-        outs.append(np.load(path))
+    try:
+        for flag in (1, 0):
+            assert hip_lib.vfi_test_set_option(b"fuse_encode", flag) == 0
+            outs.append(_frame_pack(h, w, u8))
+    finally:
+        hip_lib.vfi_test_set_option(b"fuse_encode", 1)
     assert outs[0].shape == outs[1].shape and np.array_equal(outs[0], outs[1]), float(np.abs(outs[0] - outs[1]).max())
     assert np.abs(outs[0]).max() > 0.1

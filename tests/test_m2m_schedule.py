@@ -56,6 +56,8 @@ def test_plan_known_answers():
     assert plan == [("src", 0), ("new", 0)]
     with pytest.raises(NotImplementedError):
         generic_output_plan(3, 2.0, None)
+    with pytest.raises(ValueError, match="negative"):       # the reference's torch.zeros(multiplier * 2, ...) raises (vfi_utils.py:178)
+        generic_output_plan(3, [2, -1], None)
 
 
 @pytest.mark.parametrize("multiplier,spec", CASES)

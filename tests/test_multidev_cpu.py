@@ -66,8 +66,11 @@ def test_device_selection(monkeypatch):
     assert multidev.selected_devices() == [2]                                   # default: ComfyUI's device only
     monkeypatch.setenv("VFI_DEVICES", "all")
     assert multidev.selected_devices() == [2, 0, 1, 3, 4, 5, 6, 7]             # the caller's device stays the primary
+    monkeypatch.setenv("VFI_DEVICES", "4,2,5")
+    assert multidev.selected_devices() == [2, 4, 5]      # the engine's device is the primary (it holds the weight arena = broadcast root)
     monkeypatch.setenv("VFI_DEVICES", "4,5")
-    assert multidev.selected_devices() == [2, 4, 5]      # the engine's device is always the primary (it holds the weight arena = broadcast root)
+    with pytest.raises(ValueError, match="leaves out device 2"):      # never silently add a GPU the user excluded
+        multidev.selected_devices()
     monkeypatch.setenv("VFI_DEVICES", "1,1")
     with pytest.raises(ValueError):
         multidev.selected_devices()

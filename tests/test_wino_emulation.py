@@ -211,99 +211,3 @@ def test_work_order_keeps_channel_siblings_on_one_xcd():
     assert len(flat) == NQ and all(len(v) == 1 for v in flat.values())        # all Cout/32 siblings of a quad on one XCD
     counts = [len(lst) for lst in items]
     assert max(counts) - min(counts) <= 2 and sum(counts) == NQ * 2
-
-
-# ---------------------------------------------------------------------------------------------------------------------
-# The experimental two-waves-per-SIMD form (conv_wino16_kernel, docs/design/winograd.md section 6 b): 16 tiles (16x4 pixels) per wave
-# on v_mfma_f32_16x16x4_f32, lane l = (tile m = l % 16, K slot kq = l / 16), channels (2 kq, 2 kq + 1) per lane.
-def pack16(lib, w, cin_p):
-    cout, cin = w.shape[:2]
-    cout_p = (cout + 31) // 32 * 32
-    out = np.zeros(16 * cin_p * cout_p, np.float32)
-    w = np.ascontiguousarray(w, np.float32)
-    n = lib.vfi_test_pack_wino16(w.ctypes.data, cout, cin, None, cin_p, out.ctypes.data, out.size)
-    assert n == out.size
-    return out, cout_p
-
-
-def emulate16(x, wp, bias, cout, cout_p):
-    """x [N,H,W,Cin_p]; one wave per 16x4 region and channel block, the kernel's formulas restated: DMA slot -> (stored pixel, quad)
-    with a row's even columns first, the b64 patch reads, the row-by-row transform, the 16x16x4 MFMA operand / result lanes
-    (checked on the hardware: tools/micro/mfma16_layout.hip), the per-position B item of pack_wino16, the epilogue's tile map."""
-    PW, PH = 18, 6
-    N, H, W, cin_p = x.shape
-    C8, NY = cin_p // 8, cout_p // 32
-    out = np.full((N, H, W, cout), np.nan, np.float64)
-    written = np.zeros((N, H, W, cout), np.int32)
-    lanes = np.arange(64)
-    m, kq = lanes & 15, lanes >> 4
-    ty, tx = m >> 3, m & 7
-    for n in range(N):
-        for Ry0 in range(0, H, 4):
-            for Rx0 in range(0, W, 16):
-                for nb in range(NY):
-                    acc = np.zeros((16, 2, 16, 16), np.float64)       # [xi][nblk][tile][co % 16]
-                    for k in range(C8):
-                        # LDS image of the wave: 256 slots x 4 floats
-                        A = np.zeros((256, 4), np.float32)
-                        for sp in range(PW * PH * 2):
-                            pix, q = sp >> 1, sp & 1
-                            py, pj = divmod(pix, PW)
-                            px = 2 * pj if pj < PW // 2 else 2 * (pj - PW // 2) + 1
-                            iy, ix = Ry0 - 1 + py, Rx0 - 1 + px
-                            qs = q ^ ((py >> 1) & 1)          # rows 2,3 store a pixel's two 16-byte halves swapped
-                            if 0 <= iy < H and 0 <= ix < W:
-                                A[sp] = x[n, iy, ix, k * 8 + qs * 4:k * 8 + qs * 4 + 4]
-                        Af = A.reshape(-1)
-                        base0 = ((ty * 2) * PW + tx) * 8 + (kq & 1) * 2                    # in floats (32 B per pixel, 8 B per K slot)
-                        P = np.zeros((16, 64, 2), np.float32)
-                        for dy in range(4):
-                            base = base0 + (((kq >> 1) ^ ((ty + (dy >> 1)) & 1)) << 2)
-                            for dx in range(4):
-                                o = base + (dy * PW + (dx & 1) * (PW // 2) + (dx >> 1)) * 8
-                                P[dy * 4 + dx] = Af[o[:, None] + np.arange(2)[None]]
-                        d = P.reshape(4, 4, 64, 2)
-                        t = np.stack([d[0] - d[2], d[1] + d[2], d[2] - d[1], d[1] - d[3]])       # [r][c][lane][pair]
-                        V = np.stack([t[:, 0] - t[:, 2], t[:, 1] + t[:, 2], t[:, 2] - t[:, 1], t[:, 1] - t[:, 3]], axis=1).reshape(16, 64, 2)
-                        B = wp[((nb * C8 + k) * 16) * 256:((nb * C8 + k) * 16 + 16) * 256].reshape(16, 64, 4)     # [xi][lane][h * 2 + nblk]
-                        for xi in range(16):
-                            for h in range(2):
-                                for nb2 in range(2):
-                                    # D[i][j] += sum_kk A[i][kk] B[kk][j]: A lane l = (i = l % 16, kk = l / 16), B lane l = (kk = l / 16, j = l % 16)
-                                    a_op = V[xi, :, h].reshape(4, 16).astype(np.float64)          # [kk][i]
-                                    b_op = B[xi, :, h * 2 + nb2].reshape(4, 16).astype(np.float64)   # [kk][j]
-                                    acc[xi, nb2] += np.einsum("ki,kj->ij", a_op, b_op)
-                    for nb2 in range(2):
-                        M = acc[:, nb2].reshape(4, 4, 16, 16)                  # [row][col][tile][co16]
-                        s0 = M[0] + M[1] + M[2]
-                        s1 = M[1] - M[2] - M[3]
-                        y = [s0[0] + s0[1] + s0[2], s0[1] - s0[2] - s0[3], s1[0] + s1[1] + s1[2], s1[1] - s1[2] - s1[3]]
-                        for mm in range(16):
-                            for ey in range(2):
-                                for ex in range(2):
-                                    oy, ox = Ry0 + 2 * (mm >> 3) + ey, Rx0 + 2 * (mm & 7) + ex
-                                    if oy >= H or ox >= W:
-                                        continue
-                                    for j in range(16):
-                                        co = nb * 32 + nb2 * 16 + j
-                                        if co < cout:
-                                            out[n, oy, ox, co] = y[ey * 2 + ex][mm, j] + bias[co]
-                                            written[n, oy, ox, co] += 1
-    assert (written == 1).all(), "every output written exactly once"
-    return out
-
-
-@pytest.mark.parametrize("N,H,W,cin,cout", [(1, 7, 21, 12, 40), (2, 4, 16, 8, 32), (1, 9, 33, 16, 17)])
-def test_emulated_two_wave_kernel_matches_conv2d(hip_lib, N, H, W, cin, cout):
-    g = torch.Generator().manual_seed(H * 10 + W)
-    cin_p = (cin + 7) // 8 * 8
-    x = torch.rand(N, cin, H, W, generator=g, dtype=torch.float64) * 2 - 1
-    w = (torch.rand(cout, cin, 3, 3, generator=g, dtype=torch.float64) * 2 - 1) / (cin * 9) ** 0.5
-    b = torch.rand(cout, generator=g, dtype=torch.float64) - 0.5
-    xin = torch.rand(N, H, W, cin_p, generator=g, dtype=torch.float64)      # garbage in the padded channels: zero weights must cancel it
-    xin[..., :cin] = x.permute(0, 2, 3, 1)
-    wp, cout_p = pack16(hip_lib, w.numpy().astype(np.float32), cin_p)
-    got = emulate16(xin.numpy().astype(np.float32), wp, b.numpy(), cout, cout_p)
-    want = (F.conv2d(F.pad(x, (1, 1, 1, 1)).float().double(), w.float().double()) + b.view(1, -1, 1, 1)).permute(0, 2, 3, 1).numpy()
-    err = np.abs(got - want).max()
-    assert err <= 2e-6, err

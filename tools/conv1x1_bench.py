@@ -1,5 +1,5 @@
 """GPU micro-benchmark of the 1x1 layer objects on GMFSS's transformer shapes (1080p: 130560 / 16320 tokens) for a set of tile
-variants (VFI_VARIANT_OVERRIDE is read once per process, so this script re-runs itself per variant)."""
+variants (forced per trace name through vfi_test_variant_override, include/vfi_hip_test.h)."""
 import os
 import subprocess
 import sys
@@ -43,13 +43,13 @@ def child():
 
 
 if __name__ == "__main__":
-    if "--child" in sys.argv:
-        child()
-        sys.exit(0)
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    ge.load_package()
+    from cfi_amd import _lib as _L
     names = [f"conv1x1s1_{cin}to{cout}" for _, _, _, cin, cout, _ in SHAPES]
     for label, var in [("picker", None), ("m2n2 k8 (48)", 48), ("m1n2 k8 (49)", 49), ("m1n2 k32 (55)", 55), ("m2n2w22 k32 (56)", 56)]:
-        env = dict(os.environ)
-        if var is not None:
-            env["VFI_VARIANT_OVERRIDE"] = ",".join(f"{n}={var}" for n in sorted(set(names)))
-        r = subprocess.run([sys.executable, __file__, "--child"], env=env, capture_output=True, text=True)
-        print(f"{label:16s} {r.stdout.strip().splitlines()[-1] if r.stdout.strip() else 'FAILED: ' + r.stderr.strip().splitlines()[-1]}", flush=True)
+        spec = ",".join(f"{n}={var}" for n in sorted(set(names))) if var is not None else ""
+        _L.load().vfi_test_variant_override(spec.encode())        # A/B hook of include/vfi_hip_test.h (tile variant by trace name)
+        print(f"{label:16s} ", end="", flush=True)
+        child()

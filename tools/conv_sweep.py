@@ -90,23 +90,17 @@ def run_deconv(n, h, w, cin, reps=5):
     return tot / calls
 
 
-if __name__ == "__main__" and os.environ.get("VFI_GROUPED_VARIANT"):
-    # child mode: grouped (transposed-conv) variant forced through the environment hook
-    B = int(sys.argv[1])
-    for name, h, w, cin in (("last_b3", 272, 480, 64), ("last_b2", 136, 240, 96), ("last_b1", 68, 120, 128), ("last_b0", 34, 60, 192)):
-        ms = run_deconv(B, h, w, cin)
-        flop = 2.0 * B * h * w * cin * 24 * 16
-        print(f"{name:10s} {B:2d} grouped_v{os.environ['VFI_GROUPED_VARIANT']:3s} {ms:8.4f} {flop / (ms * 1e-3) / 1e12:8.2f} (algorithmic TFLOP/s)", flush=True)
-    sys.exit(0)
-
 if __name__ == "__main__":
     batches = [int(a) for a in sys.argv[1:]] or [1, 8]
-    import subprocess
+    from cfi_amd import _lib as _L
     for B in batches:
-        for gv in (12, 13, 43, 44):
-            r = subprocess.run([sys.executable, __file__, str(B)], env=dict(os.environ, VFI_GROUPED_VARIANT=str(gv)),
-                               capture_output=True, text=True)
-            print(r.stdout.strip() or r.stderr[-300:], flush=True)
+        for gv in (12, 13, 43, 44):      # grouped (transposed-conv) tile variants, forced through the A/B option (include/vfi_hip_test.h)
+            assert _L.load().vfi_test_set_option(b"grouped_variant", gv) == 0
+            for name, h, w, cin in (("last_b3", 272, 480, 64), ("last_b2", 136, 240, 96), ("last_b1", 68, 120, 128), ("last_b0", 34, 60, 192)):
+                ms = run_deconv(B, h, w, cin)
+                flop = 2.0 * B * h * w * cin * 24 * 16
+                print(f"{name:10s} {B:2d} grouped_v{gv:<3d} {ms:8.4f} {flop / (ms * 1e-3) / 1e12:8.2f} (algorithmic TFLOP/s)", flush=True)
+        _L.load().vfi_test_set_option(b"grouped_variant", -1)
     print(f"{'layer':10s} {'B':>2s} {'variant':12s} {'ms':>8s} {'TFLOP/s':>8s} {'frac':>6s}")
     for name, h, w, cin, cout, stride, res in LAYERS:
         for B in batches:
