@@ -14,14 +14,19 @@ outputs written to HBM.  N>1: every rank runs its own stream (weak scaling, pair
 and the new frames are all-gathered over RCCL/xGMI, overlapped with the next step.
 
 Rank 0 prints ONE JSON line.  Extra objects:
-  roofline     — dominant kernel (block3 ResConv 3x3, 64->64 ch @272x480, fp32 MFMA): algorithmic (direct-form) FLOP
-                 per launch / average launch duration measured with HIP events on the launch stream
-                 (library-side tracing, second pass of the same K steps); peak = 157.3 TFLOP/s.  The kernel is the Winograd
-                 F(2x2,3x3) form (csrc/conv_wino.hip): it issues 2.25x fewer MFMA FLOP than the direct form the algorithmic
-                 count assumes, so `frac` may exceed 1; `executed` states the matrix-pipe utilisation (MFMA FLOP issued / peak).
-  roofline_hbm — the HBM-class kernels (transitions with their warps, final blend; M2M's summation splat and cost volume):
-                 algorithmic bytes per launch / HIP-event launch duration, against 8.0 TB/s spec and
-                 the 6.29 TB/s a float4 copy reaches on this chip.
+  roofline     — dominant kernel (block3 ResConv 3x3, 64->64 ch @272x480, fp32 MFMA).  The kernel is the Winograd F(2x2,3x3) form
+                 (csrc/conv_wino.hip): `achieved` / `frac` count the MFMA FLOP it ISSUES per launch (direct form / 2.25, on whole
+                 16x8-pixel regions) / the average launch duration measured with HIP events on the launch stream (library-side
+                 tracing, second pass of the same K steps) against the 157.3 TFLOP/s fp32-MFMA peak — a hardware utilisation, <= 1.
+                 `algorithmic_equiv` prices the same time in direct-form FLOP (2 * pixels * Cin * Cout * 9, SURVEY 8d: what the
+                 layer is worth to any implementation); it exceeds the peak because Winograd skips 5/9 of those multiplications.
+  roofline_hbm — the HBM-class kernels (frame pack, transitions with their warps, final blend; M2M's summation splat — inside
+                 M2M and on SURVEY 8d config 5's i.i.d. sigma = 8 px field): algorithmic bytes per launch
+                 / HIP-event launch duration, against 8.0 TB/s spec and the 6.29 TB/s a float4 copy reaches on this chip.  The
+                 M2M cost volume is VALU / LDS bound and is priced against its VALU floor (`bound: "valu"`).
+  strong_4k_x4 — BASELINE configs[3]: RIFE 4.9 (arch 4.7), multiplier 4, a 17-frame 2160x3840 host clip = 48 tasks,
+                 block-partitioned over the ranks with one halo frame per block (unequal blocks where 48 % N != 0), new frames
+                 all-gathered device-side: STRONG scaling (fixed total work), reported beside the weak-scaling headline.
   cpu_baseline — the oracle (torch-CPU restatement, bit-exact vs the reference in the build container)
                  timed on this host's cores on a bounded sample (N=1, rank 0 only); host CPU model and core count stated.
   e2e          — SURVEY 8(d) config 2, PCIe-inclusive (never `value`): a host clip [33,1080,1920,3] fp32
@@ -55,6 +60,17 @@ def hbm_entry(kernel, bytes_per_launch, ms_per_launch, launches):
     return {"kernel": kernel, "bound": "hbm", "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(ms_per_launch, 4),
             "launches": launches, "achieved": round(tbps, 3), "unit": "TB/s", "peak": HBM_SPEC_TBPS, "frac": round(tbps / HBM_SPEC_TBPS, 4),
             "frac_of_copy_rate": round(tbps / HBM_COPY_TBPS, 4)}
+
+
+VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9      # 256 CUs x 4 SIMD-32 x 2.4 GHz (MI355X_MICROARCH.md): 78.6 T lane-ops/s = 157.3 TFLOP/s / 2
+
+
+def valu_entry(kernel, lane_ops_per_launch, ms_per_launch, launches, note):
+    floor_ms = lane_ops_per_launch / VALU_LANE_OPS_PER_S * 1e3
+    return {"kernel": kernel, "bound": "valu", "lane_ops_per_launch": int(lane_ops_per_launch), "avg_launch_ms": round(ms_per_launch, 4),
+            "launches": launches, "valu_floor_ms": round(floor_ms, 4), "peak": round(VALU_LANE_OPS_PER_S / 1e12, 1), "unit": "T lane-ops/s",
+            "achieved": round(lane_ops_per_launch / (ms_per_launch * 1e-3) / 1e12, 2) if ms_per_launch else None,
+            "frac": round(floor_ms / ms_per_launch, 4) if ms_per_launch else None, "note": note}
 
 
 def clip_frames(B):
@@ -118,7 +134,7 @@ def e2e_leg(sd, dev, H, W, n_frames=33, reps=3):
         R.load_file_from_github_release = lambda model_type, ckpt: pth
         try:
             node = R.RIFE_VFI()
-            times, times8 = [], []
+            times, times8, first = [], [], {}
             for clip, acc in ((frames, times), (frames8, times8)):
                 for i in range(reps + 2):           # two warm-up calls: checkpoint load, workspace, pinned rings — and the ring / page
                                                     # cache state the second call still settles (it measures 1.5-2x the steady state)
@@ -130,6 +146,8 @@ def e2e_leg(sd, dev, H, W, n_frames=33, reps=3):
                     del res                         # release of the 1.6 GB result happens outside the timed region
                     if i > 1:
                         acc.append(dt)
+                    elif clip is frames:
+                        first[i] = dt
         finally:
             R.load_file_from_github_release = saved
             for e in R._model_cache.values():
@@ -145,6 +163,9 @@ def e2e_leg(sd, dev, H, W, n_frames=33, reps=3):
         "value": round(new / med, 2),
         "unit": "interpolated frames/s (PCIe-inclusive, host tensor to host tensor)",
         "seconds": [round(t, 4) for t in times],
+        "spread": round((max(times) - min(times)) / med, 4),
+        "first_call_s": round(first.get(0, float("nan")), 4),       # checkpoint load + weight pack + workspace + pinned rings
+        "second_call_s": round(first.get(1, float("nan")), 4),      # ring / page-cache state still settling
         "h2d_bytes": n_frames * H * W * 3 * 4,
         "d2h_bytes": new * H * W * 3 * 4,
         "pcie_pinned_GBps": rates,
@@ -210,11 +231,43 @@ def other_paths(dev, H, W):
         calls, ms = rep["costvol9x9"]
         levels = [(hp >> k, wp >> k) for k in range(2, 7)]             # 272x480 ... 17x30, both directions in one launch
         tot = sum(2 * (2 * 32 * 4 + 81 * 4) * h * w for h, w in levels)
-        e = hbm_entry("costvol9x9 (M2M prepare: 5 pyramid levels %s, 32 channels, both directions per launch; bytes and time summed over "
-                      "the levels)" % "/".join(f"{h}x{w}" for h, w in levels), tot, ms / calls * 5, calls // 5)
+        # 81 displacements x 32 channels x (v_sub_f32 + v_add_f32 |x|) per pixel and direction; the LDS floor (81 x 8 ds_read_b128 per
+        # pixel at 4 LDS cycles per wave instruction) is the same 23 us — an HBM fraction could never approach 1 for this kernel
+        ops = sum(2 * 81 * 32 * 2 * h * w for h, w in levels)
+        e = valu_entry("costvol9x9 (M2M prepare: 5 pyramid levels %s, 32 channels, both directions per launch; work and time summed over "
+                       "the levels)" % "/".join(f"{h}x{w}" for h, w in levels), ops, ms / calls * 5, calls // 5,
+                       "2 VALU lane-ops per (displacement, channel); algorithmic HBM bytes %d (%.3f TB/s): not the bound; the coarse levels "
+                       "(4 .. 60 workgroups) are launch-latency bound" % (tot, tot / (ms / calls * 5 * 1e-3) / 1e12))
         hbm.append(e)
-    out["roofline_hbm"] = hbm
     eng.close()
+    # the splat micro-benchmark — in [1,4,1088,1920] U[0,1), flow i.i.d. N(0, 8 px) seed 2 (an INCOHERENT field:
+    # the stress case of cupy_ops/softsplat.py:140-192), 8 launches; all passes of a launch are summed
+    try:
+        import ctypes as C_
+
+        g = torch.Generator(device="cpu").manual_seed(2)
+        x = torch.rand(1, hp, wp, 4, generator=g).to(dev)
+        fl = (torch.randn(1, hp, wp, 2, generator=g) * 8.0).to(dev)
+        o = torch.empty_like(x)
+        pp = lambda t: C_.c_void_p(t.data_ptr())
+        _lib.check(lib.vfi_softsplat_sum(pp(x), pp(fl), pp(o), 1, hp, wp, 4, _lib.stream_ptr()), "vfi_softsplat_sum")
+        torch.cuda.synchronize(dev)
+        lib.vfi_trace_reset()
+        lib.vfi_trace_enable(1)
+        for _ in range(8):
+            _lib.check(lib.vfi_softsplat_sum(pp(x), pp(fl), pp(o), 1, hp, wp, 4, _lib.stream_ptr()), "vfi_softsplat_sum")
+        torch.cuda.synchronize(dev)
+        lib.vfi_trace_enable(0)
+        rep = _lib.trace_report()
+        lib.vfi_trace_reset()
+        calls = rep["softsplat_sum"][0]
+        ms = sum(v[1] for v in rep.values())
+        e = hbm_entry("softsplat_sum micro-benchmark (SURVEY 8d config 5: [1,%d,%d,4], flow i.i.d. N(0, 8 px) seed 2; every pass of a launch: %s)"
+                      % (hp, wp, ", ".join(f"{k} {v[1] / v[0] * 1e3:.1f} us" for k, v in rep.items())), (4 + 2 + 4) * 4.0 * hp * wp, ms / calls, calls)
+        hbm.append(e)
+    except Exception as ex:      # never lose the line to an extra leg
+        hbm.append({"kernel": "softsplat_sum micro-benchmark", "error": f"{type(ex).__name__}: {ex}"})
+    out["roofline_hbm"] = hbm
     return out
 
 
@@ -262,6 +315,87 @@ def other_paths_dist(dev, H, W, world, rank, backend):
     out["m2m_2x"] = {"frames_per_s": round(world / t, 1), "ms_per_pair_per_gpu": round(t * 1e3, 3), "sharding": "frame pairs over ranks, all-gather of new frames"}
     eng.close()
     return out
+
+
+def strong_4k_x4(args, dev, world, rank, backend, group=None):
+    """BASELINE.json configs[3] / SURVEY 8(d) config 4: RIFE 4.9 (= arch 4.7, rife/__init__.py CKPT_NAME_VER_DICT), multiplier 4, a
+    17-frame 2160x3840 host clip -> 16 pairs x 3 timesteps = 48 independent tasks (rife/__init__.py:164-174).  STRONG scaling: the
+    task list is block-partitioned over the ranks (schedule.shard_tasks: 48 = 8 x 6, but 7 + 7 + ... at N = 5, 6, 7 and 24 / 12 at
+    N = 2 / 4), every rank uploads only the frames its block touches (its pairs + one halo frame), interpolates with the node's own
+    host pipeline (rife.run_tasks: pinned staging, uploads ahead of compute) and the new frames are all-gathered device-side over
+    RCCL.  Timed between barriers from host clip to gathered device frames, max over ranks; PCIe-inclusive on the input side.
+    ``group`` (one process, N device threads): the node's multidev path instead — every device copies its shard into the shared
+    host output tensor (RifeDeviceGroup.run -> run_sharded)."""
+    from cfi_amd import synth
+    from cfi_amd.dist import all_gather_frames
+    from cfi_amd.rife import RifeEngine, effective_batch, run_tasks
+    from cfi_amd.schedule import rife_task_list, shard_tasks
+
+    H, W, n_frames, mult = args.strong_height, args.strong_width, args.strong_frames, 4
+    g = torch.Generator(device="cpu").manual_seed(0)
+    frames = torch.rand((n_frames, H, W, 3), generator=g, dtype=torch.float32)      # the same clip on every rank
+    _, tasks = rife_task_list(n_frames, mult, None)
+    bounds = [shard_tasks(tasks, r, world) for r in range(world)]
+    counts = [hi - lo for lo, hi in bounds]
+    lo, hi = bounds[rank]
+    bs = effective_batch(1, H, W, max(counts))
+    if group is not None:      # single process, device threads
+        from cfi_amd.hostpipe import prefault_async
+
+        out = torch.empty((len(tasks), H, W, 3), dtype=torch.float32)
+        for f in prefault_async(out):
+            f.result()
+
+        def once():
+            group.run(frames, tasks, bs, 1.0, out, list(range(len(tasks))))
+    else:
+        import torch.distributed as dist
+
+        eng = RifeEngine(synth.rife47_synth_state_dict(49), "4.7", device=dev)
+
+        def once():
+            local = run_tasks(eng, frames, tasks[lo:hi], bs, 1.0, out_device=True)
+            gathered = all_gather_frames(local, counts) if world > 1 else local
+            torch.cuda.synchronize(dev)
+            return gathered.shape[0]
+
+    def sync():
+        if group is None and world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    once()                     # warm-up: workspace for 4K, pinned rings
+    times = []
+    for _ in range(args.strong_reps):
+        sync()
+        t0 = time.perf_counter()
+        once()
+        sync()
+        dt = time.perf_counter() - t0
+        if group is None and world > 1:
+            import torch.distributed as dist
+
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        times.append(dt)
+    if group is None:
+        eng.close()
+    best = min(times)
+    return {
+        "workload": f"RIFE 4.9 (arch 4.7) x{mult}, {n_frames}-frame {H}x{W} host clip (torch.manual_seed(0) torch.rand) = {len(tasks)} tasks; "
+                    f"contiguous task blocks per rank {counts} (+ 1 halo frame each), {bs} tasks per launch",
+        "scaling": "strong",
+        "value": round(len(tasks) / best, 2),
+        "unit": "interpolated frames/s (whole job; host clip in, " + ("host tensor out" if group is not None else "gathered device frames out") + ")",
+        "n_gpus": world,
+        "seconds": [round(t, 4) for t in times],
+        "tasks_per_rank": counts,
+        "collective": "none (N = 1)" if world == 1 else ("each device copies its own shard into the shared host output (multidev.run_sharded)" if group is not None
+                       else ("all_gather_into_tensor over RCCL, blocks padded to the largest" if backend == "nccl" else "all_gather (gloo, host)")),
+    }
 
 
 def cpu_baseline(sd, H, W, budget_s=25.0):
@@ -354,8 +488,7 @@ def main_single_process(args):
         if ev_gath[r][k] is not None:
             main.wait_event(ev_gath[r][k])           # this buffer's previous all-gather has finished
         base = clip_base(B, k)
-        for j in range(B + 1):
-            eng.load_frame(j, raw[r][base + j])
+        eng.load_frames(list(range(B + 1)), [raw[r][base + j] for j in range(B + 1)])
         eng.interpolate(slot0, slot1, ts, bufs[r][k][r * B:(r + 1) * B])
         if gather:
             e = torch.cuda.Event()
@@ -413,17 +546,21 @@ def main_single_process(args):
     eng0 = group.engines[0]
     t0 = time.perf_counter()
     for i in range(K):
-        for j in range(B + 1):
-            eng0.load_frame(j, raw[0][clip_base(B, i & 1) + j])
+        eng0.load_frames(list(range(B + 1)), [raw[0][clip_base(B, i & 1) + j] for j in range(B + 1)])
         eng0.interpolate(slot0, slot1, ts, bufs[0][i & 1][:B])
     torch.cuda.synchronize(0)
     traced = time.perf_counter() - t0
     lib.vfi_trace_enable(0)
     rep = _lib.trace_report()
     lib.vfi_trace_reset()
-    res = result_line(args, N, elapsed, traced, rep, eng0,
-                      "all_gather_v (RCCL grouped broadcasts, in place, comm streams), overlapped" if gather else "none")
+    mode = "RCCL grouped per-root broadcasts" if lib.vfi_comm_all_gather_mode() == 1 else "direct peer copies, one per ordered device pair"
+    res = result_line(args, N, elapsed, traced, rep, eng0, f"all_gather_v ({mode}; in place, comm streams), overlapped" if gather else "none")
     res["config"]["launch"] = f"one process, {N} device thread(s) (multidev.py; weights broadcast over RCCL)"
+    if not args.no_strong:
+        try:
+            res["strong_4k_x4"] = strong_4k_x4(args, torch.device("cuda", 0), N, 0, "nccl", group=group)
+        except Exception as e:
+            res["strong_4k_x4"] = {"error": f"{type(e).__name__}: {e}"}
     group.close()
     if N == 1 and group.comm is None:
         comm.close()
@@ -469,11 +606,22 @@ def result_line(args, world, elapsed, traced, rep, eng, collective):
                           (32 / 4 + 16 + 64 + 16 + 128 / 4) * full),
         "final_blend": ("last warp x2 + sigmoid blend + crop + clamp: T + F + image planes in, RGB frame out", (32 + 16 + 32) * full + 12.0 * H * W),
     }
+    # the frame pack (clamp / pad + encode.0 + encode.1 in one kernel): per FRAME, RGB fp32 in, the two planar4 planes out; B + 1 frames per step
+    enc_frame_bytes = 12.0 * H * W + 32.0 * full
     roofline_hbm = []
     for name, (what, per_task) in hbm_bytes.items():
         if name in rep and rep[name][0]:
             c, m = rep[name]
             roofline_hbm.append(hbm_entry(f"{name}: {what}; {B} tasks per launch", per_task * B, m / c, c))
+    if "encode_batch" in rep and rep["encode_batch"][0]:
+        c, m = rep["encode_batch"]
+        e = hbm_entry(f"encode_batch: frame pack (clamp / pad + encode.0 Conv 3->16 s2 + encode.1 Deconv 16->4) of {B + 1} frames in one persistent "
+                      f"launch: RGB fp32 in, planar4 image + feature planes out", enc_frame_bytes * (B + 1), m / c, c)
+        e["valu_floor_ms"] = round((B + 1) * (hp * wp / 1024.0) * 256 * (2 * 27 * 16 + 1024) / VALU_LANE_OPS_PER_S * 1e3, 4)      # per 32x32 tile: 2 rounds x 432 + 1024 FMA per thread
+        roofline_hbm.insert(0, e)
+    elif "encode_fused" in rep and rep["encode_fused"][0]:
+        c, m = rep["encode_fused"]
+        roofline_hbm.insert(0, hbm_entry("encode_fused: frame pack of ONE frame per launch", enc_frame_bytes, m / c, c))
     total_ms = sum(v[1] for v in rep.values())
     kernels = {k: {"calls": v[0], "ms": round(v[1], 3), "share": round(v[1] / total_ms, 4)} for k, v in rep.items()}
     return {
@@ -504,22 +652,24 @@ def result_line(args, world, elapsed, traced, rep, eng, collective):
             "kernel": ("conv_wino_kernel<8> (Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)" if wino else "conv_mfma2_kernel<s1,3x3> (direct implicit GEMM)")
                       + " as resconv_c64 (block3 ResConv 64->64 @%dx%d, batch %d)" % (hp // 4, wp // 4, B),
             "bound": "mfma",
-            "achieved": round(achieved, 3),
+            # hardware utilisation: MFMA FLOP the kernel ISSUES per launch / launch duration / peak  (<= 1)
+            "achieved": round(achieved / exec_div, 3),
             "peak": PEAK_FP32_MFMA_TFLOPS,
             "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+            "frac": round(achieved / exec_div / PEAK_FP32_MFMA_TFLOPS, 4),
+            "flop_per_launch": flop_per_launch / exec_div,
+            "flop_definition": ("executed: the Winograd F(2x2,3x3) form issues 16 MFMA multiplications per 2x2 output tile and channel pair instead "
+                                "of 36 = direct / 2.25, on whole 16x8-pixel regions") if wino else "direct form: every algorithmic FLOP is an MFMA FLOP",
             "traffic": traffic,
             "traffic_source": traffic_src,
             "launches": calls,
             "avg_launch_ms": round(avg_ms, 4),
-            "flop_per_launch": flop_per_launch,
-            "flop_definition": "algorithmic = the direct form: 2 * pixels * Cin * Cout * 9",
-            "executed": {
-                "note": "MFMA FLOP the kernel issues per launch (Winograd: direct / 2.25, computed on whole 16x8-pixel regions) and the "
-                        "matrix-pipe utilisation that implies" if wino else "direct form: every algorithmic FLOP is an MFMA FLOP",
-                "flop_per_launch": flop_per_launch / exec_div,
-                "achieved": round(achieved / exec_div, 3),
-                "frac": round(achieved / exec_div / PEAK_FP32_MFMA_TFLOPS, 4),
+            "algorithmic_equiv": {
+                "note": "the same launch priced in direct-form FLOP (SURVEY 8d: 2 * pixels * Cin * Cout * 9 — what the layer is worth to any "
+                        "implementation); > peak because Winograd skips 5/9 of the multiplications, NOT a roofline fraction",
+                "flop_per_launch": flop_per_launch,
+                "achieved": round(achieved, 3),
+                "x_peak": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
             },
             "traced_ms_per_step": round(traced / K * 1e3, 3),
         },
@@ -541,6 +691,11 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive node leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the FILM / M2M device-resident numbers")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather of new frames")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling 4K x4 leg (BASELINE configs[3])")
+    ap.add_argument("--strong-height", type=int, default=2160)
+    ap.add_argument("--strong-width", type=int, default=3840)
+    ap.add_argument("--strong-frames", type=int, default=17)
+    ap.add_argument("--strong-reps", type=int, default=2)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) | gloo (plumbing test on one GPU)")
     ap.add_argument("--device-threads", action="store_true",
                     help="route --gpus 1 through the one-process / device-thread path too (what --gpus N > 1 uses without a launcher)")
@@ -606,8 +761,7 @@ def main():
         # Every frame of the step is prepared + encoded inside the timed region: B + 1 frames for B pairs (in a real clip the
         # first one would be the previous step's last and already resident: one frame more work than the node does).
         base = clip_base(B, k)
-        for j in range(B + 1):
-            eng.load_frame(j, raw[base + j])
+        eng.load_frames(list(range(B + 1)), [raw[base + j] for j in range(B + 1)])      # ONE frame-pack launch (vfi_rife_load_frames)
         eng.interpolate(slot0, slot1, ts, outs[k])
         if world > 1 and not args.no_gather:
             if gathered is not None:
@@ -654,6 +808,12 @@ def main():
     rep = _lib.trace_report()
     lib.vfi_trace_reset()
 
+    strong = None
+    if not args.no_strong:       # every rank takes part (strong scaling over the ranks); failures never take the headline line down
+        try:
+            strong = strong_4k_x4(args, dev, world, rank, args.backend)
+        except Exception as e:
+            strong = {"error": f"{type(e).__name__}: {e}"}
     dist_extras = None
     if world > 1 and not args.no_extras:
         eng.release() if hasattr(eng, "release") else None
@@ -666,6 +826,8 @@ def main():
                           "none" if world == 1 or args.no_gather else
                           ("all_gather(RCCL), overlapped" if gathered is not None else "all_gather(gloo, host)"))
         res["config"]["launch"] = "one process per GPU (torch.distributed)" if world > 1 else "one process, one GPU"
+        if strong is not None:
+            res["strong_4k_x4"] = strong
         if dist_extras is not None:
             res["other_paths"] = dist_extras
         if world == 1:

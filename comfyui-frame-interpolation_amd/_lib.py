@@ -145,6 +145,7 @@ PROTOTYPES = {
     "vfi_window_attention": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "vfi_rife_load_frame_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "vfi_rife_load_frames": (C.c_int, [C.c_void_p, C.c_int, c_int_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p]),
     "vfi_f32_to_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "vfi_rife_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_int_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p,
                                C.POINTER(C.c_int64)]),

@@ -467,6 +467,29 @@ int vfi_rife_load_frame_u8(vfi_rife_t* net, int slot, const uint8_t* frame_dev, 
     return load_frame_impl(net, slot, nullptr, frame_dev, C, stream);
 }
 
+// A batch of frames: one launch for all of them where the architecture has the fused frame pack (arch 4.7: persistent workgroups,
+// the next tile's source prefetched under the current tile's arithmetic), frame by frame otherwise.  Bit-identical to n single calls.
+int vfi_rife_load_frames(vfi_rife_t* net, int n, const int* slots, const void* const* frames_dev, int C, int is_u8, void* stream) {
+    VFI_REQUIRE(net && net->Hp > 0, "vfi_rife_load_frames: network not configured");
+    VFI_REQUIRE(n >= 0 && (n == 0 || (slots && frames_dev)) && C >= 3, "vfi_rife_load_frames: bad arguments (n=%d C=%d)", n, C);
+    for (int i = 0; i < n; ++i) {
+        VFI_REQUIRE(slots[i] >= 0 && slots[i] < net->n_slots && frames_dev[i], "vfi_rife_load_frames: bad slot %d / null frame at %d", slots[i], i);
+        for (int j = 0; j < i; ++j) VFI_REQUIRE(slots[j] != slots[i], "vfi_rife_load_frames: slot %d listed twice", slots[i]);
+    }
+    const bool fused = option(kOptFuseEncode) != 0 && option(kOptEncodeBatched) != 0 && net->n_mid == 0 && net->CM == 16 && net->CF == 4 &&
+                       !net->enc_act && net->NF == 1;
+    if (!fused || n < 2) {
+        for (int i = 0; i < n; ++i)
+            if (int rc = load_frame_impl(net, slots[i], is_u8 ? nullptr : (const float*)frames_dev[i], is_u8 ? (const unsigned char*)frames_dev[i] : nullptr, C, stream))
+                return rc;
+        return 0;
+    }
+    std::vector<float*> packs(n);
+    for (int i = 0; i < n; ++i) packs[i] = net->Ppool.p + (size_t)slots[i] * net->pack_stride();
+    return encode47_batch_launch(n, frames_dev, is_u8 != 0, packs.data(), net->enc_w0.p, net->enc_b0.p, net->enc_w1.p, net->enc_b1.p, net->H, net->W, C,
+                                 net->Hp, net->Wp, (hipStream_t)stream);
+}
+
 int vfi_f32_to_u8(const float* in_dev, uint8_t* out_dev, int64_t n, void* stream) {
     VFI_REQUIRE(in_dev && out_dev && n >= 0 && ((uintptr_t)in_dev & 15) == 0 && ((uintptr_t)out_dev & 3) == 0,
                 "vfi_f32_to_u8: bad arguments (in 16-byte, out 4-byte aligned)");

@@ -16,6 +16,8 @@ int prep_frame_launch(const float* src, float* P, int H, int W, int C, int Hp, i
 // arch 4.7: prep + encode.0 + encode.1 in one launch (exactly one of f32 / u8 non-null)
 int encode47_fused_launch(const float* f32, const unsigned char* u8, float* P, const float* w0, const float* b0, const float* w1, const float* b1,
                           int H, int W, int C, int Hp, int Wp, hipStream_t s);
+int encode47_batch_launch(int n, const void* const* srcs, bool u8, float* const* packs, const float* w0, const float* b0, const float* w1,
+                          const float* b1, int H, int W, int C, int Hp, int Wp, hipStream_t s);
 int prep_frame_u8_launch(const unsigned char* src, float* P, int H, int W, int C, int Hp, int Wp, hipStream_t s);
 int f32_to_u8_launch(const float* in, unsigned char* out, long n, hipStream_t s);
 // Head: first conv 3 -> CM (stride 2, optional LeakyReLU) into E [Hp/2][Wp/2][CM]; last layer CM -> CF transposed conv

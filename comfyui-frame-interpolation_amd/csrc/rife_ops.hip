@@ -360,6 +360,194 @@ int encode47_fused_launch(const float* f32, const unsigned char* u8, float* P, c
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------
+// The same frame pack for a BATCH of frames in one launch (vfi_rife_load_frames): persistent workgroups, source tile of the NEXT
+// work item prefetched into registers while this one computes.
+// ---------------------------------------------------------------------------------------
+// Why: encode47_fused_kernel's 42.6 KB of LDS admit 3 workgroups per CU, and each of them alternates load -> compute -> compute:
+// on average ONE workgroup per CU has loads in flight (16 KB), where ~50 KB per CU are needed to cover the HBM latency at full
+// rate (measured r3: 51 us per 1080p frame = 1.8 TB/s for 92 MB; VALU floor 13 us, HBM floor 15 us).  Here every workgroup issues
+// the global loads of its next tile right after it has stored the current one into LDS, so they fly under phases 1 and 2
+// (~3 us of VALU work), and one launch covers all frames of a step (no per-frame launch tail: 2040 workgroups = 2.7 rounds of
+// 768 slots per frame before).  Arithmetic is encode47_fused_kernel's, expression for expression: bit-identical packs
+// (tests/test_gpu_rife.py::test_batched_frame_pack_is_bit_identical).
+constexpr int ENC_MAXF = 64;                   // frames per launch (kernel-argument arrays)
+struct EncodeBatch {
+    const void* src[ENC_MAXF];
+    float* P[ENC_MAXF];
+};
+constexpr int ENC_NPRE = (ENC_TI * ENC_TI + 255) / 256;      // source pixels per thread and tile (6)
+
+template <typename SRC>
+__global__ __launch_bounds__(256) void encode47_batch_kernel(const EncodeBatch fb, const float* __restrict__ w0, const float* __restrict__ b0,
+                                                             const float* __restrict__ w1, const float* __restrict__ b1, int H, int W, int C, int Hp,
+                                                             int Wp, int tiles_x, int tiles_per_frame, int n_items) {
+    constexpr int CM = 16, CF = 4;
+    __shared__ __attribute__((aligned(16))) float4 sI[ENC_TI * ENC_TI];
+    __shared__ __attribute__((aligned(16))) float sE[ENC_TE * ENC_TE * CM];
+    const int tid = threadIdx.x;
+    const int He = Hp / 2, We = Wp / 2;
+    // raw source values of the next item (clamp / divide happen when they are stored to LDS: same values as the single-frame kernel)
+    SRC pre[ENC_NPRE][3];
+    auto decode = [&](int item, int& f, int& Y0, int& X0) {
+        f = item / tiles_per_frame;
+        const int t = item - f * tiles_per_frame;
+        const int ty = t / tiles_x;
+        Y0 = ty * ENC_T, X0 = (t - ty * tiles_x) * ENC_T;
+    };
+    auto prefetch = [&](int item) {
+        int f, Y0, X0;
+        decode(item, f, Y0, X0);
+        const SRC* src = (const SRC*)fb.src[f];
+        const int iy0 = Y0 - 3, ix0 = X0 - 3;
+#pragma unroll
+        for (int r = 0; r < ENC_NPRE; ++r) {
+            const int i = tid + r * 256;
+            const int py = i / ENC_TI, px = i - py * ENC_TI;
+            const int Y = iy0 + py, X = ix0 + px;
+            pre[r][0] = pre[r][1] = pre[r][2] = (SRC)0;
+            if (i < ENC_TI * ENC_TI && Y >= 0 && Y < H && X >= 0 && X < W) {
+                const SRC* sp = src + ((size_t)Y * W + X) * C;
+                pre[r][0] = sp[0], pre[r][1] = sp[1], pre[r][2] = sp[2];
+            }
+        }
+    };
+    int item = blockIdx.x;
+    if (item >= n_items) return;
+    prefetch(item);
+    for (; item < n_items; item += gridDim.x) {
+        int f, Y0, X0;
+        decode(item, f, Y0, X0);
+        float* const P = fb.P[f];
+        const int iy0 = Y0 - 3, ix0 = X0 - 3;
+        // ---- phase 0: registers -> LDS (clamped / scaled), plane 0 of the tile -> HBM
+#pragma unroll
+        for (int r = 0; r < ENC_NPRE; ++r) {
+            const int i = tid + r * 256;
+            if (i < ENC_TI * ENC_TI) {
+                const int py = i / ENC_TI, px = i - py * ENC_TI;
+                const int Y = iy0 + py, X = ix0 + px;
+                float4 v = {0.f, 0.f, 0.f, 0.f};
+                if (Y >= 0 && Y < H && X >= 0 && X < W) {
+                    if (sizeof(SRC) == 1) {
+                        v.x = __fdiv_rn((float)pre[r][0], 255.0f);
+                        v.y = __fdiv_rn((float)pre[r][1], 255.0f);
+                        v.z = __fdiv_rn((float)pre[r][2], 255.0f);
+                    } else {
+                        v.x = fminf(fmaxf((float)pre[r][0], 0.f), 1.f);
+                        v.y = fminf(fmaxf((float)pre[r][1], 0.f), 1.f);
+                        v.z = fminf(fmaxf((float)pre[r][2], 0.f), 1.f);
+                    }
+                }
+                sI[i] = v;
+                if (py >= 3 && py < 3 + ENC_T && px >= 3 && px < 3 + ENC_T && Y < Hp && X < Wp) *(float4*)(P + ((size_t)Y * Wp + X) * 4) = v;
+            }
+        }
+        // the next item's source tile: in flight under phases 1 and 2
+        if (item + (int)gridDim.x < n_items) prefetch(item + gridDim.x);
+        __syncthreads();
+        // ---- phase 1: E tile
+        const int ey0 = Y0 / 2 - 1, ex0 = X0 / 2 - 1;
+        for (int i = tid; i < ENC_TE * ENC_TE; i += 256) {
+            const int py = i / ENC_TE, px = i - py * ENC_TE;
+            const int ey = ey0 + py, ex = ex0 + px;
+            float acc[CM];
+#pragma unroll
+            for (int co = 0; co < CM; ++co) acc[co] = 0.f;
+            const bool in_img = ey >= 0 && ey < He && ex >= 0 && ex < We;
+            if (in_img) {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float4 v = sI[(2 * py + ky) * ENC_TI + 2 * px + kx];
+                        const float* wt = w0 + (ky * 3 + kx) * 3 * CM;
+#pragma unroll
+                        for (int co = 0; co < CM; ++co) acc[co] = fmaf(v.z, wt[2 * CM + co], fmaf(v.y, wt[CM + co], fmaf(v.x, wt[co], acc[co])));
+                    }
+#pragma unroll
+                for (int co = 0; co < CM; ++co) acc[co] += b0[co];
+            }
+#pragma unroll
+            for (int q = 0; q < CM / 4; ++q) *(float4*)&sE[i * CM + 4 * q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        }
+        __syncthreads();
+        // ---- phase 2: one E pixel of the 16x16 centre per thread -> its 2x2 output quad
+        {
+            const int lx = tid & 15, ly = tid >> 4;
+            const int y = Y0 / 2 + ly, x = X0 / 2 + lx;
+            if (y < He && x < We) {
+                float acc[4][CF];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int co = 0; co < CF; ++co) acc[g][co] = b1[co];
+#pragma unroll
+                for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const float* e = &sE[((ly + 1 + dy) * ENC_TE + lx + 1 + dx) * CM];
+#pragma unroll
+                        for (int q = 0; q < CM / 4; ++q) {
+                            const float4 t = *(const float4*)(e + 4 * q);
+                            const float ev[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                            for (int py = 0; py < 2; ++py) {
+                                if (dy < py - 1 || dy > py) continue;
+                                const int ky = py + 1 - 2 * dy;
+#pragma unroll
+                                for (int px = 0; px < 2; ++px) {
+                                    if (dx < px - 1 || dx > px) continue;
+                                    const int kx = px + 1 - 2 * dx;
+                                    const float* wt = w1 + ((ky * 4 + kx) * CM + 4 * q) * CF;
+#pragma unroll
+                                    for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+                                        for (int co = 0; co < CF; ++co) acc[py * 2 + px][co] = fmaf(ev[ci], wt[ci * CF + co], acc[py * 2 + px][co]);
+                                }
+                            }
+                        }
+                    }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int Y = 2 * y + (g >> 1), X = 2 * x + (g & 1);
+                    *(float4*)(P + (size_t)Hp * Wp * 4 + ((size_t)Y * Wp + X) * 4) = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
+                }
+            }
+        }
+        __syncthreads();      // sE (and sI) are rewritten by the next item
+    }
+}
+
+// n frames (<= ENC_MAXF per launch; longer lists go out in several launches): srcs[i] -> packs[i]
+int encode47_batch_launch(int n, const void* const* srcs, bool u8, float* const* packs, const float* w0, const float* b0, const float* w1,
+                          const float* b1, int H, int W, int C, int Hp, int Wp, hipStream_t s) {
+    const int tiles_x = cdiv(Wp, ENC_T), tiles_y = cdiv(Hp, ENC_T);
+    int dev = 0;
+    VFI_CHECK_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t pr;
+    static int cus_cache[kMaxDevices] = {};
+    if (dev >= 0 && dev < kMaxDevices && !cus_cache[dev]) {
+        VFI_CHECK_HIP(hipGetDeviceProperties(&pr, dev));
+        cus_cache[dev] = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+    }
+    const int cus = (dev >= 0 && dev < kMaxDevices) ? cus_cache[dev] : 256;
+    for (int base = 0; base < n; base += ENC_MAXF) {
+        const int m = n - base < ENC_MAXF ? n - base : ENC_MAXF;
+        EncodeBatch fb = {};
+        for (int i = 0; i < m; ++i) fb.src[i] = srcs[base + i], fb.P[i] = packs[base + i];
+        const int per = tiles_x * tiles_y, items = per * m;
+        const int grid = items < 3 * cus ? items : 3 * cus;      // 42.6 KB of LDS: three workgroups per CU
+        TraceScope ts("encode_batch", s);
+        if (u8)
+            hipLaunchKernelGGL(encode47_batch_kernel<unsigned char>, dim3(grid), dim3(256), 0, s, fb, w0, b0, w1, b1, H, W, C, Hp, Wp, tiles_x, per, items);
+        else
+            hipLaunchKernelGGL(encode47_batch_kernel<float>, dim3(grid), dim3(256), 0, s, fb, w0, b0, w1, b1, H, W, C, Hp, Wp, tiles_x, per, items);
+        VFI_CHECK_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
 int prep_frame_launch(const float* src, float* P, int H, int W, int C, int Hp, int Wp, hipStream_t s) {
     TraceScope ts("prep_frame", s);
     hipLaunchKernelGGL(prep_frame_kernel<float>, dim3(cdiv(Hp * Wp, 256)), dim3(256), 0, s, src, P, H, W, C, Hp, Wp);

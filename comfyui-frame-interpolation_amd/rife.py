@@ -125,6 +125,19 @@ class RifeEngine:
             _lib.check(self.lib.vfi_rife_load_frame(self.handle, slot, frame_dev.data_ptr(), frame_dev.shape[2],
                                                     _lib.stream_ptr()), "vfi_rife_load_frame")
 
+    def load_frames(self, slots, frames_dev):
+        """A batch of frames in one launch (arch 4.7; frame by frame on the others): frames_dev[i] -> slot slots[i]."""
+        n = len(slots)
+        if n == 0:
+            return
+        f0 = frames_dev[0]
+        for f in frames_dev:
+            assert f.is_cuda and f.dtype == f0.dtype and f.dtype in (torch.float32, torch.uint8) and f.is_contiguous()
+            assert tuple(f.shape) == tuple(f0.shape) and tuple(f.shape[:2]) == self.cfg[:2], (f.shape, self.cfg)
+        ptrs = (C.c_void_p * n)(*[f.data_ptr() for f in frames_dev])
+        _lib.check(self.lib.vfi_rife_load_frames(self.handle, n, (C.c_int * n)(*slots), ptrs, f0.shape[2], int(f0.dtype == torch.uint8),
+                                                 _lib.stream_ptr()), "vfi_rife_load_frames")
+
     def interpolate(self, slot0, slot1, timesteps, out_dev):
         """out_dev[b] = clamp(IFNet(frame[slot0[b]], frame[slot1[b]], t[b]), 0, 1);  out_dev [B,H,W,3]."""
         B = len(timesteps)
@@ -249,13 +262,21 @@ def run_tasks(engine, frames_cpu, tasks, batch_size, scale_factor=1.0, out_devic
         for pos, bt, need in _batches(tasks, bs):
             if tl is not None:
                 t_a = time.perf_counter() - t_base
-            for f, slot in slots.assign(need):
-                assert order[item] == f
-                src = up.get(item)
+            loads = slots.assign(need)
+            # every frame this launch needs and the device does not hold yet: ONE frame-pack launch (vfi_rife_load_frames) — in chunks
+            # of the staging ring's depth (a clip with skipped pairs can need up to 2 frames per task; a staging slot is only
+            # recycled after its frame has been packed)
+            for c0 in range(0, len(loads), up.depth):
+                chunk = loads[c0:c0 + up.depth]
+                srcs = []
+                for j, (f, slot) in enumerate(chunk):
+                    assert order[item + j] == f
+                    srcs.append(up.get(item + j))
                 with _T("main.load_frame"):
-                    engine.load_frame(slot, src)
-                up.release(item)
-                item += 1
+                    engine.load_frames([slot for _, slot in chunk], srcs)
+                for j in range(len(chunk)):
+                    up.release(item + j)
+                item += len(chunk)
             m = slots.slot_of
             if out_device:
                 buf = res[pos:pos + len(bt)]

@@ -411,6 +411,10 @@ int vfi_rife_load_frame(vfi_rife_t* net, int slot, const float* frame_dev, int C
  * quarter of the PCIe bytes): the same as vfi_rife_load_frame on frame_dev[H,W,C] uint8 with x = u8 / 255 computed on the
  * device (== torch's ``frames.float() / 255`` bit for bit), and the way back: out = round(clamp(in, 0, 1) * 255), ties to even. */
 int vfi_rife_load_frame_u8(vfi_rife_t* net, int slot, const uint8_t* frame_dev, int C, void* stream);
+/* The same for n frames at once: frames_dev[i] ([H,W,C] fp32, or uint8 when is_u8) -> slot slots[i] (distinct).  ONE launch for the
+ * whole list on arch 4.7 (what a batch of the node's loop, rife/__init__.py:195-207, needs resident: 2 frames per task); results are
+ * bit-identical to n single calls. */
+int vfi_rife_load_frames(vfi_rife_t* net, int n, const int* slots, const void* const* frames_dev, int C, int is_u8, void* stream);
 int vfi_f32_to_u8(const float* in_dev, uint8_t* out_dev, int64_t n, void* stream);
 
 /* The per-task hot loop: out[b] = clamp(IFNet(frame[slot0[b]], frame[slot1[b]], t[b]), 0, 1)

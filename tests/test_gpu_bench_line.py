@@ -1,0 +1,55 @@
+"""-m gpu: bench.py's JSON line carries what the measurement contract asks for — a small configuration so
+that the test takes seconds: `roofline.frac` is a hardware utilisation (<= 1) with the direct-form figure under
+`algorithmic_equiv`, the frame pack is in `roofline_hbm`, the strong-scaling 4K x4 leg is present (here at a reduced size), and the
+two-rank launch (gloo on the one GPU) shards that leg's task list unevenly."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--height", "272", "--width", "480", "--batch", "4", "--steps", "1", "--warmup", "1", "--no-e2e", "--no-cpu-baseline",
+         "--strong-height", "136", "--strong-width", "240", "--strong-frames", "4", "--strong-reps", "1"]
+
+
+def _line(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-3000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line(hip_lib):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    res = _line(r.stdout)
+    rf = res["roofline"]
+    assert rf["bound"] == "mfma" and 0 < rf["frac"] <= 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    eq = rf["algorithmic_equiv"]
+    assert abs(eq["flop_per_launch"] / rf["flop_per_launch"] - 2.25) < 1e-9 and abs(eq["x_peak"] / rf["frac"] - 2.25) < 1e-2
+    names = [e["kernel"].split(":")[0] for e in res["roofline_hbm"]]
+    assert names[0] == "encode_batch" and {"stage_trans4", "stage_trans2", "trans1_conv0a", "final_blend"} <= set(names)
+    for e in res["roofline_hbm"]:
+        assert e["bound"] == "hbm" and 0 < e["frac"] <= 1.0
+    st = res["strong_4k_x4"]
+    assert st["scaling"] == "strong" and st["n_gpus"] == 1 and st["tasks_per_rank"] == [9] and st["value"] > 0      # 3 pairs x 3 timesteps
+    op = res["other_paths"]["roofline_hbm"]
+    kinds = {e["bound"] for e in op if "bound" in e}
+    assert kinds == {"hbm", "valu"}, op
+    assert any("micro-benchmark" in e["kernel"] and "error" not in e for e in op)
+    cv = [e for e in op if e.get("bound") == "valu"][0]
+    assert 0 < cv["frac"] <= 1.0 and cv["valu_floor_ms"] > 0
+
+
+def test_two_rank_line_shards_the_strong_leg(hip_lib):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29731",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--no-extras"] + SMALL
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    res = _line(r.stdout)
+    assert res["n_gpus"] == 2 and res["scaling"] == "weak"
+    st = res["strong_4k_x4"]
+    assert st["tasks_per_rank"] == [5, 4] and st["n_gpus"] == 2 and st["value"] > 0, st

@@ -771,6 +771,41 @@ def _frame_pack(h, w, u8):
         eng.close()
 
 
+@pytest.mark.parametrize("h,w,u8,n", [(70, 90, False, 3), (1080, 1920, False, 5), (200, 330, True, 7), (96, 64, False, 70)])
+def test_batched_frame_pack_is_bit_identical(hip_lib, h, w, u8, n):
+    """vfi_rife_load_frames: n frames packed by ONE persistent launch (encode47_batch_kernel: the next tile's source prefetched into
+    registers under the current tile's arithmetic; 70 frames = two launches of the 64-entry argument array) == n single-frame packs,
+    bit for bit, RGBA and uint8 clips included; and A/B option encode_batched = 0 routes the same call through the single launches."""
+    from cfi_amd.rife import RifeEngine
+
+    eng = RifeEngine(synth.rife47_synth_state_dict(1234), "4.7")
+    try:
+        eng.configure(h, w, 1, n, 1.0)
+        fr = synth.smooth_frames(n, h, w, seed=9, shift=1.0, c=4) * 1.3 - 0.15
+        if u8:
+            fr = (fr.clamp(0, 1) * 255).round().to(torch.uint8)
+        dev = [f.cuda().contiguous() for f in fr]
+        hp, wp = -(-h // 64) * 64, -(-w // 64) * 64
+        slots = list(range(n))[::-1]          # not the identity
+        for s, f in zip(slots, dev):
+            eng.load_frame(s, f)
+        want = [eng.debug_read(2, s, hp * wp * 8).clone() for s in slots]
+        for mode in (1, 0):
+            for s in slots:                   # poison the slots: the batched call must rewrite every one of them
+                eng.load_frame(s, torch.zeros_like(dev[0]))
+            assert hip_lib.vfi_test_set_option(b"encode_batched", mode) == 0
+            eng.load_frames(slots, dev)
+            for s, w_ in zip(slots, want):
+                got = eng.debug_read(2, s, hp * wp * 8)
+                assert torch.equal(got, w_), f"encode_batched={mode} slot {s}: {(got - w_).abs().max().item()}"
+        assert float(want[0].abs().max()) > 0.1
+        with pytest.raises(RuntimeError, match="listed twice"):
+            eng.load_frames([0, 0], dev[:2])
+    finally:
+        hip_lib.vfi_test_set_option(b"encode_batched", 1)
+        eng.close()
+
+
 @pytest.mark.parametrize("h,w,u8", [(70, 90, False), (1080, 1920, False), (200, 330, True)])
 def test_fused_frame_pack_is_bit_identical(hip_lib, h, w, u8):
     """arch 4.7: prep + encode.0 + encode.1 in one launch (encode47_fused_kernel, E never in HBM) gives BIT-IDENTICAL frame packs
