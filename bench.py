@@ -577,6 +577,8 @@ def result_line(args, world, elapsed, traced, rep, eng, collective):
     flop_per_launch = 2.0 * B * (hp // 4) * (wp // 4) * 64 * 64 * 9
     avg_ms = ms / calls if calls else float("nan")
     achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12 if calls else float("nan")
+    from cfi_amd import _lib
+
     wino = _lib.load().vfi_test_conv_algo(-1) != 1
     exec_div = 2.25 if wino else 1.0
     # HBM traffic of the dominant kernel comes from PMC counters, which need their own rocprofv3 passes (--pmc cannot share a run

@@ -150,7 +150,7 @@ for rep in range(2):
     x = torch.rand(1, 8, 8, 4, device="cuda:0")
     y = torch.empty(1, 16, 16, 4, device="cuda:0")
     assert torch.cuda.current_device() == 0, "the collective moved the thread's current device"
-    _lib.check(lib.vfi_upsample_nearest(x.data_ptr(), 4, y.data_ptr(), 4, 1, 8, 8, 4, 2, 0, None), "kernel after all_gather_v")
+    _lib.check(lib.vfi_upsample_nearest(x.data_ptr(), 4, y.data_ptr(), 4, 1, 8, 8, 16, 16, 4, None), "kernel after all_gather_v")
     comm.synchronize()
 want = torch.cat([torch.full((c,), float(r + 1)) for r, c in enumerate(counts)])
 for b in bufs:

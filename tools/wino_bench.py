@@ -47,14 +47,13 @@ LAYERS = [("rife res_c64 x32", 32, 272, 480, 64, 64), ("rife res_c96 x32", 32, 1
           ("film 2440->512 @135p", 1, 135, 240, 2440, 512), ("m2m 128->128 @272x480", 2, 272, 480, 128, 128)]
 if len(sys.argv) > 1:
     LAYERS = [l for l in LAYERS if any(k in l[0] for k in sys.argv[1:])]
-print(f"{'layer':28s} {'direct ms':>10s} {'TF/s':>7s} | {'wino16x8 ms':>11s} {'eff TF/s':>8s} {'exec frac':>9s} | {'wino32x4 ms':>11s} {'eff TF/s':>8s} | max|d| w vs direct")
+print(f"{'layer':28s} {'direct ms':>10s} {'TF/s':>7s} | {'wino16x8 ms':>11s} {'eff TF/s':>8s} {'exec frac':>9s} | {'wino32x4 ms':>11s} | max|d| vs direct")
 for name, n, h, w, cin, cout in LAYERS:
     flop = 2.0 * n * h * w * cin * cout * 9
     t0, o0 = run(n, h, w, cin, cout, -1)
     t1, o1 = run(n, h, w, cin, cout, 100)
     t2, o2 = run(n, h, w, cin, cout, 101)
-    t3, o3 = run(n, h, w, cin, cout, 102) if cout <= 256 else (None, None)      # the experimental two-waves-per-SIMD form
-    d = max((o1 - o0).abs().max().item() if o1 is not None else -1, (o2 - o0).abs().max().item() if o2 is not None else -1)
+    d = lambda o: (o - o0).abs().max().item() if o is not None else -1
     f = lambda t: f"{flop / t / 1e9:7.1f}" if t else "   n/a"
-    d3 = (o3 - o0).abs().max().item() if o3 is not None else -1
-    print(f"{name:28s} {t0:10.4f} {f(t0)} | {t1 or 0:11.4f} {f(t1):>8s} {flop / 2.25 / t1 / 1e9 / PEAK if t1 else 0:9.3f} | {t2 or 0:11.4f} {f(t2):>8s} | {d:.2e} | 2-wave {t3 or 0:8.4f} {f(t3):>8s} max|d| {d3:.2e}", flush=True)
+    ex = lambda t: flop / 2.25 / t / 1e9 / PEAK if t else 0
+    print(f"{name:28s} {t0:10.4f} {f(t0)} | {t1 or 0:11.4f} {f(t1):>8s} {ex(t1):9.3f} | {t2 or 0:11.4f} | {d(o1):.2e} {d(o2):.2e}", flush=True)
