@@ -54,6 +54,6 @@ NODE_DISPLAY_NAME_MAPPINGS = {
     "FILM VFI": "FILM VFI (MI355X HIP)",
     "M2M VFI": "M2M VFI (MI355X HIP)",
     "IFRNet VFI": "IFRNet VFI (MI355X HIP)",
-    "GMFSS Fortuna VFI": "GMFSS Fortuna VFI (MI355X HIP; first-correct path)",
+    "GMFSS Fortuna VFI": "GMFSS Fortuna VFI (MI355X HIP)",
     "IFUnet VFI": "IFUnet VFI (MI355X HIP)",
 }

@@ -173,7 +173,7 @@ SUPPORTED_ENV = {
     "VFI_HOST_PROFILE":   "'1': per-phase wall-clock accounting of the host pipeline (hostpipe.py)",
     "VFI_TRACE_SHAPES":   "per-shape rows in vfi_trace_report (profiling)",
 }
-_TEST_HARNESS_ENV = {"VFI_TEST_OPTIONS", "VFI_HOSTCHECK", "VFI_CHILD"}      # read by tests/, never by the package or the library
+_TEST_HARNESS_ENV = {"VFI_TEST_OPTIONS", "VFI_HOSTCHECK", "VFI_CHILD", "VFI_REAL_CKPTS"}      # read by tests/, never by the package or the library
 
 
 def audit_environment():

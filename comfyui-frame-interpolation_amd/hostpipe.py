@@ -126,8 +126,14 @@ class Uploader:
     """Stages ``frames[order[i]]`` (host, [H,W,C>=3]) to the device ahead of use.  ``get(i)`` returns a device tensor
     [H,W,3] valid on ``main`` until ``release(i)``; items must be consumed in order."""
 
-    def __init__(self, frames, order, device, main, depth=6, workers=WORKERS[0]):
+    def __init__(self, frames, order, device, main, depth=6, workers=WORKERS[0], on_staged=None, staged_after=0):
         self.frames, self.order, self.device, self.main = frames, list(order), device, main
+        # on_staged(): called once, from a worker, when the first `staged_after` items have been copied into pinned memory
+        self._on_staged, self._staged_left, self._staged_lock = on_staged, int(staged_after), threading.Lock()
+        self._staged_n = int(staged_after)
+        if on_staged is not None and self._staged_left <= 0:
+            on_staged()
+            self._on_staged = None
         H, W = frames.shape[1:3]
         self.depth = depth
         self.rings = _rings_grow(_rings_acquire(device, (H, W, 3), frames.dtype, "up"), device, (H, W, 3), depth, 0)   # fp32 or uint8 clips
@@ -146,11 +152,24 @@ class Uploader:
                 _wait(self.consumed[i - self.depth])
         with _T("up.memcpy_to_pinned"):
             host_copy(self.host[s], self.frames[self.order[i]][..., :3])   # pageable -> pinned (drops alpha, makes contiguous)
+        if self._on_staged is not None and i < self._staged_n:
+            fire = False
+            with self._staged_lock:
+                self._staged_left -= 1
+                if self._staged_left == 0 and self._on_staged is not None:
+                    fire = True
+            if fire:
+                cb, self._on_staged = self._on_staged, None
+                cb()
         ev = torch.cuda.Event()
         with _T("up.enqueue_h2d"), torch.cuda.stream(self.stream):
             self.dev[s].copy_(self.host[s], non_blocking=True)
             ev.record(self.stream)
         return ev
+
+    def ready(self, i):
+        """Has item i been staged and its H2D copy been enqueued?  (Non-blocking: frames packed ahead of their launch.)"""
+        return self.futs[i].done()
 
     def get(self, i):
         with _T("main.wait_upload"):
@@ -191,33 +210,41 @@ class Downloader:
         self.host = self.rings["down_host"][:depth]
         self.stream = torch.cuda.Stream(device)
         self.pool = _pool(f"down{device}", workers)
+        self.workers = workers
         self.slot_fut = [None] * depth
         self.n = 0
         self.futs = []
 
-    def _finish(self, ev, s, dst):
+    def _finish(self, ev, s, dst, part=0, nparts=1):
         with _T("down.wait_d2h"):
             _wait(ev)
         with _T("down.memcpy_to_out"):
-            host_copy(dst, self.host[s])
+            if nparts == 1:
+                host_copy(dst, self.host[s])
+            else:       # rows [r0, r1) of the frame: the last launch's few frames are moved by all workers, not one worker per frame
+                rows = dst.shape[0]
+                r0, r1 = rows * part // nparts, rows * (part + 1) // nparts
+                host_copy(dst[r0:r1], self.host[s][r0:r1])
 
     def push(self, ready_event, dev_frames, dst_rows):
         """After ``ready_event`` (recorded on the compute stream), copy dev_frames[i] -> dst_rows[i].
         Returns a cuda event that fires when the device buffer has been read completely."""
         evs = []
+        nparts = max(1, min(4, self.workers // max(1, len(dst_rows)))) if len(dst_rows) else 1
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(ready_event)
             for i, dst in enumerate(dst_rows):
                 s = self.n % self.depth
                 if self.slot_fut[s] is not None:
                     with _T("main.wait_down_slot"):
-                        self.slot_fut[s].result()      # slot still being drained by a worker
+                        for f in self.slot_fut[s]:
+                            f.result()                 # slot still being drained by a worker
                 self.host[s].copy_(dev_frames[i], non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(self.stream)
-                f = self.pool.submit(self._finish, ev, s, dst)
-                self.slot_fut[s] = f
-                self.futs.append(f)
+                fs = [self.pool.submit(self._finish, ev, s, dst, part, nparts) for part in range(nparts)]
+                self.slot_fut[s] = fs
+                self.futs.extend(fs)
                 self.n += 1
                 evs.append(ev)
         return evs[-1] if evs else ready_event
@@ -279,11 +306,12 @@ def _populate(addr, nbytes):
             _populate_ok = False
 
 
-def prefault_async(t, chunk=16 << 20, workers=None):
+def prefault_async(t, chunk=2 << 20, workers=None):
     """Populate the pages of host tensor ``t`` (contents undefined afterwards, like torch.empty) in the background,
     in address order.  MADV_HUGEPAGE changes VMA flags (mmap write lock), so it is issued once, up front; the
-    populate calls only take the read side and are kept short (16 MiB) so that other threads' faults and the HIP
-    runtime's own mappings are not held up behind them."""
+    populate calls only take the read side and are kept SHORT (2 MiB, ~0.25 ms): anything in the process that needs the
+    write side — the HIP runtime mapping memory for the launching thread — queues behind the populate calls in flight, and
+    with 16 MiB calls the launch loop stood still for ~14 ms right after the prefault started (profiles/r04_e2e_timeline.txt)."""
     workers = workers if workers is not None else (WORKERS[3] if len(WORKERS) > 3 else 6)
     if workers <= 0 or not t.is_contiguous() or t.device.type != "cpu":
         return []

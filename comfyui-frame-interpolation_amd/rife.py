@@ -15,6 +15,7 @@ Differences that do not change results:
 """
 import ctypes as C
 import os
+import threading
 import typing
 import warnings
 
@@ -36,6 +37,7 @@ MAX_LIB_BATCH = 32  # kMaxTasks in csrc/rife_ops.h
 # rife/__init__.py:68-71) only trades memory for speed.  288 GB of HBM make
 # that trade moot: the node runs at least this many tasks per launch (8 below 4K, 4 from 4K up; 0 = honour the widget).
 MIN_NODE_BATCH = int(os.environ.get("VFI_RIFE_MIN_BATCH", "8"))
+PACK_AHEAD = 16            # frames packed on the device ahead of the launch that needs them (67 MB each at 1080p)
 HOST_TIMELINE = False      # diagnostics (tools/node_e2e.py sets it): print the per-launch host timeline of run_tasks
 
 
@@ -188,6 +190,19 @@ class _FrameSlots:
             loads.append((f, self.slot_of[f]))
         return loads
 
+    def retire(self, dead):
+        """Frames no later launch uses: their slots become free for frames packed ahead of their launch."""
+        for f in dead:
+            if f in self.slot_of:
+                self.free.append(self.slot_of.pop(f))
+
+    def take(self, f):
+        """A free slot for frame ``f`` (packed ahead of the launch that needs it), or None."""
+        if f in self.slot_of or not self.free:
+            return None
+        self.slot_of[f] = self.free.pop()
+        return self.slot_of[f]
+
 
 def launch_sizes(n, bs):
     """Tasks per launch for ``n`` tasks at ``bs`` per launch.  Clips of at least two launches start and end on a half-size one:
@@ -214,24 +229,48 @@ def _batches(tasks, bs):
         pos += size
 
 
+def _pick_loads(order, item, need_set, slots, ready, depth):
+    """The next group of frames to pack, [(frame, slot)], taken from ``order[item:]`` in order: frames of ``need_set`` (this
+    launch: always, the caller blocks on their upload), then frames of later launches while ``ready(i)`` says their upload has
+    finished and fewer than PACK_AHEAD frames that this launch does not need are resident.  At most ``depth`` per group."""
+    chunk = []
+    while item + len(chunk) < len(order) and len(chunk) < depth:
+        f = order[item + len(chunk)]
+        must = f in need_set
+        if not must and (not ready(item + len(chunk)) or sum(1 for g in slots.slot_of if g not in need_set) >= PACK_AHEAD):
+            break
+        slot = slots.take(f)      # (2 * bs + 2 slots are never taken by frames packed ahead: a needed frame always finds one)
+        if slot is None:
+            if must:
+                raise RuntimeError("frame cache too small for this batch")
+            break
+        chunk.append((f, slot))
+    return chunk
+
+
 # (ckpt_name) -> RifeEngine; the reference caches by (ckpt, dtype, torch_compile), rife/__init__.py:31
 _model_cache: typing.Dict[typing.Tuple, RifeEngine] = {}
 
 
-def run_tasks(engine, frames_cpu, tasks, batch_size, scale_factor=1.0, out_device=False, out=None, out_rows=None):
+def run_tasks(engine, frames_cpu, tasks, batch_size, scale_factor=1.0, out_device=False, out=None, out_rows=None, on_staged=None):
     """Interpolate ``tasks`` = [(pair, t), ...] over host frames [N,H,W,C].
 
     Returns [len(tasks),H,W,3] (CPU tensor, or device tensor when ``out_device``).  With ``out``/``out_rows`` the
     new frame of task i is written straight into ``out[out_rows[i]]`` (the node's final output tensor) instead.
 
     Host pipeline (hostpipe.py): each input frame is uploaded once, through pinned staging and several frames ahead of
-    the compute stream, and its pad/encode result is cached on the device; device outputs are double-buffered and
-    batch k is moved to its final host rows by worker threads while batch k+1 computes."""
+    the compute stream, and its pad/encode result is cached on the device — packed as soon as its upload has finished, up to
+    PACK_AHEAD frames ahead of the launch that needs it; device outputs are double-buffered and batch k is moved to its final
+    host rows by worker threads while batch k+1 computes.  ``on_staged()`` is called (from a worker thread) once the first
+    launch's frames sit in pinned memory: the caller's other host-memory work (first touch of the output tensor, pass-through
+    copies) starts then instead of competing with the copies the GPU is waiting for."""
     from .hostpipe import Downloader, Uploader, _T
 
     n, H, W, _ = frames_cpu.shape
     bs = max(1, min(int(batch_size), MAX_LIB_BATCH))
-    n_slots = 2 * bs + 2
+    # frame slots: what one launch can need (2 per task) + PACK_AHEAD frames whose upload has finished before their launch comes up
+    # (a frame's pack depends on the frame alone: uploads and packs run ahead of the launches, which then never wait for PCIe)
+    n_slots = 2 * bs + 2 + PACK_AHEAD
     engine.configure(H, W, bs, n_slots, scale_factor)
     dev = engine.device
     u8 = out is not None and out.dtype == torch.uint8      # 8-bit output rows: converted on the device, a quarter of the D2H bytes
@@ -243,10 +282,18 @@ def run_tasks(engine, frames_cpu, tasks, batch_size, scale_factor=1.0, out_devic
     else:
         res = out
     main = torch.cuda.current_stream(dev)
-    sim = _FrameSlots(n_slots)   # dry run of the cache: the exact upload sequence, known before the first launch
-    order = [f for _, _, need in _batches(tasks, bs) for f, _ in sim.assign(need)]
+    batches = list(_batches(tasks, bs))
+    order, last_use = [], {}     # frames in order of first use = the upload sequence; the last launch that reads each
+    for bi, (_, _, need) in enumerate(batches):
+        for f in need:
+            if f not in last_use:
+                order.append(f)
+            last_use[f] = bi
+    if len(order) != len(set(order)):
+        raise AssertionError("frame listed twice in the upload order")
     slots = _FrameSlots(n_slots)
-    up = Uploader(frames_cpu, order, dev, main, depth=min(len(order), bs + 4) or 1)
+    up = Uploader(frames_cpu, order, dev, main, depth=min(len(order), 2 * bs + 2 + PACK_AHEAD) or 1, on_staged=on_staged,
+                  staged_after=min(len(order), len(dict.fromkeys(batches[0][2]))) if batches else 0)
     down = None if out_device else Downloader(dev, (H, W, 3), main, depth=2 * bs, dtype=torch.uint8 if u8 else torch.float32)
     bufs = [torch.empty((bs, H, W, 3), dtype=torch.float32, device=dev) for _ in range(2)] if not out_device else None
     bufs8 = [torch.empty((bs, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(2)] if u8 else None
@@ -258,32 +305,42 @@ def run_tasks(engine, frames_cpu, tasks, batch_size, scale_factor=1.0, out_devic
         ev_base = torch.cuda.Event(enable_timing=True)
         ev_base.record(main)
     try:
-        item, k = 0, 0
-        for pos, bt, need in _batches(tasks, bs):
+        item, k = 0, 0       # item: next entry of `order` to pack
+        for bi, (pos, bt, need) in enumerate(batches):
             if tl is not None:
                 t_a = time.perf_counter() - t_base
-            loads = slots.assign(need)
-            # every frame this launch needs and the device does not hold yet: ONE frame-pack launch (vfi_rife_load_frames) — in chunks
-            # of the staging ring's depth (a clip with skipped pairs can need up to 2 frames per task; a staging slot is only
-            # recycled after its frame has been packed)
-            for c0 in range(0, len(loads), up.depth):
-                chunk = loads[c0:c0 + up.depth]
-                srcs = []
-                for j, (f, slot) in enumerate(chunk):
-                    assert order[item + j] == f
-                    srcs.append(up.get(item + j))
+            with _T("main.retire"):
+                slots.retire([f for f, lu in last_use.items() if lu < bi])
+            # Frames to pack now, in upload order: every frame this launch needs that is not resident (blocking on its upload), then —
+            # without waiting — the frames of later launches whose upload has already finished, while slots are free.  ONE frame-pack
+            # launch per group (vfi_rife_load_frames), in chunks of the staging ring's depth (a staging slot is recycled only after
+            # its frame has been packed).
+            need_set = set(need)
+            while True:
+                with _T("main.pick"):
+                    chunk = _pick_loads(order, item, need_set, slots, up.ready, up.depth)
+                if not chunk:
+                    break
+                with _T("main.get"):
+                    srcs = [up.get(item + j) for j in range(len(chunk))]
                 with _T("main.load_frame"):
                     engine.load_frames([slot for _, slot in chunk], srcs)
-                for j in range(len(chunk)):
-                    up.release(item + j)
+                with _T("main.release"):
+                    for j in range(len(chunk)):
+                        up.release(item + j)
                 item += len(chunk)
+                if all(f in slots.slot_of for f in need_set):
+                    break
+            missing = [f for f in need_set if f not in slots.slot_of]
+            assert not missing, f"frames {missing} of launch {bi} are not resident"
             m = slots.slot_of
             if out_device:
                 buf = res[pos:pos + len(bt)]
             else:
                 buf = bufs[k][:len(bt)]
                 if buf_free[k] is not None:
-                    main.wait_event(buf_free[k])   # the copy-back of two batches ago has left this buffer
+                    with _T("main.wait_buf"):
+                        main.wait_event(buf_free[k])   # the copy-back of two batches ago has left this buffer
             if tl is not None:
                 t_b = time.perf_counter() - t_base
                 e0 = torch.cuda.Event(enable_timing=True)
@@ -302,6 +359,8 @@ def run_tasks(engine, frames_cpu, tasks, batch_size, scale_factor=1.0, out_devic
                 done.record(main)
                 with _T("main.push"):
                     buf_free[k] = down.push(done, buf, [out[out_rows[pos + i]] for i in range(len(bt))])
+                if tl is not None:
+                    tl[-1] = tl[-1] + (time.perf_counter() - t_base,)
                 k ^= 1
     finally:
         up.close()
@@ -309,9 +368,11 @@ def run_tasks(engine, frames_cpu, tasks, batch_size, scale_factor=1.0, out_devic
             down.close()
     if tl is not None:
         torch.cuda.synchronize()
-        print("   batch: host[begin, uploads ready, enqueued] ms | device[start, end] ms (device clock zeroed at host 0)")
-        for i, (a, b, c, e0, e1) in enumerate(tl):
-            print(f"   {i:3d}: host {a * 1e3:7.1f} {b * 1e3:7.1f} {c * 1e3:7.1f} | device {ev_base.elapsed_time(e0):7.1f} {ev_base.elapsed_time(e1):7.1f}")
+        print("   batch: host[begin, uploads ready, enqueued, copy-back enqueued] ms | device[start, end] ms (device clock zeroed at host 0)")
+        for i, row in enumerate(tl):
+            a, b, c, e0, e1 = row[:5]
+            d = row[5] if len(row) > 5 else float("nan")
+            print(f"   {i:3d}: host {a * 1e3:7.1f} {b * 1e3:7.1f} {c * 1e3:7.1f} {d * 1e3:7.1f} | device {ev_base.elapsed_time(e0):7.1f} {ev_base.elapsed_time(e1):7.1f}")
     return res
 
 
@@ -457,11 +518,20 @@ class RIFE_VFI:
         # ahead of the copies that fill it
         # (starting them only after the first launch was tried: the GPU starts 8 ms earlier and the call ends 15 ms later —
         # the downloads then wait for pages)
-        passthrough = prefault_async(out)
-        passthrough += copy_rows_async(out, src_rows, frames, src_idx)
+        passthrough, started = [], threading.Event()
+
+        def start_host_side():      # first touch of the output + pass-through copies: ~200 ms of host-thread time on a 33-frame 1080p clip
+            if not started.is_set():
+                started.set()
+                passthrough.extend(prefault_async(out))
+                passthrough.extend(copy_rows_async(out, src_rows, frames, src_idx))
+
         batch_size = effective_batch(batch_size, frames.shape[1], frames.shape[2], len(tasks))
         rank, ws = world()
         group = self._device_group(cache_key, engine, arch_ver) if ws == 1 else None
+        single = group is None and ws == 1 and len(tasks) > 0
+        if not single:
+            start_host_side()
         if group is not None:
             # one process, several GPUs (multidev.py): every device interpolates its block of the task list and copies its own
             # shard into `out` over its own PCIe link
@@ -480,7 +550,19 @@ class RIFE_VFI:
                 down.push(ready, new_frames[c:c + 8], [out[new_rows[i]] for i in range(c, min(c + 8, len(tasks)))])
             down.close()
         else:
-            run_tasks(engine, frames, tasks, batch_size, scale_factor, out=out, out_rows=new_rows)
+            # (started once the first launch's frames are in pinned memory: beside them the staging copies the GPU waits for took
+            # 13 ms instead of 3 on the 256-thread host; started only after the first LAUNCH the downloads then wait for pages)
+            # ~25 worker threads move frames while this thread feeds the GPU: at CPython's default 5 ms switch interval a thread that
+            # wants the GIL can wait that long for it — the launch loop lost 10 ms between two launches that way
+            # (profiles/r04_e2e_timeline.txt)
+            import sys
+            switch = sys.getswitchinterval()
+            sys.setswitchinterval(2e-4)
+            try:
+                run_tasks(engine, frames, tasks, batch_size, scale_factor, out=out, out_rows=new_rows, on_staged=start_host_side)
+            finally:
+                sys.setswitchinterval(switch)
+            start_host_side()
         from .hostpipe import _T
         with _T("main.wait_pass"):
             for f in passthrough:

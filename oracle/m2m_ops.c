@@ -43,6 +43,34 @@ void oracle_softsplat_sum(const float* in, const float* flow, float* out, int N,
                 }
 }
 
+/* The same splat with the sources visited in REVERSE order (last pixel first): every contribution is the same product, only the
+ * order of the additions into a target changes — what the reference's own atomicAdd kernel leaves undefined on a GPU
+ * (softsplat.py:176-190).  Used by oracle/m2m_hot_certificate.py to measure how far the ORACLE's frame moves under a change of
+ * summation order alone. */
+void oracle_softsplat_sum_rev(const float* in, const float* flow, float* out, int N, int C, int H, int W) {
+    memset(out, 0, sizeof(float) * (size_t)N * C * H * W);
+    for (int n = 0; n < N; ++n)
+        for (int c = 0; c < C; ++c)
+            for (int y = H - 1; y >= 0; --y)
+                for (int x = W - 1; x >= 0; --x) {
+                    const float fltX = (float)x + flow[(((size_t)n * 2 + 0) * H + y) * W + x];
+                    const float fltY = (float)y + flow[(((size_t)n * 2 + 1) * H + y) * W + x];
+                    if (!isfinite(fltX) || !isfinite(fltY)) continue;
+                    const float fltIn = in[(((size_t)n * C + c) * H + y) * W + x];
+                    const int nwX = (int)floorf(fltX), nwY = (int)floorf(fltY);
+                    const int neX = nwX + 1, neY = nwY, swX = nwX, swY = nwY + 1, seX = nwX + 1, seY = nwY + 1;
+                    const float wNW = ((float)seX - fltX) * ((float)seY - fltY);
+                    const float wNE = (fltX - (float)swX) * ((float)swY - fltY);
+                    const float wSW = ((float)neX - fltX) * (fltY - (float)neY);
+                    const float wSE = (fltX - (float)nwX) * (fltY - (float)nwY);
+                    float* o = out + ((size_t)n * C + c) * H * W;
+                    if (seX >= 0 && seX < W && seY >= 0 && seY < H) o[(size_t)seY * W + seX] += fltIn * wSE;
+                    if (swX >= 0 && swX < W && swY >= 0 && swY < H) o[(size_t)swY * W + swX] += fltIn * wSW;
+                    if (neX >= 0 && neX < W && neY >= 0 && neY < H) o[(size_t)neY * W + neX] += fltIn * wNE;
+                    if (nwX >= 0 && nwX < W && nwY >= 0 && nwY < H) o[(size_t)nwY * W + nwX] += fltIn * wNW;
+                }
+}
+
 /* costvol.py:10-42: thread per (n,y,x); 81 output channels (dy outer, dx inner, both -4..4);
  * out = sum_c |one - two(shifted)| / C, out-of-bounds shift -> sum_c |one| / C. */
 void oracle_costvol(const float* one, const float* two, float* out, int N, int C, int H, int W) {

@@ -20,20 +20,21 @@ def lib():
         if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(_HERE, "m2m_ops.c")):
             subprocess.check_call(["make", "-s", "-C", _HERE])
         _lib = C.CDLL(so)
-        for f in (_lib.oracle_softsplat_sum, _lib.oracle_costvol):
+        for f in (_lib.oracle_softsplat_sum, _lib.oracle_softsplat_sum_rev, _lib.oracle_costvol):
             f.restype = None
             f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
     return _lib
 
 
-def softsplat_sum(ten_in, ten_flow):
-    """NCHW float32 numpy arrays -> summation splat (softsplat_func.forward, cupy_ops/softsplat.py:197-233)."""
+def softsplat_sum(ten_in, ten_flow, reverse=False):
+    """NCHW float32 numpy arrays -> summation splat (softsplat_func.forward, cupy_ops/softsplat.py:197-233).  ``reverse``: the same
+    contributions added in the opposite source order (oracle/m2m_hot_certificate.py)."""
     a = np.ascontiguousarray(ten_in, np.float32)
     f = np.ascontiguousarray(ten_flow, np.float32)
     n, c, h, w = a.shape
     assert f.shape == (n, 2, h, w)
     out = np.empty_like(a)
-    lib().oracle_softsplat_sum(a.ctypes.data, f.ctypes.data, out.ctypes.data, n, c, h, w)
+    (lib().oracle_softsplat_sum_rev if reverse else lib().oracle_softsplat_sum)(a.ctypes.data, f.ctypes.data, out.ctypes.data, n, c, h, w)
     return out
 
 

@@ -33,6 +33,18 @@ def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
 
 
+@pytest.fixture()
+def oracle_threads():
+    """Host-side oracle runs inside GPU tests: torch's default of one thread per logical CPU (256 on the MI355X box) is several
+    times SLOWER than 32 for these convolution sizes (bench.py's cpu_baseline measures the same)."""
+    import torch
+
+    before = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    yield
+    torch.set_num_threads(before)
+
+
 def apply_test_options(lib):
     """``VFI_TEST_OPTIONS="stage_quad=0,fuse_encode=0"`` — a variable of the TEST HARNESS (read here, never by the library): child
     processes of A/B tests select the other of two correct kernel forms through ``vfi_test_set_option`` (include/vfi_hip_test.h)."""

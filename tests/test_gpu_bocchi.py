@@ -4,6 +4,7 @@ oracle/VALIDATION_BOCCHI.log), default synthetic checkpoints and the "hot" ones 
 
 The goldens are fingerprints (oracle/golden_stats.py): per-pixel |d| <= 1e-3 on 12 full-precision 128x128 crops (corners,
 borders, centre, interior) and the mean / max of every 8x8 block of the whole frame."""
+import json
 import os
 
 import numpy as np
@@ -80,7 +81,10 @@ def test_film_bocchi_1080p_vs_reference_node(hip_lib, frames, golden_dir, tmp_pa
 def test_m2m_bocchi_1080p_vs_reference_node(hip_lib, frames, golden_dir, tmp_path, monkeypatch, tag, m, k):
     """Hot checkpoint: refined multi-branch flows up to 107 px — the summation splat is discontinuous in the flow (a source moves
     to the next target cell when its flow crosses an integer), so isolated pixels can exceed the per-pixel gate for ANY change of
-    rounding; they are bounded in number instead (<= 20 per frame) and in mean."""
+    rounding.  The bound on their number is DERIVED, not chosen: tests/golden/m2m_hot_certificate.json (oracle/m2m_hot_certificate.py)
+    records how many values of the ORACLE's own frame move by more than 1e-3 when the flows entering its splats are perturbed by the
+    size of this path's measured flow deviation — inside the 12 fingerprint crops: none, for every seed.  So inside the crops the
+    plain per-pixel gate holds here too; the full-frame statement is test_m2m_full_frame_vs_host_oracle below."""
     from cfi_amd import ckpt, m2m
 
     sd = synth.m2m_synth_state_dict(1234) if tag == "default" else synth.m2m_hot_state_dict(1234)
@@ -101,5 +105,91 @@ def test_m2m_bocchi_1080p_vs_reference_node(hip_lib, frames, golden_dir, tmp_pat
     d = np.abs(got["crops"] - fp["crops"])
     dm = np.abs(got["pool_mean"].astype(np.float64) - fp["pool_mean"])
     print(f"M2M hot x{m}: crops max|d| {d.max():.2e} mean {d.mean():.2e} n>1e-3 {(d > 1e-3).sum()}; block-mean max|d| {dm.max():.2e}")
-    assert d.mean() <= 2e-6 and (d > 1e-3).sum() <= 20, (d.max(), d.mean(), (d > 1e-3).sum())
-    assert (dm > golden_stats.POOL_MEAN_TOL).sum() <= 40
+    cert = json.load(open(os.path.join(golden_dir, "m2m_hot_certificate.json")))[key]
+    matched = [v for name, v in cert.items() if name.startswith("flow_rel9e-6")]
+    assert (d > 1e-3).sum() <= max(c["crop_values_over_1e-3"] for c in matched), (d.max(), (d > 1e-3).sum())          # = 0: the per-pixel gate
+    assert d.mean() <= max(c["crop_mean"] for c in matched) and (dm > golden_stats.POOL_MEAN_TOL).sum() <= max(c["blocks_over_pool_mean_tol"] for c in matched)
+
+
+# ---- FULL-FRAME per-pixel gates: the oracle (bit-exact with the reference nodes on this very pair, oracle/VALIDATION_BOCCHI.log) is
+# executed on the GPU box's HOST cores and every one of the 1080 x 1920 x 3 values is compared — the fingerprints above assert the
+# per-pixel gate on 4.7 % of the frame only (VERDICT r3 "weak" 3).
+
+
+@pytest.mark.parametrize("tag", ["default", "hot"])
+def test_rife47_full_frame_vs_host_oracle(hip_lib, frames, tag, oracle_threads):
+    from cfi_amd.rife import RifeEngine, run_tasks
+    from oracle import rife_oracle
+
+    sd = synth.rife47_synth_state_dict(1234) if tag == "default" else synth.rife47_hot_state_dict(1234)
+    want = rife_oracle.rife_vfi(sd, frames, multiplier=4)[1:4]                     # t = .25, .5, .75
+    eng = RifeEngine(sd, "4.7")
+    try:
+        got = run_tasks(eng, frames, [(0, 0.25), (0, 0.5), (0, 0.75)], batch_size=3)
+    finally:
+        eng.close()
+    d = (got - want).abs()
+    print(f"RIFE 4.7 {tag} x4 @1080p bocchi, FULL frames vs the oracle on the host: max|d| {d.max().item():.2e} mean {d.mean().item():.2e}")
+    assert d.max().item() <= 1e-3
+
+
+@pytest.mark.parametrize("tag", ["default", "hot"])
+def test_film_full_frame_vs_host_oracle(hip_lib, frames, tag, oracle_threads):
+    from cfi_amd.film import FilmEngine
+    from oracle import film_oracle
+
+    sd = synth.film_synth_state_dict(1234) if tag == "default" else synth.film_hot_state_dict(1234)
+    x = frames.permute(0, 3, 1, 2).contiguous()
+    with torch.inference_mode():
+        want = film_oracle.film_forward(sd, x[0:1], x[1:2]).clamp(0, 1).permute(0, 2, 3, 1)[0]
+    eng = FilmEngine(sd)
+    try:
+        f = frames.cuda()
+        got = eng.forward(f[0].contiguous(), f[1].contiguous(), clamp=True).cpu()
+    finally:
+        eng.close()
+    d = (got - want).abs()
+    print(f"FILM {tag} x2 @1080p bocchi, FULL frame vs the oracle on the host: max|d| {d.max().item():.2e} mean {d.mean().item():.2e}")
+    assert d.max().item() <= 1e-3
+
+
+@pytest.mark.parametrize("tag,m,k", [("default", 2, 1), ("default", 3, 1), ("hot", 2, 1), ("hot", 3, 1)])
+def test_m2m_full_frame_vs_host_oracle(hip_lib, frames, golden_dir, tag, m, k, oracle_threads):
+    """Default checkpoint: the plain per-pixel gate on every value of the frame.  Hot checkpoint (refined flows up to 107 px): the
+    number of pixels over 1e-3 must not exceed what the ORACLE ITSELF moves when the flows entering its splats are perturbed by the
+    size of this path's flow deviation (tests/golden/m2m_hot_certificate.json, 'flow_rel9e-6_*': uniform relative 9e-6 = mean 4.5e-6;
+    the smallest count over the seeds is the bound) — and that the deviation of the flows really is of that size is asserted here too."""
+    from cfi_amd.m2m import M2MEngine
+    from oracle import m2m_model_oracle as MO
+
+    sd = synth.m2m_synth_state_dict(1234) if tag == "default" else synth.m2m_hot_state_dict(1234)
+    x = frames.permute(0, 3, 1, 2)
+    t = k / m
+    with torch.inference_mode():
+        (o,), aux = MO.m2m_forward(sd, x[0:1], x[1:2], [torch.full((1, 1, 1, 1), float(t))], return_aux=True)
+    want = o[0].permute(1, 2, 0).contiguous()
+    eng = M2MEngine(sd)
+    try:
+        f = frames.cuda()
+        eng.prepare(f[0].contiguous(), f[1].contiguous())
+        got = eng.render(t).cpu()
+        d0, r = eng.d0, eng.r
+    finally:
+        eng.close()
+    d = (got - want).abs()
+    over = int((d.max(dim=2).values > 1e-3).sum())
+    rel_mean = []
+    for di, name in ((0, "ten_fwd"), (1, "ten_bwd")):
+        hip = d0[di, :, :, 0:2].repeat(1, 1, 4) + r[di, :, :, 0:8]
+        ora = aux[name][0].permute(1, 2, 0)
+        rel_mean.append(((hip - ora).abs() / ora.abs().clamp_min(1.0)).mean().item())
+    print(f"M2M {tag} x{m} frame {k} @1080p bocchi, FULL frame vs the oracle on the host: max|d| {d.max().item():.2e} mean {d.mean().item():.2e}, "
+          f"pixels over 1e-3: {over}; refined flows (max {aux['ten_fwd'].abs().max().item():.0f} px): mean relative deviation {rel_mean[0]:.2e} / {rel_mean[1]:.2e}")
+    if tag == "default":
+        assert d.max().item() <= 1e-3
+        return
+    cert = json.load(open(os.path.join(golden_dir, "m2m_hot_certificate.json")))[f"hot_x{m}_{k}"]
+    matched = [v for name, v in cert.items() if name.startswith("flow_rel9e-6")]
+    assert max(rel_mean) <= 4.5e-6 * 1.25, "the flows deviate by more than the perturbation the certificate was computed for"
+    assert over <= min(c["frame_pixels_over_1e-3"] for c in matched), (over, [c["frame_pixels_over_1e-3"] for c in matched])
+    assert d.mean().item() <= min(c["frame_mean"] for c in matched)

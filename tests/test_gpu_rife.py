@@ -83,7 +83,7 @@ def test_frame_pack_against_oracle(engine, sd):
     with torch.inference_mode():
         feat = rife_oracle.encode(sd, img)
     found = 0
-    for slot in range(4):
+    for slot in range(engine.cfg[3]):      # every frame slot of the configuration (run_tasks packs into whichever is free)
         pk = engine.debug_read(2, slot, hp * wp * 8).view(2, hp, wp, 4)   # planar4: [rgb0 | features]
         for k in range(2):
             if (pk[0][..., :3] - img[k].permute(1, 2, 0)).abs().max().item() == 0.0:
@@ -324,7 +324,7 @@ def test_rife417_frame_pack_and_flows(engine417, sd417):
             _, aux = rife_oracle.ifnet47_forward(sd417, x[0:1], x[1:2], torch.tensor([0.5]).view(1, 1, 1, 1), return_aux=True, arch="4.17")
             feat = rife_oracle.encode417(sd417, torch.nn.functional.pad(x[0:1].clamp(0, 1), (0, wp - w, 0, hp - h)))
         slot = None
-        for s_ in range(4):   # find the slot that holds frame 0 (slot assignment is an implementation detail)
+        for s_ in range(engine417.cfg[3]):   # find the slot that holds frame 0 (slot assignment is an implementation detail)
             pack = engine417.debug_read(2, s_, 3 * hp * wp * 4).view(3, hp, wp, 4)
             if torch.equal(pack[0, :h, :w, :3], frames[0].clamp(0, 1)):
                 slot = s_

@@ -55,3 +55,51 @@ def test_shard_tasks_partition(n, world):
     assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
     sizes = [hi - lo for lo, hi in parts]
     assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.parametrize("n_frames,mult,bs,skip,ready_mode", [(33, 2, 8, (), "always"), (33, 2, 8, (), "never"), (17, 4, 4, (), "alternate"),
+                                                               (12, 3, 8, (2, 5, 6), "always"), (3, 2, 8, (), "never"), (40, 2, 16, (1, 3, 5, 7, 9, 11), "alternate")])
+def test_frame_pack_run_ahead_policy(n_frames, mult, bs, skip, ready_mode):
+    """rife.run_tasks' frame-pack policy without a device (rife._pick_loads + _FrameSlots): every launch finds its frames resident,
+    every frame is packed exactly once and in upload order, frames packed AHEAD of their launch never exceed PACK_AHEAD nor the
+    slot count, whatever the uploads' timing (``ready``: always / never / every other query)."""
+    from cfi_amd import rife as R
+    from cfi_amd.schedule import InterpolationStateList, rife_task_list
+
+    states = InterpolationStateList(list(skip), True) if skip else None
+    _, tasks = rife_task_list(n_frames, mult, states)
+    batches = list(R._batches(tasks, bs))
+    order, last_use = [], {}
+    for bi, (_, _, need) in enumerate(batches):
+        for f in need:
+            if f not in last_use:
+                order.append(f)
+            last_use[f] = bi
+    n_slots = 2 * bs + 2 + R.PACK_AHEAD
+    depth = min(len(order), n_slots) or 1
+    slots = R._FrameSlots(n_slots)
+    calls = [0]
+
+    def ready(i):
+        calls[0] += 1
+        return ready_mode == "always" or (ready_mode == "alternate" and calls[0] % 2 == 0)
+
+    item, packed = 0, []
+    for bi, (pos, bt, need) in enumerate(batches):
+        slots.retire([f for f, lu in last_use.items() if lu < bi])
+        need_set = set(need)
+        while True:
+            chunk = R._pick_loads(order, item, need_set, slots, ready, depth)
+            if not chunk:
+                break
+            packed += [f for f, _ in chunk]
+            item += len(chunk)
+            assert len(set(slots.slot_of.values())) == len(slots.slot_of) <= n_slots
+            assert sum(1 for g in slots.slot_of if g not in need_set) <= R.PACK_AHEAD
+            if all(f in slots.slot_of for f in need_set):
+                break
+        assert all(f in slots.slot_of for f in need_set), (bi, need_set, slots.slot_of)
+    assert packed == order[:len(packed)] and len(packed) == len(set(packed))
+    assert set(packed) >= {f for _, _, need in batches for f in need}
+    if ready_mode == "never":       # nothing is packed before the launch that needs it
+        assert packed == order
