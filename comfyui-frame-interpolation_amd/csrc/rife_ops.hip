@@ -17,6 +17,7 @@
 #include "rife_ops.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <atomic>
 #include "rife_warp.h"
 #include <cstdlib>
@@ -378,6 +379,12 @@ struct EncodeBatch {
 };
 constexpr int ENC_NPRE = (ENC_TI * ENC_TI + 255) / 256;      // source pixels per thread and tile (6)
 
+// Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() is fence + s_barrier and the fence waits for EVERY outstanding
+// memory operation of the wave (s_waitcnt vmcnt(0)): the global loads of the next tile, issued just before, would be waited for at
+// the very next barrier — no prefetch at all.  Here only the LDS counter is drained; the prefetched registers are waited for by
+// hipcc's own wait-count pass where they are first used (the next iteration's phase 0).
+__device__ __forceinline__ void enc_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <typename SRC>
 __global__ __launch_bounds__(256) void encode47_batch_kernel(const EncodeBatch fb, const float* __restrict__ w0, const float* __restrict__ b0,
                                                              const float* __restrict__ w1, const float* __restrict__ b1, int H, int W, int C, int Hp,
@@ -387,8 +394,10 @@ __global__ __launch_bounds__(256) void encode47_batch_kernel(const EncodeBatch f
     __shared__ __attribute__((aligned(16))) float sE[ENC_TE * ENC_TE * CM];
     const int tid = threadIdx.x;
     const int He = Hp / 2, We = Wp / 2;
-    // raw source values of the next item (clamp / divide happen when they are stored to LDS: same values as the single-frame kernel)
-    SRC pre[ENC_NPRE][3];
+    // raw source values of the next item (clamp / divide happen when they are stored to LDS: same values as the single-frame kernel),
+    // one 32-bit register each
+    typedef typename std::conditional<sizeof(SRC) == 1, unsigned, float>::type RAW;
+    RAW pre[ENC_NPRE][3];
     auto decode = [&](int item, int& f, int& Y0, int& X0) {
         f = item / tiles_per_frame;
         const int t = item - f * tiles_per_frame;
@@ -404,12 +413,11 @@ __global__ __launch_bounds__(256) void encode47_batch_kernel(const EncodeBatch f
         for (int r = 0; r < ENC_NPRE; ++r) {
             const int i = tid + r * 256;
             const int py = i / ENC_TI, px = i - py * ENC_TI;
-            const int Y = iy0 + py, X = ix0 + px;
-            pre[r][0] = pre[r][1] = pre[r][2] = (SRC)0;
-            if (i < ENC_TI * ENC_TI && Y >= 0 && Y < H && X >= 0 && X < W) {
-                const SRC* sp = src + ((size_t)Y * W + X) * C;
-                pre[r][0] = sp[0], pre[r][1] = sp[1], pre[r][2] = sp[2];
-            }
+            // UNCONDITIONAL loads from a clamped address (validity is applied when the values are consumed): a load inside a branch is
+            // merged with the "else 0" by moves right behind it, i.e. waited for at once — six serial round trips instead of six in flight
+            const int Y = min(max(iy0 + py, 0), H - 1), X = min(max(ix0 + px, 0), W - 1);
+            const SRC* sp = src + ((size_t)Y * W + X) * C;
+            pre[r][0] = (RAW)sp[0], pre[r][1] = (RAW)sp[1], pre[r][2] = (RAW)sp[2];
         }
     };
     int item = blockIdx.x;
@@ -424,28 +432,33 @@ __global__ __launch_bounds__(256) void encode47_batch_kernel(const EncodeBatch f
 #pragma unroll
         for (int r = 0; r < ENC_NPRE; ++r) {
             const int i = tid + r * 256;
+            // the prefetched registers become visible to the optimiser HERE: without the pin hipcc computes the clamp / division right
+            // behind the loads of the previous iteration (pure arithmetic on loaded values) and waits for them there — no prefetch
+            RAW x0 = pre[r][0], x1 = pre[r][1], x2 = pre[r][2];
+            asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2));
             if (i < ENC_TI * ENC_TI) {
                 const int py = i / ENC_TI, px = i - py * ENC_TI;
                 const int Y = iy0 + py, X = ix0 + px;
                 float4 v = {0.f, 0.f, 0.f, 0.f};
                 if (Y >= 0 && Y < H && X >= 0 && X < W) {
                     if (sizeof(SRC) == 1) {
-                        v.x = __fdiv_rn((float)pre[r][0], 255.0f);
-                        v.y = __fdiv_rn((float)pre[r][1], 255.0f);
-                        v.z = __fdiv_rn((float)pre[r][2], 255.0f);
+                        v.x = __fdiv_rn((float)x0, 255.0f);
+                        v.y = __fdiv_rn((float)x1, 255.0f);
+                        v.z = __fdiv_rn((float)x2, 255.0f);
                     } else {
-                        v.x = fminf(fmaxf((float)pre[r][0], 0.f), 1.f);
-                        v.y = fminf(fmaxf((float)pre[r][1], 0.f), 1.f);
-                        v.z = fminf(fmaxf((float)pre[r][2], 0.f), 1.f);
+                        v.x = fminf(fmaxf((float)x0, 0.f), 1.f);
+                        v.y = fminf(fmaxf((float)x1, 0.f), 1.f);
+                        v.z = fminf(fmaxf((float)x2, 0.f), 1.f);
                     }
                 }
                 sI[i] = v;
                 if (py >= 3 && py < 3 + ENC_T && px >= 3 && px < 3 + ENC_T && Y < Hp && X < Wp) *(float4*)(P + ((size_t)Y * Wp + X) * 4) = v;
             }
         }
-        // the next item's source tile: in flight under phases 1 and 2
-        if (item + (int)gridDim.x < n_items) prefetch(item + gridDim.x);
-        __syncthreads();
+        // the next item's source tile: in flight under phases 1 and 2.  Unconditional (the last item re-reads its own tile): behind a
+        // branch the loaded registers are merged with the old ones by moves at the end of the block — and waited for there
+        prefetch(min(item + (int)gridDim.x, n_items - 1));
+        enc_lds_barrier();
         // ---- phase 1: E tile
         const int ey0 = Y0 / 2 - 1, ex0 = X0 / 2 - 1;
         for (int i = tid; i < ENC_TE * ENC_TE; i += 256) {
@@ -471,7 +484,7 @@ __global__ __launch_bounds__(256) void encode47_batch_kernel(const EncodeBatch f
 #pragma unroll
             for (int q = 0; q < CM / 4; ++q) *(float4*)&sE[i * CM + 4 * q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
         }
-        __syncthreads();
+        enc_lds_barrier();
         // ---- phase 2: one E pixel of the 16x16 centre per thread -> its 2x2 output quad
         {
             const int lx = tid & 15, ly = tid >> 4;
@@ -515,7 +528,7 @@ __global__ __launch_bounds__(256) void encode47_batch_kernel(const EncodeBatch f
                 }
             }
         }
-        __syncthreads();      // sE (and sI) are rewritten by the next item
+        enc_lds_barrier();      // sE (and sI) are rewritten by the next item
     }
 }
 
