@@ -29,6 +29,7 @@ PROTOTYPES = {
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "vfi_test_conv_algo": (C.c_int, [C.c_int]),
     "vfi_test_pack_wino3x3": (C.c_int64, [C.c_void_p, C.c_int, C.c_int, c_int_p, C.c_int, C.c_void_p, C.c_int64]),
+    "vfi_test_pack_deconv3x3": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64]),
     "vfi_test_set_option": (C.c_int, [C.c_char_p, C.c_int64]),
     "vfi_test_variant_override": (C.c_int, [C.c_char_p]),
     "vfi_deconv4x4_ps2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,

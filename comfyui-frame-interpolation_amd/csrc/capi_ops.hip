@@ -118,6 +118,22 @@ int64_t vfi_test_pack_wino3x3(const float* weight_host, int Cout, int Cin, const
     return (int64_t)wp.size();
 }
 
+int64_t vfi_test_pack_deconv3x3(const float* weight_host, const float* bias_host, int Cin, int LO, float* w3_host, float* b3_host, int64_t cap) {
+    if (!weight_host || !w3_host || !b3_host || Cin <= 0 || LO <= 0) {
+        set_error("vfi_test_pack_deconv3x3: bad arguments");
+        return -1;
+    }
+    std::vector<float> w3, b3;
+    pack_deconv_as_conv3x3(weight_host, bias_host, Cin, LO, w3, b3);
+    if ((int64_t)w3.size() > cap) {
+        set_error("vfi_test_pack_deconv3x3: buffer too small (need %lld floats)", (long long)w3.size());
+        return -1;
+    }
+    memcpy(w3_host, w3.data(), w3.size() * sizeof(float));
+    memcpy(b3_host, b3.data(), b3.size() * sizeof(float));
+    return (int64_t)w3.size();
+}
+
 int vfi_conv3x3_naive(const float* in_dev, const float* weight_host, const float* bias_host, const float* beta_host,
                       float* out_dev, int N, int H, int W, int Cin, int Cout, int stride, int act, float slope,
                       void* stream) {
@@ -166,8 +182,25 @@ int vfi_deconv4x4_ps2(const float* in_dev, const float* weight_host, const float
     a.Cout_p = 32;
     a.Cout = Cout;
     a.out_mode = 1;
-    deconv4x4_taps(a);
-    if (conv_launch(a, 1, true, -1, st, nullptr)) return -1;
+    Tmp dw3, db3;
+    if (option(kOptDeconvWino) && conv_wino_mode(-1) != 1 && option(kOptGroupedVariant) < 0 && Cin % 8 == 0) {
+        // the form the RIFE network uses: one 3x3 layer with 4 * Cout channels on the Winograd kernel, pixel-shuffle epilogue
+        std::vector<float> w3, b3, wq;
+        pack_deconv_as_conv3x3(weight_host, bias_host, Cin, Cout, w3, b3);
+        const int cp = round_up(4 * Cout, 32);
+        pack_wino3x3(w3.data(), 4 * Cout, Cin, nullptr, Cin, cp, wq);
+        b3.resize(cp, 0.f);
+        if (dw3.put(wq) || db3.put(b3)) return -1;
+        conv3x3_taps(a);
+        a.w = dw3.p;
+        a.bias = db3.p;
+        a.Cout = 4 * Cout;
+        a.Cout_p = cp;
+        if (conv_wino_launch(a, 8, st, "deconv4x4_wino")) return -1;
+    } else {
+        deconv4x4_taps(a);
+        if (conv_launch(a, 1, true, -1, st, nullptr)) return -1;
+    }
     if (t_to_nhwc_launch(T.p, out_dev, N, H, W, Cout / 4, st)) return -1;
     VFI_CHECK_HIP(hipStreamSynchronize(st));
     return 0;

@@ -48,6 +48,8 @@ struct WinoArgs {
     int NY;         // Cout_p / 32
     int xcd_map;    // 1: XCD-aware work order (gridDim.x % 8 == 0)
     float inv_NY, inv_per, inv_rx;   // 1 / NY, 1 / (rx * ry), 1 / rx: the work decode divides by multiplication (see wino_div)
+    int LO;                          // SHUF epilogue: channels per parity group (Cout / 4) and
+    float inv_LO;                    //   its reciprocal (an integer division in the epilogue keeps a hoisted reciprocal alive — spilled — through the K loop)
 };
 
 template <int RTX>
@@ -126,14 +128,21 @@ __device__ __forceinline__ f32x2 wino_pk_mul(f32x2 x, f32x2 y) {
 // MODE 10 + act: the general form (residual, any activation of ConvArgs::act, post affine).
 // FULL: the region lies completely inside the image (wave-uniform, true for all but the last row / column of regions): no
 // row branches and no per-store column test (they were ~260 of the epilogue's 1350 instructions).
-template <int RTX, int MODE, bool FULL = false>
+// SHUF (MODE 0 only, ConvArgs::out_mode 1): the layer is a ConvTranspose2d(4, 2, 1) + PixelShuffle(2) written as a 3x3 convolution —
+// output channel co = parity group g x LO + cg (pack_deconv_as_conv3x3) — and the epilogue stores straight into the planar4 block
+// output T [n][planes][4H][4W][4]: pixel (4 oy + 2 (g >> 1) + ((cg >> 1) & 1), 4 ox + 2 (g & 1) + (cg & 1)), plane (cg >> 2) >> 2,
+// component (cg >> 2) & 3 — the mapping of conv_mfma2's out_mode 1 epilogue.
+template <int RTX, int MODE, bool FULL = false, bool SHUF = false>
 __device__ __forceinline__ void wino_epilogue(const f32x16 (&acc)[16], const ConvArgs& a, int n, int oy0, int ox0, int co, int coc, int half, float bs,
-                                              float bt, float pre) {
+                                              float bt, float pre, int LO = 0, float inv_LO = 0.f) {
     const int H = a.Hin, W = a.Win;
     const float uslope = a.act == 1 ? a.slope : 1.0f;
     const float ps = a.post_scale != 0.f ? a.post_scale : 1.0f, sh = a.post_scale != 0.f ? a.post_shift : 0.0f;
+    const int planes = a.out_planes ? a.out_planes : 2;
+    const int Ws4 = 4 * W;                       // SHUF: T row length in pixels
     const __amdgpu_buffer_rsrc_t orsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)n * H * W * a.out_cs), 0, H * W * a.out_cs * 4, 0x00020000);
+        SHUF ? __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)n * planes * 16 * H * W * 4), 0, planes * 16 * H * W * 16, 0x00020000)
+             : __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)n * H * W * a.out_cs), 0, H * W * a.out_cs * 4, 0x00020000);
     const bool has_res = MODE >= 10 && a.res != nullptr;
     const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(has_res ? a.res + (size_t)n * H * W * a.res_cs : a.out), 0, has_res ? H * W * a.res_cs * 4 : 0, 0x00020000);
@@ -141,8 +150,15 @@ __device__ __forceinline__ void wino_epilogue(const f32x16 (&acc)[16], const Con
     const bool cok = co < a.Cout;
     const bool interior = FULL || ox0 + 2 * RTX <= W;  // every column of the region is inside the image (wave-uniform)
     // lane part of the byte offsets in a VGPR (0x80000000 = dropped by the descriptor's range check), per-store part scalar
-    const int lane_o = cok ? (xlane * a.out_cs + co) * 4 : (int)0x80000000;
+    int lane_o = cok ? (xlane * a.out_cs + co) * 4 : (int)0x80000000;
     const int lane_r = cok ? (xlane * a.res_cs + co) * 4 : (int)0x80000000;
+    if (SHUF && cok) {      // lane part: plane, sub-pixel of the 4x4 cell, component, and the lane's first column
+        int g = (int)((float)co * inv_LO), cg = co - g * LO;      // co / LO by multiplication + one fix-up (0 <= co < 2^10)
+        if (cg < 0) --g, cg += LO;
+        if (cg >= LO) ++g, cg -= LO;
+        const int c = cg >> 2;
+        lane_o = ((((c >> 2) * 4 * H + 2 * (g >> 1) + ((cg >> 1) & 1)) * Ws4 + 2 * (g & 1) + (cg & 1) + 4 * xlane) * 4 + (c & 3)) * 4;
+    }
     // Two tiles (accumulator registers r, r + 1 = neighbours in x) per step, in packed fp32: the epilogue's VALU work is not hidden by
     // anything (the wave's MFMAs are over), v_pk_* does two values per instruction in the same order of operations as the scalar form.
     const f32x2 bsbt = {bs, bt}, sl2 = {uslope, uslope};
@@ -168,7 +184,7 @@ __device__ __forceinline__ void wino_epilogue(const f32x16 (&acc)[16], const Con
         for (int ey = 0; ey < 2; ++ey) {
             const int oy = oy0 + 2 * tyy + ey;          // wave-uniform
             if (FULL || oy < H) {
-                const int rowo = oy * W * a.out_cs * 4, rowr = oy * W * a.res_cs * 4;
+                const int rowo = SHUF ? oy * 4 * Ws4 * 16 : oy * W * a.out_cs * 4, rowr = oy * W * a.res_cs * 4;
 #pragma unroll
                 for (int ex = 0; ex < 2; ++ex) {
                     f32x2 v2 = wino_pk_mul_hi(wino_pk_add_lo(y[ey * 2 + ex], bsbt), bsbt);
@@ -191,7 +207,7 @@ __device__ __forceinline__ void wino_epilogue(const f32x16 (&acc)[16], const Con
                             else if (MODE == 15) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
                             v = v * ps + sh;
                         }
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orsrc, ok ? lane_o : (int)0x80000000, rowo + xq * a.out_cs * 4, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orsrc, ok ? lane_o : (int)0x80000000, rowo + (SHUF ? xq * 64 : xq * a.out_cs * 4), 0);
                     }
                 }
             }
@@ -200,7 +216,7 @@ __device__ __forceinline__ void wino_epilogue(const f32x16 (&acc)[16], const Con
     }
 }
 
-template <int RTX, int MODE>
+template <int RTX, int MODE, bool SHUF = false>
 __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr bool EXT = MODE != 0;      // a general epilogue (wino_epilogue's MODE 10 + act): one kernel per activation, no switch in the item loop
@@ -536,9 +552,9 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
                 const int co = ccur.nb * 32 + (ole & 31);
                 const int coc = co < a.Cout ? co : a.Cout - 1;
                 if (ccur.Ry0 + RH <= H && ccur.Rx0 + RW <= W)
-                    wino_epilogue<RTX, MODE, true>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half, cst[co], cst[G::MAXCO + co], cst[2 * G::MAXCO + co]);
+                    wino_epilogue<RTX, MODE, true, SHUF>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half, cst[co], cst[G::MAXCO + co], cst[2 * G::MAXCO + co], p.LO, p.inv_LO);
                 else
-                    wino_epilogue<RTX, MODE, false>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half, cst[co], cst[G::MAXCO + co], cst[2 * G::MAXCO + co]);
+                    wino_epilogue<RTX, MODE, false, SHUF>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half, cst[co], cst[G::MAXCO + co], cst[2 * G::MAXCO + co], p.LO, p.inv_LO);
             }
         }
 #undef WINO_MF4
@@ -571,6 +587,30 @@ void pack_wino3x3(const float* w_oihw, int Cout, int Cin, const int* chan_map, i
                 wp[idx] += (float)U[xi >> 2][xi & 3];
             }
         }
+}
+
+// ConvTranspose2d(Cin, LO, 4, 2, 1) as ONE 3x3 stride-1 pad-1 convolution with 4 * LO output channels: output parity (py, px) of
+// the transposed convolution reads the 2x2 input neighbourhood rows {y + py - 1, y + py} x columns {x + px - 1, x + px} with kernel
+// taps ky = 3 - py - 2a, kx = 3 - px - 2b (pack_deconv4x4) — four of the nine taps of a 3x3 window centred on (y, x).
+// w_iohw [Cin][LO][4][4] -> w3 OIHW [4 * LO][Cin][3][3] with channel g * LO + co, g = 2 py + px; bias repeated per parity.
+// No multiplication is saved against the four 2x2 parity convolutions (5 of 9 taps are zero and Winograd's 16 products per 2x2
+// tile equal the 4 x 4 direct ones) — what is saved is the padding of LO = 24 to a 32-wide MFMA N tile (4 x 24 = 96 = 3 x 32
+// exactly) and the layer runs on the tuned Winograd kernel instead of the grouped direct one.
+void pack_deconv_as_conv3x3(const float* w_iohw, const float* bias, int Cin, int LO, std::vector<float>& w3, std::vector<float>& b3) {
+    w3.assign((size_t)4 * LO * Cin * 9, 0.f);
+    b3.assign((size_t)4 * LO, 0.f);
+    for (int g = 0; g < 4; ++g) {
+        const int py = g >> 1, px = g & 1;
+        for (int co = 0; co < LO; ++co) {
+            if (bias) b3[(size_t)g * LO + co] = bias[co];
+            for (int t = 0; t < 4; ++t) {
+                const int a = t >> 1, b = t & 1;
+                const int ky = 3 - py - 2 * a, kx = 3 - px - 2 * b;
+                for (int ci = 0; ci < Cin; ++ci)
+                    w3[(((size_t)(g * LO + co) * Cin + ci) * 3 + py + a) * 3 + px + b] = w_iohw[(((size_t)ci * LO + co) * 4 + ky) * 4 + kx];
+            }
+        }
+    }
 }
 
 // 0 = automatic, 1 = direct kernel only, 2 = Winograd wherever the layer shape allows it.  Set through the test hook
@@ -609,7 +649,7 @@ bool conv_wino_eligible(const ConvArgs& a) {
     return regions / 4 * (a.Cout_p / 32) >= 192;
 }
 
-template <int RTX, int MODE>
+template <int RTX, int MODE, bool SHUF = false>
 static int wino_launch_t(WinoArgs& p, hipStream_t s, const char* name) {
     using G = WinoGeom<RTX>;
     ConvArgs& a = p.a;
@@ -620,12 +660,14 @@ static int wino_launch_t(WinoArgs& p, hipStream_t s, const char* name) {
     p.NY = a.Cout_p / 32;
     VFI_REQUIRE((long)p.NQ * p.NY + 2048 < (1L << 24) && p.R < (1 << 24), "conv_wino %s: too many work items for the kernel's float work decode", name);
     p.inv_NY = 1.0f / (float)p.NY, p.inv_per = 1.0f / (float)(p.rx * p.ry), p.inv_rx = 1.0f / (float)p.rx;
+    p.LO = a.Cout >= 4 ? a.Cout / 4 : 1;
+    p.inv_LO = 1.0f / (float)p.LO;
     int dev = 0;
     VFI_CHECK_HIP(hipGetDevice(&dev));
     VFI_REQUIRE(dev >= 0 && dev < kMaxDevices, "conv_wino %s: device index %d out of range", name, dev);
     static std::atomic<int> attr_set[kMaxDevices];
     if (!attr_set[dev].load(std::memory_order_acquire)) {
-        VFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<RTX, MODE>),
+        VFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<RTX, MODE, SHUF>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
         attr_set[dev].store(1, std::memory_order_release);
     }
@@ -635,14 +677,14 @@ static int wino_launch_t(WinoArgs& p, hipStream_t s, const char* name) {
     grid = round_up(grid, 8);
     p.xcd_map = option(kOptWinoXcd) ? 1 : 0;
     TraceScope ts(name, s);
-    hipLaunchKernelGGL((conv_wino_kernel<RTX, MODE>), dim3(grid), dim3(256), G::LDS_BYTES, s, p);
+    hipLaunchKernelGGL((conv_wino_kernel<RTX, MODE, SHUF>), dim3(grid), dim3(256), G::LDS_BYTES, s, p);
     VFI_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 // a.w must point at pack_wino3x3's output (device).  variant: 0 = pick, 8 / 16 = region shape (tiles per row)
 int conv_wino_launch(const ConvArgs& a, int variant, hipStream_t s, const char* name) {
-    VFI_REQUIRE(a.ntaps == 9 && a.Hout == a.Hin && a.Wout == a.Win && !a.in_plane && a.out_mode == 0,
+    VFI_REQUIRE(a.ntaps == 9 && a.Hout == a.Hin && a.Wout == a.Win && !a.in_plane && (a.out_mode == 0 || a.out_mode == 1),
                 "conv_wino %s: 3x3 stride-1 NHWC layers only", name);
     VFI_REQUIRE(a.Cin_p % 8 == 0 && a.Cout_p % 32 == 0 && a.Cout_p <= 1024 && a.in_cs >= a.Cin_p && a.in_cs % 4 == 0, "conv_wino %s: bad channel padding Cin_p=%d Cout_p=%d in_cs=%d",
                 name, a.Cin_p, a.Cout_p, a.in_cs);
@@ -660,12 +702,17 @@ int conv_wino_launch(const ConvArgs& a, int variant, hipStream_t s, const char* 
         variant = e16 > e8 * 1.15 ? 16 : 8;
     }
     VFI_REQUIRE(variant == 8 || variant == 16, "conv_wino %s: bad variant %d", name, variant);
-    VFI_REQUIRE((long)a.Hin * a.Win * a.out_cs * 4 < 0x7fffffffL && (!a.res || (long)a.Hin * a.Win * a.res_cs * 4 < 0x7fffffffL),
+    VFI_REQUIRE((a.out_mode == 1 || (long)a.Hin * a.Win * a.out_cs * 4 < 0x7fffffffL) && (!a.res || (long)a.Hin * a.Win * a.res_cs * 4 < 0x7fffffffL),
                 "conv_wino %s: output / residual image larger than 2 GiB", name);
     // the hot epilogue: no residual, no post affine, none / LeakyReLU with a slope in [0,1]
     const bool ext = a.res != nullptr || a.post_scale != 0.f || !(a.act == 0 || (a.act == 1 && a.slope >= 0.f && a.slope <= 1.f));
     VFI_REQUIRE(a.act >= 0 && a.act <= 5, "conv_wino %s: activation code %d", name, a.act);
     const int mode = ext ? 10 + a.act : 0;      // wino_epilogue's MODE: one kernel per general activation
+    if (a.out_mode == 1) {      // transposed convolution + PixelShuffle as a 3x3 layer (pack_deconv_as_conv3x3): hot epilogue, 16x8 regions
+        VFI_REQUIRE(!ext && a.Cout % 4 == 0 && a.act == 0 && !a.beta, "conv_wino %s: the pixel-shuffle output takes the plain epilogue (bias only)", name);
+        VFI_REQUIRE((long)(a.out_planes ? a.out_planes : 2) * 16 * a.Hin * a.Win * 16 < 0x7fffffffL, "conv_wino %s: block output larger than 2 GiB", name);
+        return wino_launch_t<8, 0, true>(p, s, name);
+    }
 #define WINO_DISPATCH(R_)                                              \
     switch (mode) {                                                    \
         case 0: return wino_launch_t<R_, 0>(p, s, name);               \

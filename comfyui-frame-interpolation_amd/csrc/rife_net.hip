@@ -68,7 +68,9 @@ int upload(DevBuf& b, const std::vector<float>& h) {
 }
 
 struct ConvLayer {
-    DevBuf w, ww, bias, beta;   // ww: Winograd F(2x2,3x3) pack (3x3 stride-1 layers: the ResConvs and the 4.17 / 4.26 head)
+    DevBuf w, ww, bias, beta;   // ww: Winograd F(2x2,3x3) pack (3x3 stride-1 layers: the ResConvs and the 4.17 / 4.26 head; lastconv as a 3x3 layer)
+    DevBuf bias3;               // lastconv as a 4 * LO-channel 3x3 layer (pack_deconv_as_conv3x3): its bias, repeated per parity group
+    int Cout3_p = 0;
     int Cin = 0, Cin_p = 0, Cout = 0, Cout_p = 0;
     bool folded = false;  // residual folded into the centre tap (ResConv)
 };
@@ -236,6 +238,13 @@ vfi_rife_t* vfi_rife_create(int arch_ver_x10, const float* const* tensors, const
             std::vector<float> wp, bp;
             pack_deconv4x4(w, bi, c, LO, c, LOp, wp, bp);
             ok = !upload(L.w, wp) && !upload(L.bias, bp);
+            // the same layer as ONE 3x3 convolution with 4 * LO channels on the Winograd kernel (no padding of 24 to a 32-wide N tile)
+            std::vector<float> w3, b3, wq;
+            pack_deconv_as_conv3x3(w, bi, c, LO, w3, b3);
+            L.Cout3_p = round_up(4 * LO, 32);
+            pack_wino3x3(w3.data(), 4 * LO, c, nullptr, c, L.Cout3_p, wq);
+            b3.resize(L.Cout3_p, 0.f);
+            ok = ok && !upload(L.ww, wq) && !upload(L.bias3, b3);
         }
     }
     if (ok) {
@@ -586,8 +595,18 @@ int vfi_rife_interpolate(vfi_rife_t* net, int B, const int* slot0, const int* sl
         fill_args(a, net->last[i], cur, c, net->T.p, 128, B, Hs / 4, Ws / 4, 1);
         a.out_mode = 1;  // PixelShuffle(2) resolved by the epilogue: T is planar4 [B][TP][Hs][Ws][4]
         a.out_planes = TP;
-        deconv4x4_taps(a);
-        if (conv_launch(a, 1, true, -1, st, kLastName[i])) return -1;
+        if (option(kOptDeconvWino) && conv_wino_mode(-1) != 1 && net->last[i].ww.p && c % 8 == 0) {
+            // as a 3x3 stride-1 layer with 4 * LO output channels on the Winograd kernel (conv_wino.hip: pack_deconv_as_conv3x3, SHUF epilogue)
+            conv3x3_taps(a);
+            a.w = net->last[i].ww.p;
+            a.bias = net->last[i].bias3.p;
+            a.Cout = 4 * net->last[i].Cout;
+            a.Cout_p = net->last[i].Cout3_p;
+            if (conv_wino_launch(a, 8, st, kLastName[i])) return -1;
+        } else {
+            deconv4x4_taps(a);
+            if (conv_launch(a, 1, true, -1, st, kLastName[i])) return -1;
+        }
         const float* Tsrc = net->T.p;
         if (u > 1) {  // interpolate(tmp, scale) and flow * scale: back to the frame resolution, then as a scale-1 block
             if (t_down_launch(net->T.p, net->T1.p, B, Hp, Wp, u, TP, st)) return -1;

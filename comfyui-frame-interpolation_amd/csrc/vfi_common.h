@@ -58,6 +58,7 @@ enum Option {
     kOptSplatAtomic,     // 1: force the LDS-atomic splat kernel (default 0: list-gather kernel with the atomic kernel as overflow fallback)
     kOptSplatSpillCap,   // spill-list capacity of the list-gather splat (default -1 = built-in)
     kOptWinoXcd,         // 1: XCD-aware work order of the Winograd kernel (default), 0: plain order
+    kOptDeconvWino,      // 1: ConvTranspose2d(4, 2, 1) + PixelShuffle (RIFE lastconv) as a 96-channel 3x3 layer on the Winograd kernel (default), 0: grouped direct kernel
     kOptEncodeBatched,   // 1: one frame-pack launch for a batch of frames where the caller offers one (default), 0: one launch per frame
     kOptCount
 };
@@ -134,6 +135,7 @@ void conv3x3_taps(ConvArgs& a);
 // logical to physical input channels (nullptr = identity).  Launch: ConvArgs as for the direct kernel with a.w = that pack;
 // variant 0 = pick the region shape, 8 / 16 = 16x8 / 32x4 output pixels per wave.
 void pack_wino3x3(const float* w_oihw, int Cout, int Cin, const int* chan_map, int Cin_p, int Cout_p, std::vector<float>& wp);
+void pack_deconv_as_conv3x3(const float* w_iohw, const float* bias, int Cin, int LO, std::vector<float>& w3, std::vector<float>& b3);
 bool conv_wino_eligible(const ConvArgs& a);
 int conv_wino_mode(int set);      // set < 0: query.  0 automatic, 1 direct kernel only, 2 Winograd wherever legal
 int conv_wino_launch(const ConvArgs& a, int variant, hipStream_t s, const char* trace_name);

@@ -29,10 +29,14 @@ int vfi_test_conv_algo(int mode);
  * [Cout_p/32][Cin_p/8][j][xi/4][half][co%32][xi%4], physical input channel = c8*8 + half*4 + j), written to a HOST buffer: lets the
  * CPU suite check the pack and emulate the kernel's addressing (tests/test_wino_emulation.py).  Returns floats written or < 0. */
 int64_t vfi_test_pack_wino3x3(const float* weight_host, int Cout, int Cin, const int* chan_map, int Cin_p, float* out_host, int64_t cap);
+/* ConvTranspose2d(Cin, LO, 4, 2, 1) rewritten as ONE 3x3 stride-1 pad-1 convolution with 4 * LO output channels (channel g * LO + co =
+ * output parity g = 2 py + px of channel co; csrc/conv_wino.hip: pack_deconv_as_conv3x3 — how the RIFE lastconv runs on the Winograd
+ * kernel): w3_host OIHW [4 * LO][Cin][3][3], b3_host [4 * LO].  Host only.  Returns floats written to w3_host or < 0. */
+int64_t vfi_test_pack_deconv3x3(const float* weight_host, const float* bias_host, int Cin, int LO, float* w3_host, float* b3_host, int64_t cap);
 
 /* A/B options of tools/ and tests/: each selects between two CORRECT forms of a kernel or launch (csrc/vfi_common.h, enum Option):
  *   stage_quad (bit mask, default 14), fuse_encode (1), fuse0a (1), m2n2_px (-1), grouped_variant (-1), splitk (1), splat_atomic (0),
- *   splat_spill_cap (-1), wino_xcd (1), encode_batched (1).
+ *   splat_spill_cap (-1), wino_xcd (1), deconv_wino (1), encode_batched (1).
  * The product library reads NO experiment switch from the environment; this call is the only way to leave the defaults.
  * Returns 0, or -2 for an unknown name. */
 int vfi_test_set_option(const char* name, int64_t value);

@@ -184,16 +184,21 @@ def test_layer_object_winograd_matches_direct_and_torch(lib, act, post, pad_mode
         assert (got - want).abs().max().item() <= tol, describe_diff(got, want, f"mode {mode} act {act}")
 
 
-@pytest.mark.parametrize("gvariant", [None, 12, 13, 43, 44])
+@pytest.mark.parametrize("gvariant", [None, "direct", 12, 13, 43, 44])
 @pytest.mark.parametrize("cin,h,w", [(64, 17, 30), (192, 9, 15), (96, 34, 60)])
 def test_deconv4x4_pixelshuffle(lib, cin, h, w, gvariant):
-    # A/B option grouped_variant forces a tile variant of the transposed convolution (read at every launch)
+    # None: the default form — the layer as a 96-channel 3x3 convolution on the Winograd kernel with the pixel-shuffle epilogue
+    # (A/B option deconv_wino = 1); "direct": the grouped direct kernel (deconv_wino = 0) with its own tile choice; a number: that
+    # tile variant of the grouped kernel forced (A/B option grouped_variant, read at every launch)
     try:
-        if gvariant is not None:
+        if gvariant == "direct":
+            assert lib.vfi_test_set_option(b"deconv_wino", 0) == 0
+        elif gvariant is not None:
             assert lib.vfi_test_set_option(b"grouped_variant", gvariant) == 0
         _deconv_case(lib, cin, h, w)
     finally:
         lib.vfi_test_set_option(b"grouped_variant", -1)
+        lib.vfi_test_set_option(b"deconv_wino", 1)
 
 
 def _deconv_case(lib, cin, h, w):

@@ -211,3 +211,30 @@ def test_work_order_keeps_channel_siblings_on_one_xcd():
     assert len(flat) == NQ and all(len(v) == 1 for v in flat.values())        # all Cout/32 siblings of a quad on one XCD
     counts = [len(lst) for lst in items]
     assert max(counts) - min(counts) <= 2 and sum(counts) == NQ * 2
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# RIFE's lastconv — ConvTranspose2d(c, 24, 4, 2, 1) + PixelShuffle(2) — as ONE 3x3 convolution with 96 output channels
+# (csrc/conv_wino.hip: pack_deconv_as_conv3x3): the host rewrite against torch, on the CPU.
+
+
+@pytest.mark.parametrize("cin,lo,h,w", [(16, 24, 9, 13), (8, 52, 6, 7), (64, 24, 5, 5)])
+def test_deconv_as_conv3x3_equals_conv_transpose(hip_lib, cin, lo, h, w):
+    import torch
+    import torch.nn.functional as F
+
+    g = torch.Generator().manual_seed(cin + lo)
+    wt = (torch.rand(cin, lo, 4, 4, generator=g) * 2 - 1).contiguous()
+    b = (torch.rand(lo, generator=g) - 0.5).contiguous()
+    x = torch.rand(2, cin, h, w, generator=g) * 2 - 1
+    w3 = torch.full((4 * lo, cin, 3, 3), float("nan"))
+    b3 = torch.full((4 * lo,), float("nan"))
+    n = hip_lib.vfi_test_pack_deconv3x3(wt.data_ptr(), b.data_ptr(), cin, lo, w3.data_ptr(), b3.data_ptr(), w3.numel())
+    assert n == w3.numel() and not torch.isnan(w3).any() and not torch.isnan(b3).any()
+    assert (w3 != 0).sum().item() <= 4 * lo * cin * 4               # four of the nine taps per parity group
+    want = F.conv_transpose2d(x.double(), wt.double(), b.double(), 2, 1)      # [2, lo, 2h, 2w]
+    got = F.conv2d(x.double(), w3.double(), b3.double(), padding=1)           # [2, 4 lo, h, w]
+    for gi in range(4):
+        py, px = gi >> 1, gi & 1
+        d = (got[:, gi * lo:(gi + 1) * lo] - want[:, :, py::2, px::2]).abs().max().item()
+        assert d <= 1e-12, (gi, d)
