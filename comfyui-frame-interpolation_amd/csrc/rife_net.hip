@@ -291,7 +291,7 @@ vfi_rife_t* vfi_rife_clone_empty(const vfi_rife_t* src) {
     net->arch = src->arch, net->NF = src->NF, net->CM = src->CM, net->CF = src->CF, net->n_mid = src->n_mid;
     net->nblocks = src->nblocks, net->NX = src->NX, net->enc_act = src->enc_act;
     auto meta = [](ConvLayer& d, const ConvLayer& s_) {
-        d.Cin = s_.Cin, d.Cin_p = s_.Cin_p, d.Cout = s_.Cout, d.Cout_p = s_.Cout_p, d.folded = s_.folded;
+        d.Cin = s_.Cin, d.Cin_p = s_.Cin_p, d.Cout = s_.Cout, d.Cout_p = s_.Cout_p, d.folded = s_.folded, d.Cout3_p = s_.Cout3_p;
     };
     for (int b = 0; b < kMaxBlocks; ++b) {
         meta(net->conv00[b], src->conv00[b]);

@@ -84,11 +84,27 @@ def moved(base, other):
             "blocks_over_pool_mean_tol": int((dm > golden_stats.POOL_MEAN_TOL).sum()), "block_mean_max": float(dm.max())}
 
 
-def outlier_bound(sd, frames, t, eps=9e-6, seeds=(0, 1)):
+def poisson_quantile(lam, q=0.999):
+    """smallest k with P(Poisson(lam) <= k) >= q"""
+    import math
+
+    k, term = 0, math.exp(-lam)
+    cdf = term
+    while cdf < q and k < 100000:
+        k += 1
+        term *= lam / k
+        cdf += term
+    return k
+
+
+def outlier_bound(sd, frames, t, eps=9e-6, seeds=(0, 1, 2)):
     """For ANY M2M checkpoint: the oracle's frame at time t for the pair ``frames`` [2,H,W,3], and how many of ITS pixels move by
     more than 1e-3 when the flows entering its splats are perturbed by a relative ``eps`` (uniform; 9e-6 = the HIP path's measured
-    flow deviation, see the module docstring) — the smallest count over the seeds, and the smallest mean.  Used by
-    tests/test_gpu_real_ckpt.py, where no pre-computed certificate can exist."""
+    flow deviation, see the module docstring).  Such pixels are rare events (a handful per 2 M): the counts over the seeds estimate
+    their RATE, and the bound returned is the 99.9 % quantile of a Poisson variable at the rate's upper estimate
+    (sum of counts + 3) / seeds ("rule of three" for all-zero counts) — a perturbation no larger than the certificate's exceeds it
+    once in a thousand runs.  Returns (oracle frame, bound, counts, largest mean |d|).  Used by tests/test_gpu_real_ckpt.py, where
+    no pre-computed certificate can exist."""
     x = frames[..., :3].permute(0, 3, 1, 2)
     base = run(sd, x, t, plain)
     counts, means = [], []
@@ -96,7 +112,7 @@ def outlier_bound(sd, frames, t, eps=9e-6, seeds=(0, 1)):
         d = np.abs(run(sd, x, t, make_rel(s, eps)) - base)
         counts.append(int((d.max(axis=2) > 1e-3).sum()))
         means.append(float(d.mean()))
-    return torch.from_numpy(base), min(counts), min(means)
+    return torch.from_numpy(base), poisson_quantile((sum(counts) + 3.0) / len(seeds)), counts, max(means)
 
 
 def main():
