@@ -351,10 +351,32 @@ def strong_4k_x4(args, dev, world, rank, backend, group=None):
     else:
         import torch.distributed as dist
 
-        eng = RifeEngine(synth.rife47_synth_state_dict(49), "4.7", device=dev)
+        def agree(err, where):
+            """A rank that fails before a collective would leave the others waiting in it for ever: every local step runs under
+            try, the ranks agree on its outcome (one small all-reduce), and only then go on — or ALL raise."""
+            if world > 1:
+                flag = torch.tensor([0.0 if err is None else 1.0], device=dev if backend == "nccl" else "cpu")
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                if flag.item() > 0:
+                    raise RuntimeError(f"strong_4k_x4: a rank failed in {where} ({type(err).__name__ if err else 'another rank'}: {err})")
+            elif err is not None:
+                raise err
+
+        eng, err0 = None, None
+        try:
+            eng = RifeEngine(synth.rife47_synth_state_dict(49), "4.7", device=dev)
+        except Exception as e:  # noqa: BLE001
+            err0 = e
+        agree(err0, "engine creation")
 
         def once():
-            local = run_tasks(eng, frames, tasks[lo:hi], bs, 1.0, out_device=True)
+            err, local = None, None
+            try:
+                local = run_tasks(eng, frames, tasks[lo:hi], bs, 1.0, out_device=True)
+                torch.cuda.synchronize(dev)
+            except Exception as e:  # noqa: BLE001
+                err = e
+            agree(err, "its block of the task list")
             gathered = all_gather_frames(local, counts) if world > 1 else local
             torch.cuda.synchronize(dev)
             return gathered.shape[0]

@@ -128,11 +128,14 @@ __device__ __forceinline__ f32x2 wino_pk_mul(f32x2 x, f32x2 y) {
 // MODE 10 + act: the general form (residual, any activation of ConvArgs::act, post affine).
 // FULL: the region lies completely inside the image (wave-uniform, true for all but the last row / column of regions): no
 // row branches and no per-store column test (they were ~260 of the epilogue's 1350 instructions).
-// SHUF (MODE 0 only, ConvArgs::out_mode 1): the layer is a ConvTranspose2d(4, 2, 1) + PixelShuffle(2) written as a 3x3 convolution —
-// output channel co = parity group g x LO + cg (pack_deconv_as_conv3x3) — and the epilogue stores straight into the planar4 block
-// output T [n][planes][4H][4W][4]: pixel (4 oy + 2 (g >> 1) + ((cg >> 1) & 1), 4 ox + 2 (g & 1) + (cg & 1)), plane (cg >> 2) >> 2,
-// component (cg >> 2) & 3 — the mapping of conv_mfma2's out_mode 1 epilogue.
-template <int RTX, int MODE, bool FULL = false, bool SHUF = false>
+// SHUF != 0: the layer is a ConvTranspose2d(4, 2, 1) written as a 3x3 convolution — output channel co = parity group g x LO + cg
+// (pack_deconv_as_conv3x3) — and the epilogue puts the parities where they belong:
+//   1 (ConvArgs::out_mode 1, RIFE lastconv): + PixelShuffle(2) into the planar4 block output T [n][planes][4H][4W][4]: pixel
+//     (4 oy + 2 (g >> 1) + ((cg >> 1) & 1), 4 ox + 2 (g & 1) + (cg & 1)), plane (cg >> 2) >> 2, component (cg >> 2) & 3 — the mapping
+//     of conv_mfma2's out_mode 1 epilogue;
+//   2 (out_mode 2, the layer objects of M2M / IFRNet / IFUNet / GMFSS): NHWC [n][2H][2W][out_cs], pixel (2 oy + (g >> 1), 2 ox + (g & 1)),
+//     channel cg.  No residual in either form.
+template <int RTX, int MODE, bool FULL = false, int SHUF = 0>
 __device__ __forceinline__ void wino_epilogue(const f32x16 (&acc)[16], const ConvArgs& a, int n, int oy0, int ox0, int co, int coc, int half, float bs,
                                               float bt, float pre, int LO = 0, float inv_LO = 0.f) {
     const int H = a.Hin, W = a.Win;
@@ -141,8 +144,9 @@ __device__ __forceinline__ void wino_epilogue(const f32x16 (&acc)[16], const Con
     const int planes = a.out_planes ? a.out_planes : 2;
     const int Ws4 = 4 * W;                       // SHUF: T row length in pixels
     const __amdgpu_buffer_rsrc_t orsrc =
-        SHUF ? __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)n * planes * 16 * H * W * 4), 0, planes * 16 * H * W * 16, 0x00020000)
-             : __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)n * H * W * a.out_cs), 0, H * W * a.out_cs * 4, 0x00020000);
+        SHUF == 1 ? __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)n * planes * 16 * H * W * 4), 0, planes * 16 * H * W * 16, 0x00020000)
+        : SHUF == 2 ? __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)n * 4 * H * W * a.out_cs), 0, 4 * H * W * a.out_cs * 4, 0x00020000)
+                    : __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)n * H * W * a.out_cs), 0, H * W * a.out_cs * 4, 0x00020000);
     const bool has_res = MODE >= 10 && a.res != nullptr;
     const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(has_res ? a.res + (size_t)n * H * W * a.res_cs : a.out), 0, has_res ? H * W * a.res_cs * 4 : 0, 0x00020000);
@@ -157,7 +161,8 @@ __device__ __forceinline__ void wino_epilogue(const f32x16 (&acc)[16], const Con
         if (cg < 0) --g, cg += LO;
         if (cg >= LO) ++g, cg -= LO;
         const int c = cg >> 2;
-        lane_o = ((((c >> 2) * 4 * H + 2 * (g >> 1) + ((cg >> 1) & 1)) * Ws4 + 2 * (g & 1) + (cg & 1) + 4 * xlane) * 4 + (c & 3)) * 4;
+        if (SHUF == 1) lane_o = ((((c >> 2) * 4 * H + 2 * (g >> 1) + ((cg >> 1) & 1)) * Ws4 + 2 * (g & 1) + (cg & 1) + 4 * xlane) * 4 + (c & 3)) * 4;
+        else lane_o = (((g >> 1) * 2 * W + (g & 1) + 2 * xlane) * a.out_cs + cg) * 4;
     }
     // Two tiles (accumulator registers r, r + 1 = neighbours in x) per step, in packed fp32: the epilogue's VALU work is not hidden by
     // anything (the wave's MFMAs are over), v_pk_* does two values per instruction in the same order of operations as the scalar form.
@@ -184,7 +189,7 @@ __device__ __forceinline__ void wino_epilogue(const f32x16 (&acc)[16], const Con
         for (int ey = 0; ey < 2; ++ey) {
             const int oy = oy0 + 2 * tyy + ey;          // wave-uniform
             if (FULL || oy < H) {
-                const int rowo = SHUF ? oy * 4 * Ws4 * 16 : oy * W * a.out_cs * 4, rowr = oy * W * a.res_cs * 4;
+                const int rowo = SHUF == 1 ? oy * 4 * Ws4 * 16 : (SHUF == 2 ? oy * 4 * W * a.out_cs * 4 : oy * W * a.out_cs * 4), rowr = oy * W * a.res_cs * 4;
 #pragma unroll
                 for (int ex = 0; ex < 2; ++ex) {
                     f32x2 v2 = wino_pk_mul_hi(wino_pk_add_lo(y[ey * 2 + ex], bsbt), bsbt);
@@ -207,7 +212,7 @@ __device__ __forceinline__ void wino_epilogue(const f32x16 (&acc)[16], const Con
                             else if (MODE == 15) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
                             v = v * ps + sh;
                         }
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orsrc, ok ? lane_o : (int)0x80000000, rowo + (SHUF ? xq * 64 : xq * a.out_cs * 4), 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orsrc, ok ? lane_o : (int)0x80000000, rowo + (SHUF == 1 ? xq * 64 : (SHUF == 2 ? 2 * xq * a.out_cs * 4 : xq * a.out_cs * 4)), 0);
                     }
                 }
             }
@@ -216,7 +221,7 @@ __device__ __forceinline__ void wino_epilogue(const f32x16 (&acc)[16], const Con
     }
 }
 
-template <int RTX, int MODE, bool SHUF = false>
+template <int RTX, int MODE, int SHUF = 0>
 __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr bool EXT = MODE != 0;      // a general epilogue (wino_epilogue's MODE 10 + act): one kernel per activation, no switch in the item loop
@@ -649,7 +654,7 @@ bool conv_wino_eligible(const ConvArgs& a) {
     return regions / 4 * (a.Cout_p / 32) >= 192;
 }
 
-template <int RTX, int MODE, bool SHUF = false>
+template <int RTX, int MODE, int SHUF = 0>
 static int wino_launch_t(WinoArgs& p, hipStream_t s, const char* name) {
     using G = WinoGeom<RTX>;
     ConvArgs& a = p.a;
@@ -684,7 +689,7 @@ static int wino_launch_t(WinoArgs& p, hipStream_t s, const char* name) {
 
 // a.w must point at pack_wino3x3's output (device).  variant: 0 = pick, 8 / 16 = region shape (tiles per row)
 int conv_wino_launch(const ConvArgs& a, int variant, hipStream_t s, const char* name) {
-    VFI_REQUIRE(a.ntaps == 9 && a.Hout == a.Hin && a.Wout == a.Win && !a.in_plane && (a.out_mode == 0 || a.out_mode == 1),
+    VFI_REQUIRE(a.ntaps == 9 && a.Hout == a.Hin && a.Wout == a.Win && !a.in_plane && a.out_mode >= 0 && a.out_mode <= 2,
                 "conv_wino %s: 3x3 stride-1 NHWC layers only", name);
     VFI_REQUIRE(a.Cin_p % 8 == 0 && a.Cout_p % 32 == 0 && a.Cout_p <= 1024 && a.in_cs >= a.Cin_p && a.in_cs % 4 == 0, "conv_wino %s: bad channel padding Cin_p=%d Cout_p=%d in_cs=%d",
                 name, a.Cin_p, a.Cout_p, a.in_cs);
@@ -702,7 +707,7 @@ int conv_wino_launch(const ConvArgs& a, int variant, hipStream_t s, const char* 
         variant = e16 > e8 * 1.15 ? 16 : 8;
     }
     VFI_REQUIRE(variant == 8 || variant == 16, "conv_wino %s: bad variant %d", name, variant);
-    VFI_REQUIRE((a.out_mode == 1 || (long)a.Hin * a.Win * a.out_cs * 4 < 0x7fffffffL) && (!a.res || (long)a.Hin * a.Win * a.res_cs * 4 < 0x7fffffffL),
+    VFI_REQUIRE((a.out_mode == 1 || (long)a.Hin * a.Win * a.out_cs * 4 * (a.out_mode == 2 ? 4 : 1) < 0x7fffffffL) && (!a.res || (long)a.Hin * a.Win * a.res_cs * 4 < 0x7fffffffL),
                 "conv_wino %s: output / residual image larger than 2 GiB", name);
     // the hot epilogue: no residual, no post affine, none / LeakyReLU with a slope in [0,1]
     const bool ext = a.res != nullptr || a.post_scale != 0.f || !(a.act == 0 || (a.act == 1 && a.slope >= 0.f && a.slope <= 1.f));
@@ -711,7 +716,13 @@ int conv_wino_launch(const ConvArgs& a, int variant, hipStream_t s, const char* 
     if (a.out_mode == 1) {      // transposed convolution + PixelShuffle as a 3x3 layer (pack_deconv_as_conv3x3): hot epilogue, 16x8 regions
         VFI_REQUIRE(!ext && a.Cout % 4 == 0 && a.act == 0 && !a.beta, "conv_wino %s: the pixel-shuffle output takes the plain epilogue (bias only)", name);
         VFI_REQUIRE((long)(a.out_planes ? a.out_planes : 2) * 16 * a.Hin * a.Win * 16 < 0x7fffffffL, "conv_wino %s: block output larger than 2 GiB", name);
-        return wino_launch_t<8, 0, true>(p, s, name);
+        return wino_launch_t<8, 0, 1>(p, s, name);
+    }
+    if (a.out_mode == 2) {      // transposed convolution of a layer object as a 3x3 layer: parities interleaved into NHWC at twice the resolution
+        // (hot epilogue only: with the general epilogue — per-channel PReLU, IFUNet's decoders — the form measured SLOWER than the grouped
+        // direct kernel, 3.2 vs 2.5 ms per IFUNet frame: two spilled registers in an epilogue that already carries the parity addressing)
+        VFI_REQUIRE(!a.res && a.Cout % 4 == 0 && mode == 0, "conv_wino %s: the transposed-convolution form takes none / LeakyReLU only", name);
+        return wino_launch_t<8, 0, 2>(p, s, name);
     }
 #define WINO_DISPATCH(R_)                                              \
     switch (mode) {                                                    \

@@ -157,6 +157,11 @@ struct vfi_conv {
     float* ww = nullptr;     // Winograd F(2x2,3x3) pack of a 3x3 stride-1 layer (conv_wino.hip), next to the direct kernel's
     float* bias = nullptr;
     float* prelu = nullptr;  // per-channel PReLU slopes [Cout_p] (optional)
+    // ConvTranspose2d(4, 2, 1) as ONE 3x3 layer with 4 * Cout channels on the Winograd kernel (conv_wino.hip: pack_deconv_as_conv3x3):
+    // ww holds that pack, bias3 the bias repeated per parity group (none / LeakyReLU layers take this form; per-channel PReLU stays
+    // on the grouped direct kernel)
+    float* bias3 = nullptr;
+    int Cout3_p = 0;
     int Cout = 0, Cout_p = 0, Cin = 0, Cin_p = 0, kh = 0, kw = 0, taps = 0;
     int stride = 1, pad_mode = 0, kind = 0;  // kind 0: Conv2d, 1: ConvTranspose2d(4, 2, 1)
 };
@@ -233,6 +238,7 @@ void vfi_conv_destroy(vfi_conv_t* c) {
     if (c->ww) (void)hipFree(c->ww);
     if (c->bias) (void)hipFree(c->bias);
     if (c->prelu) (void)hipFree(c->prelu);
+    if (c->bias3) (void)hipFree(c->bias3);
     delete c;
 }
 
@@ -298,6 +304,14 @@ vfi_conv_t* vfi_conv_create_ex(int kind, const float* w_host, const float* bias_
         for (int co = 0; co < Cout; ++co) pp[co] = prelu_host[co];
         ok = upload(&c->prelu, pp);
     }
+    if (ok && kind == 1 && 4 * Cout <= 1024) {
+        std::vector<float> w3, b3, ww;
+        pack_deconv_as_conv3x3(w_host, bias_host, Cin, Cout, w3, b3);
+        c->Cout3_p = round_up(4 * Cout, 32);
+        pack_wino3x3(w3.data(), 4 * Cout, Cin, chan_map, Cin_phys, c->Cout3_p, ww);
+        b3.resize(c->Cout3_p, 0.f);
+        ok = upload(&c->ww, ww) && upload(&c->bias3, b3);
+    }
     if (!ok) {
         set_error("vfi_conv_create_ex: device allocation/upload failed");
         vfi_conv_destroy(c);
@@ -359,6 +373,20 @@ int vfi_conv_forward_ex(const vfi_conv_t* c, const float* in_dev, int in_cs, int
     if (c->ww && c->kind == 0 && c->stride == 1 && conv_wino_eligible(a)) {
         a.w = c->ww;
         return conv_wino_launch(a, 0, (hipStream_t)stream, it->second);
+    }
+    if (c->ww && c->kind == 1 && option(kOptDeconvWino) && conv_wino_mode(-1) != 1 && !c->pad_mode && post_scale == 0.f &&
+        (act == 0 || (act == 1 && slope >= 0.f && slope <= 1.f))) {
+        // the transposed convolution as one 3x3 layer with 4 * Cout channels (no padding of Cout to a 32-wide N tile per parity group);
+        // chosen from the image, never from the batch
+        ConvArgs b = a;
+        conv3x3_taps(b);
+        b.w = c->ww;
+        b.bias = c->bias3;
+        b.Cout = 4 * c->Cout;
+        b.Cout_p = c->Cout3_p;
+        const long regions = 2L * cdiv(Hin, 8) * cdiv(Win, 16);
+        if (regions / 4 * (b.Cout_p / 32) >= 192 && (long)4 * Hin * Win * out_cs * 4 < 0x7fffffffL && (long)Hin * Win * in_cs * 4 < 0x7fffffffL)
+            return conv_wino_launch(b, 8, (hipStream_t)stream, it->second);
     }
     return conv_launch(a, c->kind == 1 ? 1 : c->stride, c->kind == 1, -1, (hipStream_t)stream, it->second);
 }

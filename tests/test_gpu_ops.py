@@ -184,6 +184,49 @@ def test_layer_object_winograd_matches_direct_and_torch(lib, act, post, pad_mode
         assert (got - want).abs().max().item() <= tol, describe_diff(got, want, f"mode {mode} act {act}")
 
 
+@pytest.mark.parametrize("act", [0, 1, 3])
+@pytest.mark.parametrize("cin,cout,n,h,w", [(64, 16, 2, 40, 56), (24, 32, 1, 33, 70), (128, 32, 2, 17, 30), (256, 64, 1, 34, 60)])
+def test_layer_object_deconv_winograd_matches_direct_and_torch(lib, act, cin, cout, n, h, w):
+    """vfi_conv_create_ex(kind = 1): ConvTranspose2d(4, 2, 1) of the layer objects (M2M / IFRNet / IFUNet / GMFSS decoders) in both forms —
+    the grouped direct kernel (A/B option deconv_wino = 0) and ONE 3x3 layer with 4 * Cout channels on the Winograd kernel whose
+    epilogue interleaves the parities into NHWC at twice the resolution (default) — vs torch: none / LeakyReLU / per-channel PReLU,
+    a channel window on both sides, odd sizes (partial regions), small layers that stay on the direct kernel by size."""
+    g = torch.Generator().manual_seed(cin + cout + act)
+    x = torch.rand(n, cin, h, w, generator=g) * 2 - 1
+    wt = ((torch.rand(cin, cout, 4, 4, generator=g) * 2 - 1) / (cin * 4) ** 0.5).contiguous()
+    b = (torch.rand(cout, generator=g) - 0.5).contiguous()
+    slopes = (0.1 + 0.3 * torch.rand(cout, generator=g)).contiguous()
+    y = F.conv_transpose2d(x.double(), wt.double(), b.double(), 2, 1)
+    if act == 1:
+        y = F.leaky_relu(y, 0.25)
+    elif act == 3:
+        y = torch.where(y > 0, y, y * slopes.double().view(1, -1, 1, 1))
+    want = nhwc(y.float())
+    xin = torch.rand(n, h, w, cin + 8, generator=g)
+    xin[..., 4:4 + cin] = x.permute(0, 2, 3, 1)
+    xd = xin.cuda()
+    hnd = lib.vfi_conv_create_ex(1, wt.data_ptr(), b.data_ptr(), cout, cin, 4, 2, 0, None, cin, slopes.data_ptr() if act == 3 else None)
+    assert hnd, "create failed"
+    outs = {}
+    try:
+        for form in (1, 0):
+            assert lib.vfi_test_set_option(b"deconv_wino", form) == 0
+            out = torch.full((n, 2 * h, 2 * w, cout + 5), float("nan"), device="cuda")
+            _check(lib, lib.vfi_conv_forward_ex(hnd, xd.data_ptr() + 16, cin + 8, h, w, out.data_ptr() + 12, cout + 5, n, act, 0.25, 0.0, 0.0, None, 0, None),
+                   "conv_forward_ex")
+            torch.cuda.synchronize()
+            got = out.cpu()
+            assert torch.isnan(got[..., :3]).all() and torch.isnan(got[..., 3 + cout:]).all(), "wrote outside its channel window"
+            outs[form] = got[..., 3:3 + cout]
+    finally:
+        lib.vfi_test_set_option(b"deconv_wino", 1)
+        lib.vfi_conv_destroy(hnd)
+    tol = 2e-5 * max(1.0, want.abs().max().item())
+    for form, got in outs.items():
+        assert not torch.isnan(got).any(), f"deconv_wino={form}: unwritten outputs"
+        assert (got - want).abs().max().item() <= tol, describe_diff(got, want, f"deconv_wino={form} act {act}")
+
+
 @pytest.mark.parametrize("gvariant", [None, "direct", 12, 13, 43, 44])
 @pytest.mark.parametrize("cin,h,w", [(64, 17, 30), (192, 9, 15), (96, 34, 60)])
 def test_deconv4x4_pixelshuffle(lib, cin, h, w, gvariant):
