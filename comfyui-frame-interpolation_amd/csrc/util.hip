@@ -137,6 +137,20 @@ int vfi_device_info(char* arch_buf, int arch_buf_len, int* n_cus) {
     return 0;
 }
 
+int vfi_memcpy_async(void* dst, const void* src, int64_t bytes, int kind, void* stream) {
+    VFI_REQUIRE(dst && src && bytes >= 0 && (kind == 1 || kind == 2 || kind == 3), "vfi_memcpy_async: bad arguments (kind %d)", kind);
+    if (bytes == 0) return 0;
+    if (stream) {       // worker threads never chose a device: the copy must be issued with the stream's device current
+        hipDevice_t sdev = 0;
+        int cur = 0;
+        if (hipStreamGetDevice((hipStream_t)stream, &sdev) == hipSuccess && hipGetDevice(&cur) == hipSuccess && cur != (int)sdev) VFI_CHECK_HIP(hipSetDevice((int)sdev));
+        (void)hipGetLastError();
+    }
+    VFI_CHECK_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, kind == 1 ? hipMemcpyHostToDevice : (kind == 2 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice),
+                                 (hipStream_t)stream));
+    return 0;
+}
+
 int vfi_test_set_option(const char* name, int64_t value) { return option_set(name, (long)value); }
 int vfi_test_variant_override(const char* spec) {
     variant_override_set(spec);

@@ -76,6 +76,27 @@ def host_copy(dst, src):
         dst.copy_(src)
 
 
+def _events(n, stream):
+    """n events whose native handles already exist (torch creates them at the first record): made BEFORE the output tensor's first
+    touch starts — while 8 threads populate pages, anything in the process that maps memory (event creation does) queues behind them:
+    the first copy-back of a call took 4.5 ms instead of 0.5."""
+    evs = [torch.cuda.Event() for _ in range(n)]
+    for e in evs:
+        e.record(stream)
+    return evs
+
+
+def _memcpy_async(dst, src, kind, stream):
+    """dst.copy_(src, non_blocking=True) between a pinned host tensor and a device tensor (same dtype, both contiguous) as ONE
+    hipMemcpyAsync through the library (vfi_memcpy_async): torch's copy_ holds the interpreter lock through its dispatch and
+    queries the pointers' attributes — 0.6-2.7 ms per call beside 25 worker threads, on the launch loop's critical path."""
+    assert dst.is_contiguous() and src.is_contiguous() and dst.dtype == src.dtype and dst.numel() == src.numel()
+    from . import _lib
+
+    _lib.check(_lib.load().vfi_memcpy_async(dst.data_ptr(), src.data_ptr(), dst.numel() * dst.element_size(), kind, ctypes.c_void_p(stream.cuda_stream)),
+               "vfi_memcpy_async")
+
+
 def _pool(name, n):
     if name not in _pools:
         _pools[name] = ThreadPoolExecutor(max_workers=n, thread_name_prefix="vfi-" + name)
@@ -141,6 +162,10 @@ class Uploader:
         self.stream = torch.cuda.Stream(device)
         self.freed = [threading.Event() for _ in self.order]      # slot of item i may be overwritten
         self.consumed = [None] * len(self.order)                  # cuda event: main stream finished reading item i
+        # (an item's events are dead once item i + depth has been staged: a ring of 4 * depth serves clips of any length)
+        self._ne = max(1, min(len(self.order), 4 * depth))
+        self._ev_up = _events(self._ne, self.stream)              # H2D of item i done
+        self._ev_cons = _events(self._ne, main)                   # main stream has consumed item i
         pool = _pool(f"up{device}", workers)
         self.futs = [pool.submit(self._stage, i) for i in range(len(self.order))]
 
@@ -161,9 +186,9 @@ class Uploader:
             if fire:
                 cb, self._on_staged = self._on_staged, None
                 cb()
-        ev = torch.cuda.Event()
-        with _T("up.enqueue_h2d"), torch.cuda.stream(self.stream):
-            self.dev[s].copy_(self.host[s], non_blocking=True)
+        ev = self._ev_up[i % self._ne]
+        with _T("up.enqueue_h2d"):
+            _memcpy_async(self.dev[s], self.host[s], 1, self.stream)
             ev.record(self.stream)
         return ev
 
@@ -178,7 +203,7 @@ class Uploader:
         return self.dev[i % self.depth]
 
     def release(self, i):
-        ev = torch.cuda.Event()
+        ev = self._ev_cons[i % self._ne]
         ev.record(self.main)
         self.consumed[i] = ev
         self.freed[i].set()
@@ -211,6 +236,7 @@ class Downloader:
         self.stream = torch.cuda.Stream(device)
         self.pool = _pool(f"down{device}", workers)
         self.workers = workers
+        self._ev = _events(depth, self.stream)                    # one per staging slot (a slot's previous copy has been drained before reuse)
         self.slot_fut = [None] * depth
         self.n = 0
         self.futs = []
@@ -239,8 +265,8 @@ class Downloader:
                     with _T("main.wait_down_slot"):
                         for f in self.slot_fut[s]:
                             f.result()                 # slot still being drained by a worker
-                self.host[s].copy_(dev_frames[i], non_blocking=True)
-                ev = torch.cuda.Event()
+                _memcpy_async(self.host[s], dev_frames[i], 2, self.stream)
+                ev = self._ev[s]
                 ev.record(self.stream)
                 fs = [self.pool.submit(self._finish, ev, s, dst, part, nparts) for part in range(nparts)]
                 self.slot_fut[s] = fs

@@ -432,6 +432,12 @@ int vfi_rife_interpolate(vfi_rife_t* net, int B, const int* slot0, const int* sl
 int vfi_rife_run(vfi_rife_t* net, const float* frames_host, int N, int H, int W, int C, const int* multipliers,
                  const uint8_t* skip, float scale_factor, int batch, float* out_host, int64_t* n_out);
 
+/* Host pipeline helper: hipMemcpyAsync(dst, src, bytes, kind, stream) with kind 1 = host -> device, 2 = device -> host, 3 = device ->
+ * device; host memory should be pinned (pageable memory makes the call synchronous).  What the node's frame uploads / downloads
+ * (`frames.to(device)` / `.cpu()`, rife/__init__.py:195-207,225-230) become: issued from worker threads without the framework's
+ * per-copy dispatch (which holds the interpreter lock and queries pointer attributes: 0.6-2.7 ms per call under load, measured). */
+int vfi_memcpy_async(void* dst, const void* src, int64_t bytes, int kind, void* stream);
+
 /* Work done by one interpolate call for roofline accounting (algorithmic, per task). */
 int vfi_rife_work(vfi_rife_t* net, double* conv_flop_per_task, double* hbm_bytes_per_task);
 
