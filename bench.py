@@ -703,6 +703,24 @@ def result_line(args, world, elapsed, traced, rep, eng, collective):
     }
 
 
+def extras_watchdog(res, rank, deadline_s):
+    """Timer for the legs AFTER the timed region of a multi-process run: when it fires, rank 0 prints the headline line it
+    already holds (plus a note saying which legs are missing) and every rank leaves with os._exit — the only exit that works
+    while the main thread sits inside a collective."""
+    import threading
+
+    def bail():
+        if rank == 0 and res is not None:
+            res.setdefault("notes", []).append(f"legs after the timed region did not finish within {deadline_s:.0f} s; line printed by the watchdog")
+            print(json.dumps(res), flush=True)
+        os._exit(0)
+
+    t = threading.Timer(deadline_s + (0.0 if rank == 0 else 5.0), bail)   # rank 0 first, so its line is out before peers drop
+    t.daemon = True
+    t.start()
+    return t
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -716,6 +734,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the FILM / M2M device-resident numbers")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather of new frames")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling 4K x4 leg (BASELINE configs[3])")
+    ap.add_argument("--extras-deadline", type=float, default=420.0,
+                    help="multi-process runs: seconds the legs after the timed region may take before the headline line is printed without them")
     ap.add_argument("--strong-height", type=int, default=2160)
     ap.add_argument("--strong-width", type=int, default=3840)
     ap.add_argument("--strong-frames", type=int, default=17)
@@ -832,28 +852,35 @@ def main():
     rep = _lib.trace_report()
     lib.vfi_trace_reset()
 
-    strong = None
-    if not args.no_strong:       # every rank takes part (strong scaling over the ranks); failures never take the headline line down
-        try:
-            strong = strong_4k_x4(args, dev, world, rank, args.backend)
-        except Exception as e:
-            strong = {"error": f"{type(e).__name__}: {e}"}
-    dist_extras = None
-    if world > 1 and not args.no_extras:
-        eng.release() if hasattr(eng, "release") else None
-        try:
-            dist_extras = other_paths_dist(dev, H, W, world, rank, args.backend)
-        except Exception as e:      # never lose the headline line to the extra legs
-            dist_extras = {"error": f"{type(e).__name__}: {e}"}
+    res = None
     if rank == 0:
         res = result_line(args, world, elapsed, traced, rep, eng,
                           "none" if world == 1 or args.no_gather else
                           ("all_gather(RCCL), overlapped" if gathered is not None else "all_gather(gloo, host)"))
         res["config"]["launch"] = "one process per GPU (torch.distributed)" if world > 1 else "one process, one GPU"
-        if strong is not None:
+    # The headline is measured; every later leg is extra.  A leg that RAISES is recorded as an error string; a leg that STALLS
+    # (a collective whose peer died) cannot be recovered from inside the process, so a watchdog prints the headline line as it
+    # stands and ends the rank instead of losing it to the launcher's timeout.
+    guard = extras_watchdog(res, rank, args.extras_deadline) if world > 1 else None
+    strong = None
+    if not args.no_strong:       # every rank takes part (strong scaling over the ranks)
+        try:
+            strong = strong_4k_x4(args, dev, world, rank, args.backend)
+        except Exception as e:
+            strong = {"error": f"{type(e).__name__}: {e}"}
+        if rank == 0:
             res["strong_4k_x4"] = strong
-        if dist_extras is not None:
+    if world > 1 and not args.no_extras:
+        eng.release() if hasattr(eng, "release") else None
+        try:
+            dist_extras = other_paths_dist(dev, H, W, world, rank, args.backend)
+        except Exception as e:
+            dist_extras = {"error": f"{type(e).__name__}: {e}"}
+        if rank == 0:
             res["other_paths"] = dist_extras
+    if guard is not None:
+        guard.cancel()
+    if rank == 0:
         if world == 1:
             eng.close()
             if not args.no_e2e:
