@@ -13,6 +13,7 @@ Differences that do not change results:
     rounds the clip to that dtype on the way in and returns the IMAGE tensor in it, like the reference,
     but computes in float32 (the parity contract is fp32, |d| <= 1e-3).
 """
+import contextlib
 import ctypes as C
 import os
 import threading
@@ -250,6 +251,30 @@ def _pick_loads(order, item, need_set, slots, ready, depth):
 
 # (ckpt_name) -> RifeEngine; the reference caches by (ckpt, dtype, torch_compile), rife/__init__.py:31
 _model_cache: typing.Dict[typing.Tuple, RifeEngine] = {}
+
+
+_switch_lock, _switch_users, _switch_saved = threading.Lock(), 0, None
+
+
+@contextlib.contextmanager
+def _short_switch_interval(seconds=2e-4):
+    """sys.setswitchinterval is process-wide: the first caller in saves the interpreter's value, the last one out restores it (two
+    host threads running the node at once must not leave the process on the short interval for good)."""
+    global _switch_users, _switch_saved
+    import sys
+
+    with _switch_lock:
+        if _switch_users == 0:
+            _switch_saved = sys.getswitchinterval()
+            sys.setswitchinterval(seconds)
+        _switch_users += 1
+    try:
+        yield
+    finally:
+        with _switch_lock:
+            _switch_users -= 1
+            if _switch_users == 0:
+                sys.setswitchinterval(_switch_saved)
 
 
 def run_tasks(engine, frames_cpu, tasks, batch_size, scale_factor=1.0, out_device=False, out=None, out_rows=None, on_staged=None):
@@ -555,13 +580,8 @@ class RIFE_VFI:
             # ~25 worker threads move frames while this thread feeds the GPU: at CPython's default 5 ms switch interval a thread that
             # wants the GIL can wait that long for it — the launch loop lost 10 ms between two launches that way
             # (profiles/r04_e2e_timeline.txt)
-            import sys
-            switch = sys.getswitchinterval()
-            sys.setswitchinterval(2e-4)
-            try:
+            with _short_switch_interval():
                 run_tasks(engine, frames, tasks, batch_size, scale_factor, out=out, out_rows=new_rows, on_staged=start_host_side)
-            finally:
-                sys.setswitchinterval(switch)
             start_host_side()
         from .hostpipe import _T
         with _T("main.wait_pass"):

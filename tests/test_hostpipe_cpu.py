@@ -41,3 +41,33 @@ def test_copy_rows_async_matches_index_copy():
     for r, j in zip(rows, idx):
         assert torch.equal(out[r], frames[j][..., :3])
     assert float(out[1::2].abs().sum()) == 0.0
+
+
+def test_short_switch_interval_is_reentrant_across_threads():
+    """rife._short_switch_interval: the first thread in saves the interpreter's switch interval, the last one out restores it."""
+    import sys
+    import threading
+    from cfi_amd import rife
+
+    before = sys.getswitchinterval()
+    inside, leave = threading.Barrier(3, timeout=30), threading.Event()
+    seen = []
+
+    def user():
+        with rife._short_switch_interval(1e-4):
+            seen.append(sys.getswitchinterval())
+            inside.wait()
+            leave.wait(30)
+
+    ts = [threading.Thread(target=user, daemon=True) for _ in range(2)]
+    for t in ts:
+        t.start()
+    try:
+        inside.wait()
+        during = sys.getswitchinterval()
+    finally:
+        leave.set()
+    for t in ts:
+        t.join(30)
+    assert len(seen) == 2 and all(abs(x - 1e-4) < 1e-6 for x in seen + [during])
+    assert sys.getswitchinterval() == before
