@@ -1188,6 +1188,11 @@ __global__ __launch_bounds__(F0_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         const float* P1 = Ppool + (size_t)tasks.slot1[b] * pack_stride;
         const float tstep = tasks.t[b];
         // ---- phase A: the X patch (stage_trans_kernel<1, true, 1> per pixel)
+        // Raised issue priority: the CU's other workgroup is usually in phase B, and an fp32 MFMA keeps every VALU instruction of its
+        // SIMD out for 64 cycles — at equal priority this phase's address arithmetic (hence its loads) only trickles out between them.
+        // With priority the loads leave early and the MFMAs fill the wait (3.48 -> 3.32 ms per launch together with the fragment
+        // addressing below; profiles/r04_trans1_conv0a_phases.txt).
+        __builtin_amdgcn_s_setprio(3);
 #pragma unroll 1
         for (int it = 0; it < 2; ++it) {
             const int p = tid + F0_THREADS * it;
@@ -1218,23 +1223,38 @@ __global__ __launch_bounds__(F0_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 #pragma unroll
             for (int q = 0; q < 5; ++q) *(float4*)(d + 4 * q) = make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
         }
+        __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         // ---- phase B: 128 output pixels x 32 channels, K = 9 taps x 24 channels; this wave: K-steps [14 khalf, 14 khalf + 14)
         f32x16_t acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        {
+            // Fragment addresses = ONE opaque byte base per operand + compile-time offsets (the ds_read_b128 offset field).  Left to
+            // itself hipcc hoists the 27 + 27 per-step addresses out of the tile loop and keeps them in 28 VGPRs through phase A
+            // (128-register budget: 2 spilled; now 102, none).  khalf is wave-uniform: each half is its own straight-line code.
+            int ab = abase * 4, bb = bbase * 4;
+            asm volatile("" : "+v"(ab), "+v"(bb));
+            const char* const ap = (const char*)lds + ab;
+            const char* const bp = (const char*)wl + bb;
+            auto steps = [&](auto KH) {
+                constexpr int kh = decltype(KH)::value;
 #pragma unroll
-        for (int k = 0; k < 14; ++k) {
-            const int st = khalf * 14 + k;
-            if (st < 27) {
-                const int t = st / 3, c8 = st - 3 * t;
-                const int toff = ((t / 3) * F0_TWI + (t % 3)) * F0_S;
-                const f32x4_t av = *(const f32x4_t*)&lds[abase + toff + c8 * 8];
-                const f32x4_t bv = *(const f32x4_t*)&wl[st * 256 + bbase];
+                for (int k = 0; k < 14; ++k) {
+                    const int st = kh * 14 + k;
+                    if (st < 27) {
+                        const int t = st / 3, c8 = st - 3 * t;
+                        const int toff = ((t / 3) * F0_TWI + (t % 3)) * F0_S;
+                        const f32x4_t av = *(const f32x4_t*)(ap + (toff + c8 * 8) * 4);
+                        const f32x4_t bv = *(const f32x4_t*)(bp + st * 1024);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
-            }
-            if (k & 1) __builtin_amdgcn_sched_barrier(0);    // at most two steps' fragments in flight (register budget: 128)
+                        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
+                    }
+                    if (k & 1) __builtin_amdgcn_sched_barrier(0);    // at most two steps' fragments in flight
+                }
+            };
+            if (khalf) steps(std::integral_constant<int, 1>{});
+            else steps(std::integral_constant<int, 0>{});
         }
         __syncthreads();   // the patch is consumed: its LDS now carries the upper K-half's partial sums
         f32x16_t* red = (f32x16_t*)lds;
@@ -1243,8 +1263,10 @@ __global__ __launch_bounds__(F0_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         if (!khalf) {
             const f32x16_t other = red[sub * 64 + lane];
             // ---- epilogue: + bias, LeakyReLU, NHWC store (32 lanes = 128 contiguous bytes per pixel)
-            const int oy0 = Y0 + sy * 4, ox0 = X0 + sx * 8 + 4 * half;
-            float* ob = A0 + ((size_t)(b * Ho + oy0) * Wo + ox0) * 32 + l31;
+            int ot = tid;                     // lane part of the store address re-derived here: hoisted out of the tile loop it is one
+            asm volatile("" : "+v"(ot));      // more 64-bit value live through phase A
+            const int oy0 = Y0 + sy * 4, ox0 = X0 + sx * 8 + 4 * ((ot >> 5) & 1);
+            float* ob = A0 + ((size_t)(b * Ho + oy0) * Wo + ox0) * 32 + (ot & 31);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const float v = (acc[i] + other[i]) + bs;
