@@ -97,6 +97,20 @@ def _memcpy_async(dst, src, kind, stream):
                "vfi_memcpy_async")
 
 
+_stream_cache = {}
+
+
+def _stream(device, role):
+    """The pipeline's copy streams, made once per (device, role) and reused by every call: torch hands out side streams from a pool
+    round-robin and the HIP runtime maps streams onto a handful of hardware queues, so a stream made per call shared a queue with
+    the compute stream in every other call — its copies then queued behind the kernels (node calls alternated 53 / 63 ms)."""
+    key = (str(device), role)
+    st = _stream_cache.get(key)
+    if st is None:
+        st = _stream_cache[key] = torch.cuda.Stream(device)
+    return st
+
+
 def _pool(name, n):
     if name not in _pools:
         _pools[name] = ThreadPoolExecutor(max_workers=n, thread_name_prefix="vfi-" + name)
@@ -159,7 +173,7 @@ class Uploader:
         self.depth = depth
         self.rings = _rings_grow(_rings_acquire(device, (H, W, 3), frames.dtype, "up"), device, (H, W, 3), depth, 0)   # fp32 or uint8 clips
         self.host, self.dev = self.rings["up_host"][:depth], self.rings["up_dev"][:depth]
-        self.stream = torch.cuda.Stream(device)
+        self.stream = _stream(device, "up")
         self.freed = [threading.Event() for _ in self.order]      # slot of item i may be overwritten
         self.consumed = [None] * len(self.order)                  # cuda event: main stream finished reading item i
         # (an item's events are dead once item i + depth has been staged: a ring of 4 * depth serves clips of any length)
@@ -233,7 +247,7 @@ class Downloader:
         self.device, self.main, self.depth = device, main, depth
         self.rings = _rings_grow(_rings_acquire(device, shape, dtype, "down"), device, shape, 0, depth)
         self.host = self.rings["down_host"][:depth]
-        self.stream = torch.cuda.Stream(device)
+        self.stream = _stream(device, "down")
         self.pool = _pool(f"down{device}", workers)
         self.workers = workers
         self._ev = _events(depth, self.stream)                    # one per staging slot (a slot's previous copy has been drained before reuse)
