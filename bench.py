@@ -118,7 +118,7 @@ def pcie_rates(dev, nbytes=256 << 20):
     return out
 
 
-def e2e_leg(sd, dev, H, W, n_frames=33, reps=3):
+def e2e_leg(sd, dev, H, W, n_frames=33, reps=5):
     """SURVEY 8(d) config 2 through the drop-in node: host clip in, host tensor out, wall clock."""
     import tempfile
 
