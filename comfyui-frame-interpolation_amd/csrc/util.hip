@@ -143,8 +143,10 @@ int vfi_memcpy_async(void* dst, const void* src, int64_t bytes, int kind, void* 
     if (stream) {       // worker threads never chose a device: the copy must be issued with the stream's device current
         hipDevice_t sdev = 0;
         int cur = 0;
-        if (hipStreamGetDevice((hipStream_t)stream, &sdev) == hipSuccess && hipGetDevice(&cur) == hipSuccess && cur != (int)sdev) VFI_CHECK_HIP(hipSetDevice((int)sdev));
-        (void)hipGetLastError();
+        if (hipStreamGetDevice((hipStream_t)stream, &sdev) != hipSuccess || hipGetDevice(&cur) != hipSuccess)
+            (void)hipGetLastError();      // (only these queries' own failure is read away: the copy below then reports what is wrong with the stream)
+        else if (cur != (int)sdev)
+            VFI_CHECK_HIP(hipSetDevice((int)sdev));
     }
     VFI_CHECK_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, kind == 1 ? hipMemcpyHostToDevice : (kind == 2 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice),
                                  (hipStream_t)stream));
