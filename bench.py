@@ -484,6 +484,15 @@ def main_single_process(args):
     devices = list(range(N))
     sd = synth.rife47_synth_state_dict(1234)
     torch.cuda.set_device(0)
+    reserve = 0
+    if N > 1 and not args.no_gather and args.reserve_cus > 0 and _lib.load().vfi_comm_all_gather_mode() == 1:
+        # (RCCL is bound at the first communicator: the cap must be in the environment before it; see main() for the reasoning)
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(args.reserve_cus))
+        try:
+            reserve = max(0, int(os.environ["NCCL_MAX_NCHANNELS"]))
+        except ValueError:
+            reserve = args.reserve_cus
+        _lib.check(_lib.load().vfi_set_reserved_cus(reserve), "vfi_set_reserved_cus")
     group = multidev.RifeDeviceGroup(sd, "4.7", devices)
     comm = group.comm if group.comm is not None else multidev.Comm(devices)      # N = 1: the degenerate clique, same calls
     gather = not args.no_gather
@@ -578,6 +587,8 @@ def main_single_process(args):
     mode = "RCCL grouped per-root broadcasts" if lib.vfi_comm_all_gather_mode() == 1 else "direct peer copies, one per ordered device pair"
     res = result_line(args, N, elapsed, traced, rep, eng0, f"all_gather_v ({mode}; in place, comm streams), overlapped" if gather else "none")
     res["config"]["launch"] = f"one process, {N} device thread(s) (multidev.py; weights broadcast over RCCL)"
+    res["config"]["reserved_cus"] = reserve
+    _lib.load().vfi_set_reserved_cus(0)
     if not args.no_strong:
         try:
             res["strong_4k_x4"] = strong_4k_x4(args, torch.device("cuda", 0), N, 0, "nccl", group=group)
@@ -734,6 +745,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the FILM / M2M device-resident numbers")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather of new frames")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling 4K x4 leg (BASELINE configs[3])")
+    ap.add_argument("--reserve-cus", type=int, default=16,
+                    help="N>1 over RCCL: compute units the persistent kernels leave to the overlapped all-gather's kernel (also caps "
+                         "RCCL's channels to the same number unless NCCL_MAX_NCHANNELS is set); 0 = none")
     ap.add_argument("--extras-deadline", type=float, default=420.0,
                     help="multi-process runs: seconds the legs after the timed region may take before the headline line is printed without them")
     ap.add_argument("--strong-height", type=int, default=2160)
@@ -761,6 +775,17 @@ def main():
 
     import torch.distributed as dist
 
+    # The new-frame all-gather overlaps the next step's kernels.  RCCL's kernel stays resident for the whole collective and takes whole
+    # compute units from the library's one-workgroup-per-CU kernels (+24 % per step with a 16-workgroup stand-in on one GPU,
+    # profiles/r04_reserved_cus.txt); so RCCL is held to `reserve` channels (one workgroup each) and the library leaves as many
+    # units free (vfi_set_reserved_cus below): +8.5 % instead.  A caller's own NCCL_MAX_NCHANNELS wins and sets the reserve.
+    reserve = 0
+    if world > 1 and args.backend == "nccl" and not args.no_gather and args.reserve_cus > 0:
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(args.reserve_cus))
+        try:
+            reserve = max(0, int(os.environ["NCCL_MAX_NCHANNELS"]))
+        except ValueError:
+            reserve = args.reserve_cus
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.backend, rank=rank, world_size=world,
@@ -834,6 +859,8 @@ def main():
         torch.cuda.synchronize()
         return time.perf_counter() - t0
 
+    if reserve:
+        _lib.check(_lib.load().vfi_set_reserved_cus(reserve), "vfi_set_reserved_cus")
     for i in range(Wm):
         step(i)
     drain()
@@ -851,6 +878,7 @@ def main():
     lib.vfi_trace_enable(0)
     rep = _lib.trace_report()
     lib.vfi_trace_reset()
+    lib.vfi_set_reserved_cus(0)       # the later legs gather after their compute, not beside it
 
     res = None
     if rank == 0:
@@ -858,6 +886,9 @@ def main():
                           "none" if world == 1 or args.no_gather else
                           ("all_gather(RCCL), overlapped" if gathered is not None else "all_gather(gloo, host)"))
         res["config"]["launch"] = "one process per GPU (torch.distributed)" if world > 1 else "one process, one GPU"
+        if world > 1:
+            res["config"]["reserved_cus"] = reserve
+            res["config"]["nccl_max_nchannels"] = os.environ.get("NCCL_MAX_NCHANNELS")
     # The headline is measured; every later leg is extra.  A leg that RAISES is recorded as an error string; a leg that STALLS
     # (a collective whose peer died) cannot be recovered from inside the process, so a watchdog prints the headline line as it
     # stands and ends the rank instead of losing it to the launcher's timeout.

@@ -125,6 +125,8 @@ PROTOTYPES = {
     "vfi_rife_debug_read": (C.c_int64, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64]),
     "vfi_rife_work": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vfi_memcpy_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "vfi_set_reserved_cus": (C.c_int, [C.c_int]),
+    "vfi_get_reserved_cus": (C.c_int, []),
     "vfi_film_create": (C.c_void_p, [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int]),
     "vfi_film_destroy": (None, [C.c_void_p]),
     "vfi_film_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),

@@ -536,7 +536,7 @@ static int launch2_e(ConvArgs a, hipStream_t s, const char* name) {
     // Persistent (one resident wave of workgroups, each walks its share of tiles, DMA pipelined across tiles)
     // when every workgroup gets several tiles; with only a few tiles per slot a static split leaves some
     // CUs a whole tile behind, so then launch one workgroup per tile and let the dispatcher balance.
-    int gx = (cus * occ) / ny;
+    int gx = (launch_cus(cus) * occ) / ny;
     if (gx < 1) gx = 1;
     if (gx > T || (long)T * ny < 4L * cus * occ) gx = T;
     dim3 grid(gx, ny);

@@ -676,7 +676,7 @@ static int wino_launch_t(WinoArgs& p, hipStream_t s, const char* name) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
         attr_set[dev].store(1, std::memory_order_release);
     }
-    const int cus = wino_cus(dev);
+    const int cus = launch_cus(wino_cus(dev));      // persistent: one workgroup per compute unit it may use
     const long items = (long)p.NQ * p.NY;
     int grid = (int)(items < cus ? items : cus);
     grid = round_up(grid, 8);

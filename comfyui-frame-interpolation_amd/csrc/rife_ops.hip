@@ -550,7 +550,7 @@ int encode47_batch_launch(int n, const void* const* srcs, bool u8, float* const*
         EncodeBatch fb = {};
         for (int i = 0; i < m; ++i) fb.src[i] = srcs[base + i], fb.P[i] = packs[base + i];
         const int per = tiles_x * tiles_y, items = per * m;
-        const int grid = items < 3 * cus ? items : 3 * cus;      // 42.6 KB of LDS: three workgroups per CU
+        const int grid = items < 3 * launch_cus(cus) ? items : 3 * launch_cus(cus);      // 42.6 KB of LDS: three workgroups per CU
         TraceScope ts("encode_batch", s);
         if (u8)
             hipLaunchKernelGGL(encode47_batch_kernel<unsigned char>, dim3(grid), dim3(256), 0, s, fb, w0, b0, w1, b1, H, W, C, Hp, Wp, tiles_x, per, items);
@@ -1300,7 +1300,7 @@ int trans1_conv0a_launch(const float* Ppool, size_t pack_stride, const RifeTasks
         VFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trans1_conv0a_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (F0_XF + F0_WF) * 4));
         attr_set[dev] = true;
     }
-    const int grid = std::min(n_tiles, 2 * cus);
+    const int grid = std::min(n_tiles, 2 * launch_cus(cus));
     TraceScope ts("trans1_conv0a", st);
     hipLaunchKernelGGL(trans1_conv0a_kernel, dim3(grid), dim3(F0_THREADS), (F0_XF + F0_WF) * 4, st, Ppool, pack_stride, tasks, T, Fin, Fout, wpk, bias, A0, Hp, Wp,
                        n_tiles, tiles_x, tiles_y, slope);

@@ -137,6 +137,26 @@ int vfi_device_info(char* arch_buf, int arch_buf_len, int* n_cus) {
     return 0;
 }
 
+static std::atomic<int> g_reserved_cus{0};
+}  // extern "C" (reopened below)
+namespace vfi {
+int launch_cus(int device_cus) {
+    const int r = g_reserved_cus.load(std::memory_order_relaxed);
+    int c = device_cus - (r > 0 ? r : 0);
+    c -= c % 8;
+    return c < 8 ? (device_cus < 8 ? device_cus : 8) : c;
+}
+}  // namespace vfi
+extern "C" {
+
+int vfi_set_reserved_cus(int n) {
+    VFI_REQUIRE(n >= 0 && n <= 1024, "vfi_set_reserved_cus: %d compute units", n);
+    g_reserved_cus.store(n, std::memory_order_relaxed);
+    return 0;
+}
+
+int vfi_get_reserved_cus(void) { return g_reserved_cus.load(std::memory_order_relaxed); }
+
 int vfi_memcpy_async(void* dst, const void* src, int64_t bytes, int kind, void* stream) {
     VFI_REQUIRE(dst && src && bytes >= 0 && (kind == 1 || kind == 2 || kind == 3), "vfi_memcpy_async: bad arguments (kind %d)", kind);
     if (bytes == 0) return 0;

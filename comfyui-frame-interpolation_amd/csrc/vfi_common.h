@@ -66,6 +66,11 @@ long option(Option o);
 int option_set(const char* name, long value);      // 0, or -2 for an unknown name
 int variant_override(const char* trace_name);      // tile variant forced for a trace name (vfi_test_variant_override), -1 = none
 
+// Compute units the persistent kernels may size their grids for: the device's count minus what vfi_set_reserved_cus holds back for a
+// collective kernel running beside them (a resident RCCL kernel takes whole CUs from one-workgroup-per-CU kernels, whose displaced
+// workgroups then run as a second round: +37 % while it is resident, profiles/r04_reserved_cus.txt).  A multiple of 8 (XCDs), >= 8.
+int launch_cus(int device_cus);
+
 constexpr int kMaxDevices = 16;   // devices one process may drive (per-device caches are indexed by the HIP device id)
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -432,6 +432,16 @@ int vfi_rife_interpolate(vfi_rife_t* net, int B, const int* slot0, const int* sl
 int vfi_rife_run(vfi_rife_t* net, const float* frames_host, int N, int H, int W, int C, const int* multipliers,
                  const uint8_t* skip, float scale_factor, int batch, float* out_host, int64_t* n_out);
 
+/* Compute units to leave free for a collective kernel that runs beside the library's launches (process-wide; 0 = none, the
+ * default).  The library's persistent kernels launch one workgroup per compute unit and fill it (512 registers per SIMD, up to
+ * 150 KB of LDS): a resident RCCL kernel on another stream takes whole units away and the displaced workgroups run as a second
+ * round (+37 % per launch while it is resident, profiles/r04_reserved_cus.txt).  With n units reserved the persistent grids are sized
+ * for the rest — results are bit-identical for any n (work items are independent of the workgroup that computes them).  The
+ * multi-process path (torch.distributed: `all_gather_frames`, bench.py --gpus N) sets it around its overlapped all-gather — what the
+ * reference leaves to NCCL's own scheduling.  vfi_get_reserved_cus returns the current value. */
+int vfi_set_reserved_cus(int n);
+int vfi_get_reserved_cus(void);
+
 /* Host pipeline helper: hipMemcpyAsync(dst, src, bytes, kind, stream) with kind 1 = host -> device, 2 = device -> host, 3 = device ->
  * device; host memory should be pinned (pageable memory makes the call synchronous).  What the node's frame uploads / downloads
  * (`frames.to(device)` / `.cpu()`, rife/__init__.py:195-207,225-230) become: issued from worker threads without the framework's

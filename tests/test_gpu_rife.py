@@ -819,3 +819,33 @@ def test_fused_frame_pack_is_bit_identical(hip_lib, h, w, u8):
         hip_lib.vfi_test_set_option(b"fuse_encode", 1)
     assert outs[0].shape == outs[1].shape and np.array_equal(outs[0], outs[1]), float(np.abs(outs[0] - outs[1]).max())
     assert np.abs(outs[0]).max() > 0.1
+
+
+def test_reserved_compute_units_change_no_bit():
+    """vfi_set_reserved_cus sizes the persistent kernels' grids for fewer compute units (room for an overlapped collective's kernel);
+    a frame's bits do not depend on it."""
+    from cfi_amd import _lib, synth
+    from cfi_amd.rife import RifeEngine
+
+    lib = _lib.load()
+    eng = RifeEngine(synth.rife47_synth_state_dict(7), "4.7")
+    H, W, B = 270, 480, 3
+    eng.configure(H, W, B, B + 1, 1.0)
+    g = torch.Generator().manual_seed(5)
+    raw = torch.rand((B + 1, H, W, 3), generator=g).cuda()
+    outs = []
+    try:
+        for r in (0, 32, 200, 100000):
+            rc = lib.vfi_set_reserved_cus(r)
+            if r > 1024:
+                assert rc != 0
+                continue
+            assert rc == 0 and lib.vfi_get_reserved_cus() == r
+            out = torch.empty((B, H, W, 3), device="cuda")
+            eng.load_frames(list(range(B + 1)), [raw[j] for j in range(B + 1)])
+            eng.interpolate(list(range(B)), list(range(1, B + 1)), [0.5, 0.25, 0.75], out)
+            outs.append(out.cpu())
+    finally:
+        lib.vfi_set_reserved_cus(0)
+        eng.close()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
