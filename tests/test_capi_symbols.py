@@ -68,3 +68,15 @@ def test_engines_need_a_gpu():
                      (M2MEngine, synth.m2m_synth_state_dict), (Rife40Engine, synth.rife40_synth_state_dict)):
         with pytest.raises(RuntimeError, match="no GPU"):
             ctor(sd(1))
+
+
+def test_reserved_cus_setting_round_trips_without_a_gpu(hip_lib):
+    """vfi_set_reserved_cus is plain process state (read by the persistent kernels' launchers): settable and readable on any box,
+    out-of-range values refused with a message."""
+    try:
+        assert hip_lib.vfi_get_reserved_cus() == 0
+        assert hip_lib.vfi_set_reserved_cus(16) == 0 and hip_lib.vfi_get_reserved_cus() == 16
+        assert hip_lib.vfi_set_reserved_cus(-1) != 0 and "vfi_set_reserved_cus" in _lib.last_error()
+        assert hip_lib.vfi_set_reserved_cus(5000) != 0 and hip_lib.vfi_get_reserved_cus() == 16
+    finally:
+        assert hip_lib.vfi_set_reserved_cus(0) == 0
