@@ -16,7 +16,7 @@ torch is used for what it is here for: pinned allocations, streams, events.  Pin
 import ctypes
 import os
 import threading
-from concurrent.futures import ThreadPoolExecutor
+from concurrent.futures import Future, ThreadPoolExecutor
 
 import torch
 
@@ -53,6 +53,7 @@ class _T:
                 c[1] += dt
 
 
+SPLIT_PARTS = 4   # row bands per frame of the first launch's uploads (1 = whole frames)
 POLL = False      # diagnostics (tools/node_e2e.py sets it): busy-poll the events instead of blocking in event.synchronize()
 
 
@@ -84,6 +85,15 @@ def _events(n, stream):
     for e in evs:
         e.record(stream)
     return evs
+
+
+def _ring_events(r, key, n, stream):
+    """n events kept with the staging set `r` (exclusively the caller's between acquire and release) and reused by every call: a 33-frame
+    clip needs ~80 of them, and creating + destroying that many per call cost ~1 ms at the head and ~2 ms after the last copy-back."""
+    have = r.setdefault(key, [])
+    if len(have) < n:
+        have.extend(_events(n - len(have), stream))
+    return have[:n]
 
 
 def _memcpy_async(dst, src, kind, stream):
@@ -178,19 +188,27 @@ class Uploader:
         self.consumed = [None] * len(self.order)                  # cuda event: main stream finished reading item i
         # (an item's events are dead once item i + depth has been staged: a ring of 4 * depth serves clips of any length)
         self._ne = max(1, min(len(self.order), 4 * depth))
-        self._ev_up = _events(self._ne, self.stream)              # H2D of item i done
-        self._ev_cons = _events(self._ne, main)                   # main stream has consumed item i
+        self._ev_up = _ring_events(self.rings, "ev_up", self._ne, self.stream)      # H2D of item i done
+        self._ev_cons = _ring_events(self.rings, "ev_cons", self._ne, main)         # main stream has consumed item i
         pool = _pool(f"up{device}", workers)
-        self.futs = [pool.submit(self._stage, i) for i in range(len(self.order))]
+        # The frames of the first launch (`staged_after` of them) are what the GPU waits for at the head of a call: each is copied into
+        # its pinned slot in SPLIT_PARTS row bands by as many workers, so that frame 0's H2D starts after a quarter of a frame copy
+        # and the others follow back to back (whole frames per worker: all of them finish together, then queue on the link).
+        self._split_n = min(int(staged_after), len(self.order), depth) if SPLIT_PARTS > 1 else 0
+        self._parts_left = [SPLIT_PARTS] * self._split_n
+        self.futs = []
+        for i in range(len(self.order)):
+            if i < self._split_n:
+                fut = Future()
+                fut.set_running_or_notify_cancel()
+                self.futs.append(fut)
+                for part in range(SPLIT_PARTS):
+                    pool.submit(self._stage_part, i, part, fut)
+            else:
+                self.futs.append(pool.submit(self._stage, i))
 
-    def _stage(self, i):
-        s = i % self.depth
-        if i >= self.depth:
-            with _T("up.wait_slot"):
-                self.freed[i - self.depth].wait()
-                _wait(self.consumed[i - self.depth])
-        with _T("up.memcpy_to_pinned"):
-            host_copy(self.host[s], self.frames[self.order[i]][..., :3])   # pageable -> pinned (drops alpha, makes contiguous)
+    def _staged_one(self, i):
+        """Item i sits in pinned memory: fire on_staged once the first `staged_after` items do."""
         if self._on_staged is not None and i < self._staged_n:
             fire = False
             with self._staged_lock:
@@ -200,11 +218,44 @@ class Uploader:
             if fire:
                 cb, self._on_staged = self._on_staged, None
                 cb()
+
+    def _enqueue_h2d(self, i):
+        s = i % self.depth
         ev = self._ev_up[i % self._ne]
         with _T("up.enqueue_h2d"):
             _memcpy_async(self.dev[s], self.host[s], 1, self.stream)
             ev.record(self.stream)
         return ev
+
+    def _stage_part(self, i, part, fut):
+        """Row band `part` of a first-launch frame (i < depth: its slot is free from the start); the band that finishes last issues the H2D."""
+        try:
+            s = i % self.depth
+            src = self.frames[self.order[i]]
+            rows = src.shape[0]
+            r0, r1 = rows * part // SPLIT_PARTS, rows * (part + 1) // SPLIT_PARTS
+            with _T("up.memcpy_to_pinned"):
+                host_copy(self.host[s][r0:r1], src[r0:r1][..., :3])
+            with self._staged_lock:
+                self._parts_left[i] -= 1
+                last = self._parts_left[i] == 0
+            if last:
+                self._staged_one(i)
+                fut.set_result(self._enqueue_h2d(i))
+        except BaseException as e:      # surfaces in get(i) / close()
+            if not fut.done():
+                fut.set_exception(e)
+
+    def _stage(self, i):
+        s = i % self.depth
+        if i >= self.depth:
+            with _T("up.wait_slot"):
+                self.freed[i - self.depth].wait()
+                _wait(self.consumed[i - self.depth])
+        with _T("up.memcpy_to_pinned"):
+            host_copy(self.host[s], self.frames[self.order[i]][..., :3])   # pageable -> pinned (drops alpha, makes contiguous)
+        self._staged_one(i)
+        return self._enqueue_h2d(i)
 
     def ready(self, i):
         """Has item i been staged and its H2D copy been enqueued?  (Non-blocking: frames packed ahead of their launch.)"""
@@ -250,7 +301,7 @@ class Downloader:
         self.stream = _stream(device, "down")
         self.pool = _pool(f"down{device}", workers)
         self.workers = workers
-        self._ev = _events(depth, self.stream)                    # one per staging slot (a slot's previous copy has been drained before reuse)
+        self._ev = _ring_events(self.rings, "ev_down", depth, self.stream)      # one per staging slot (a slot's previous copy has been drained before reuse)
         self.slot_fut = [None] * depth
         self.n = 0
         self.futs = []

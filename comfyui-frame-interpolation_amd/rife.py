@@ -388,11 +388,18 @@ def run_tasks(engine, frames_cpu, tasks, batch_size, scale_factor=1.0, out_devic
                     tl[-1] = tl[-1] + (time.perf_counter() - t_base,)
                 k ^= 1
     finally:
+        if tl is not None:
+            t_loop = time.perf_counter() - t_base
         up.close()
+        if tl is not None:
+            t_up = time.perf_counter() - t_base
         if down is not None:
             down.close()
+        if tl is not None:
+            t_down = time.perf_counter() - t_base
     if tl is not None:
         torch.cuda.synchronize()
+        print(f"   tail: launch loop done {t_loop * 1e3:.1f} ms, uploader closed {t_up * 1e3:.1f}, downloader drained {t_down * 1e3:.1f}")
         print("   batch: host[begin, uploads ready, enqueued, copy-back enqueued] ms | device[start, end] ms (device clock zeroed at host 0)")
         for i, row in enumerate(tl):
             a, b, c, e0, e1 = row[:5]

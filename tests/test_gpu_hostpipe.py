@@ -16,7 +16,10 @@ def test_upload_download_round_trip_and_stream_reuse():
     seen = []
     for rep in range(2):
         order = [3, 0, 6, 1, 5]
-        up = hostpipe.Uploader(frames, order, dev, main, depth=2)
+        fired = []
+        # second repetition: the first two items go through the split (row-band) staging path and announce themselves
+        up = hostpipe.Uploader(frames, order, dev, main, depth=2, on_staged=(lambda: fired.append(1)) if rep else None, staged_after=2 if rep else 0)
+        assert up._split_n == (2 if rep else 0)
         down = hostpipe.Downloader(dev, (40, 56, 3), main, depth=3)
         seen.append((up.stream, down.stream))
         out = torch.zeros(len(order), 40, 56, 3)
@@ -33,5 +36,6 @@ def test_upload_download_round_trip_and_stream_reuse():
             down.close()
         for i, f in enumerate(order):
             assert torch.equal(out[i], frames[f][..., :3] * 2.0)
+        assert fired == ([1] if rep else [])
     assert seen[0][0] is seen[1][0] and seen[0][1] is seen[1][1] and seen[0][0] is not seen[0][1]
     assert hostpipe._stream(dev, "up") is seen[0][0]
