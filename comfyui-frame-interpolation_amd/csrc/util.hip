@@ -142,7 +142,8 @@ static std::atomic<int> g_reserved_cus{0};
 namespace vfi {
 int launch_cus(int device_cus) {
     const int r = g_reserved_cus.load(std::memory_order_relaxed);
-    int c = device_cus - (r > 0 ? r : 0);
+    if (r <= 0) return device_cus;      // nothing reserved: the device's own count, whatever its divisibility
+    int c = device_cus - r;
     c -= c % 8;
     return c < 8 ? (device_cus < 8 ? device_cus : 8) : c;
 }
