@@ -780,12 +780,15 @@ def main():
     # profiles/r04_reserved_cus.txt); so RCCL is held to `reserve` channels (one workgroup each) and the library leaves as many
     # units free (vfi_set_reserved_cus below): +8.5 % instead.  A caller's own NCCL_MAX_NCHANNELS wins and sets the reserve.
     reserve = 0
-    if world > 1 and args.backend == "nccl" and not args.no_gather and args.reserve_cus > 0:
-        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(args.reserve_cus))
-        try:
-            reserve = max(0, int(os.environ["NCCL_MAX_NCHANNELS"]))
-        except ValueError:
-            reserve = args.reserve_cus
+    if world > 1 and not args.no_gather and args.reserve_cus > 0:
+        reserve = args.reserve_cus
+        if args.backend == "nccl":
+            os.environ.setdefault("NCCL_MAX_NCHANNELS", str(args.reserve_cus))
+            try:
+                reserve = max(0, int(os.environ["NCCL_MAX_NCHANNELS"]))
+            except ValueError:
+                reserve = args.reserve_cus
+        # (gloo plumbing runs take the same code path: the trials below are then between equals)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.backend, rank=rank, world_size=world,
@@ -864,6 +867,20 @@ def main():
     for i in range(Wm):
         step(i)
     drain()
+    reserve_trials = None
+    if reserve:
+        # RCCL's real kernel has never run beside this library (no multi-GPU box was available): how many units it takes, and for how
+        # long, is an estimate.  So the reserve is CHOSEN here, untimed, from what this node actually does: a few steps each with the
+        # planned reserve, none, and twice as many; every rank sees the same all-reduced times and takes the same decision.
+        reserve_trials = {}
+        for cand in (reserve, 0, 2 * reserve):
+            _lib.check(_lib.load().vfi_set_reserved_cus(cand), "vfi_set_reserved_cus")
+            timed(1)
+            t = torch.tensor([timed(3)], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            reserve_trials[cand] = float(t.item()) / 3
+        reserve = min(reserve_trials, key=lambda c: (reserve_trials[c], c))
+        _lib.check(_lib.load().vfi_set_reserved_cus(reserve), "vfi_set_reserved_cus")
     elapsed = timed(K)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
@@ -889,6 +906,8 @@ def main():
         if world > 1:
             res["config"]["reserved_cus"] = reserve
             res["config"]["nccl_max_nchannels"] = os.environ.get("NCCL_MAX_NCHANNELS")
+            if reserve_trials is not None:
+                res["config"]["reserved_cus_trials_ms_per_step"] = {str(c): round(v * 1e3, 3) for c, v in reserve_trials.items()}
     # The headline is measured; every later leg is extra.  A leg that RAISES is recorded as an error string; a leg that STALLS
     # (a collective whose peer died) cannot be recovered from inside the process, so a watchdog prints the headline line as it
     # stands and ends the rank instead of losing it to the launcher's timeout.

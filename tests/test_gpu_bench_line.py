@@ -53,3 +53,7 @@ def test_two_rank_line_shards_the_strong_leg(hip_lib):
     assert res["n_gpus"] == 2 and res["scaling"] == "weak"
     st = res["strong_4k_x4"]
     assert st["tasks_per_rank"] == [5, 4] and st["n_gpus"] == 2 and st["value"] > 0, st
+    # the reserve for an overlapped collective is chosen from untimed trials (planned, none, twice as many) and reported
+    cfg = res["config"]
+    assert set(cfg["reserved_cus_trials_ms_per_step"]) == {"16", "0", "32"} and cfg["reserved_cus"] in (0, 16, 32)
+    assert all(v > 0 for v in cfg["reserved_cus_trials_ms_per_step"].values())
