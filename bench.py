@@ -317,6 +317,94 @@ def other_paths_dist(dev, H, W, world, rank, backend):
     return out
 
 
+def peer_copy_gather_leg(eng, raw, B, H, W, K, dev, world, rank, backend):
+    """The headline loop once more with the new frames exchanged WITHOUT a collective kernel: every rank maps its peers' gather buffers
+    through IPC handles and pushes its B new frames into them with plain device-to-device copies on a side stream (peer copies over
+    xGMI run on the SDMA engines: no compute units taken from the persistent kernels — the form DESIGN.md section 6 prefers on
+    point-to-point links).  Reported NEXT to the RCCL-based `value`, never instead of it: this leg has only ever run with its ranks
+    on one GPU (tests/test_gpu_bench_line.py), so it sits behind the watchdog and validates what arrived before it reports a number."""
+    import torch.distributed as dist
+
+    ctl = dev if backend == "nccl" else "cpu"
+    outs = [torch.empty((B, H, W, 3), dtype=torch.float32, device=dev) for _ in range(2)]
+    gathered = [torch.zeros((world * B, H, W, 3), dtype=torch.float32, device=dev) for _ in range(2)]
+    torch.cuda.synchronize(dev)
+    views, err = [], None          # views[r][k]: rank r's gathered[k] as a tensor of THIS process
+    try:
+        mine = [g.untyped_storage()._share_cuda_() for g in gathered]
+    except Exception as e:
+        mine, err = None, f"{type(e).__name__}: {e}"
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    if err is None and all(h is not None for h in everyone):
+        try:
+            for r in range(world):
+                if r == rank:
+                    views.append(gathered)
+                    continue
+                vk = []
+                for k in range(2):
+                    st = torch.UntypedStorage._new_shared_cuda(*everyone[r][k])
+                    vk.append(torch.empty(0, dtype=torch.float32, device=st.device).set_(st, 0, (world * B, H, W, 3)))
+                views.append(vk)
+        except Exception as e:
+            err = f"{type(e).__name__}: {e}"
+    elif err is None:
+        err = "a peer could not export its buffers"
+    bad = torch.tensor([0.0 if err is None else 1.0], device=ctl)
+    dist.all_reduce(bad)            # every rank learns whether ALL mappings exist before any of them enters the loop's barriers
+    if float(bad.item()) != 0.0:
+        return {"error": err or "a peer could not map the buffers"}
+    side = torch.cuda.Stream(dev)
+    main = torch.cuda.current_stream(dev)
+    copied = [None, None]           # outs[k]'s copies of two steps ago have left it
+    slot0, slot1, ts = list(range(B)), list(range(1, B + 1)), [0.5] * B
+
+    def step(i):
+        k = i & 1
+        base = clip_base(B, k)
+        if copied[k] is not None:
+            main.wait_event(copied[k])
+        eng.load_frames(list(range(B + 1)), [raw[base + j] for j in range(B + 1)])
+        eng.interpolate(slot0, slot1, ts, outs[k])
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            for r in range(world):          # own block first, then the peers, each rank starting with a different one
+                views[(rank + r) % world][k][rank * B:(rank + 1) * B].copy_(outs[k], non_blocking=True)
+            copied[k] = torch.cuda.Event()
+            copied[k].record(side)
+
+    def timed(n):
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(n):
+            step(i)
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        return time.perf_counter() - t0
+
+    timed(2)
+    # validation: every rank publishes a fingerprint of its own new frames; what arrived in THIS rank's buffer must match all of them
+    fp = [float(outs[1][0, ::97, ::89].double().sum().item()), float(outs[1][B - 1, ::83, ::101].double().sum().item())]
+    fps = [None] * world
+    dist.all_gather_object(fps, fp)
+    ok = all(abs(float(gathered[1][r * B, ::97, ::89].double().sum().item()) - fps[r][0]) <= 1e-6 * max(1.0, abs(fps[r][0])) and
+             abs(float(gathered[1][r * B + B - 1, ::83, ::101].double().sum().item()) - fps[r][1]) <= 1e-6 * max(1.0, abs(fps[r][1]))
+             for r in range(world))
+    flag = torch.tensor([0.0 if ok else 1.0], device=ctl)
+    dist.all_reduce(flag)
+    if float(flag.item()) != 0.0:
+        return {"error": f"{int(flag.item())} rank(s) did not find their peers' frames in the mapped buffers"}
+    t = torch.tensor([timed(K)], dtype=torch.float64, device=ctl)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+    del views
+    return {"value": round(world * B * K / el, 2), "unit": "interpolated frames/s (whole job)", "ms_per_step": round(el / K * 1e3, 3), "steps": K,
+            "exchange": "each rank copies its new frames into every peer's gather buffer (IPC-mapped) with device-to-device copies on a side stream; "
+                        "no collective kernel", "validated": "fingerprints of every rank's frames found in every rank's buffer"}
+
+
 def strong_4k_x4(args, dev, world, rank, backend, group=None):
     """BASELINE.json configs[3] / SURVEY 8(d) config 4: RIFE 4.9 (= arch 4.7, rife/__init__.py CKPT_NAME_VER_DICT), multiplier 4, a
     17-frame 2160x3840 host clip -> 16 pairs x 3 timesteps = 48 independent tasks (rife/__init__.py:164-174).  STRONG scaling: the
@@ -745,6 +833,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the FILM / M2M device-resident numbers")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather of new frames")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling 4K x4 leg (BASELINE configs[3])")
+    ap.add_argument("--no-peer-copy-leg", action="store_true", help="N>1: skip the extra weak-scaling leg that exchanges frames by IPC-mapped peer copies")
     ap.add_argument("--reserve-cus", type=int, default=16,
                     help="N>1 over RCCL: compute units the persistent kernels leave to the overlapped all-gather's kernel (also caps "
                          "RCCL's channels to the same number unless NCCL_MAX_NCHANNELS is set); 0 = none")
@@ -920,6 +1009,13 @@ def main():
             strong = {"error": f"{type(e).__name__}: {e}"}
         if rank == 0:
             res["strong_4k_x4"] = strong
+    if world > 1 and not args.no_gather and not args.no_peer_copy_leg:
+        try:
+            pc = peer_copy_gather_leg(eng, raw, B, H, W, max(2, min(K, 10)), dev, world, rank, args.backend)
+        except Exception as e:
+            pc = {"error": f"{type(e).__name__}: {e}"}
+        if rank == 0:
+            res["weak_peer_copy_gather"] = pc
     if world > 1 and not args.no_extras:
         eng.release() if hasattr(eng, "release") else None
         try:

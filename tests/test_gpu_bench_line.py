@@ -57,3 +57,6 @@ def test_two_rank_line_shards_the_strong_leg(hip_lib):
     cfg = res["config"]
     assert set(cfg["reserved_cus_trials_ms_per_step"]) == {"16", "0", "32"} and cfg["reserved_cus"] in (0, 16, 32)
     assert all(v > 0 for v in cfg["reserved_cus_trials_ms_per_step"].values())
+    # the extra weak-scaling leg that exchanges frames by IPC-mapped peer copies (no collective kernel): ran, validated what arrived
+    pc = res["weak_peer_copy_gather"]
+    assert "error" not in pc and pc["value"] > 0 and "fingerprints" in pc["validated"], pc
