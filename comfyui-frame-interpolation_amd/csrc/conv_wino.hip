@@ -231,7 +231,6 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63;   // (prologue only: the loops take the lane id from opaque_lane())
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int C8 = a.Cin_p >> 3;
     const int H = a.Hin, W = a.Win;
@@ -297,9 +296,6 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
             const bool ok = code >= 0 && c.valid && (a.pad_replicate || (cy == iy && cx == ix));
             avtab[i * 64 + ol] = ok ? ((cy * W + cx) * a.in_cs + (code & 1) * 4) * 4 : (int)0x80000000;
         }
-    };
-    auto make_rsrc = [&](int n) {
-        return __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)n * img_floats), 0, img_floats * 4, 0x00020000);
     };
     // One DMA piece per call: the K loop spreads a chunk's pieces over its MFMA groups (ten in a row back up the texture
     // addresser, which all four waves of the workgroup share, and stall the issuing wave).  At the stream's tail the cursor's
