@@ -27,8 +27,16 @@ Rank 0 prints ONE JSON line.  Extra objects:
   strong_4k_x4 — BASELINE configs[3]: RIFE 4.9 (arch 4.7), multiplier 4, a 17-frame 2160x3840 host clip = 48 tasks,
                  block-partitioned over the ranks with one halo frame per block (unequal blocks where 48 % N != 0), new frames
                  all-gathered device-side: STRONG scaling (fixed total work), reported beside the weak-scaling headline.
-  cpu_baseline — the oracle (torch-CPU restatement, bit-exact vs the reference in the build container)
-                 timed on this host's cores on a bounded sample (N=1, rank 0 only); host CPU model and core count stated.
+  cpu_baseline — the oracle (torch-CPU restatement, bit-exact vs the reference in the build container) timed on this host's
+                 cores BEFORE the GPU leg, on pair 0 of the very clip the GPU leg is timed on (identical tensors, BASELINE.md
+                 section 3): a bounded sample (N=1, rank 0 only); host CPU model and core count stated.
+  parity       — the in-run gate: frame 0 of the LAST timed step (32-task launch, i.i.d. noise clip) against the oracle's frame
+                 for the same pair from the cpu_baseline forwards: max |d|, pixels over 1e-3.  A line whose parity fails is
+                 printed with "ok": false and the process exits non-zero.
+  clock        — the shader clock the chip sustained inside the dominant kernel during the timed region (s_memtime /
+                 s_memrealtime deltas of workgroup 0 in every Winograd launch, vfi_clock_probe) + sysfs sclk / socket power
+                 samples where the box exposes them; roofline.frac_at_clock prices the kernel against the peak AT that clock
+                 (the chip clocks to its power budget: the same binary measures 5-7 % apart between boxes).
   e2e          — SURVEY 8(d) config 2, PCIe-inclusive (never `value`): a host clip [33,1080,1920,3] fp32
                  (torch.manual_seed(0); torch.rand) through the node class RIFE_VFI.vfi to a host tensor, wall clock from the
                  call to the returned tensor (first H2D ... last D2H + host assembly), warm, median of 3; plus the measured
@@ -493,12 +501,13 @@ def strong_4k_x4(args, dev, world, rank, backend, group=None):
         times.append(dt)
     if group is None:
         eng.close()
-    best = min(times)
+    best = sorted(times)[len(times) // 2]      # the median (upper of two), like the e2e leg; all times are listed under `seconds`
     return {
         "workload": f"RIFE 4.9 (arch 4.7) x{mult}, {n_frames}-frame {H}x{W} host clip (torch.manual_seed(0) torch.rand) = {len(tasks)} tasks; "
                     f"contiguous task blocks per rank {counts} (+ 1 halo frame each), {bs} tasks per launch",
         "scaling": "strong",
         "value": round(len(tasks) / best, 2),
+        "value_is": f"tasks / median of {len(times)} timed repetitions",
         "unit": "interpolated frames/s (whole job; host clip in, " + ("host tensor out" if group is not None else "gathered device frames out") + ")",
         "n_gpus": world,
         "seconds": [round(t, 4) for t in times],
@@ -508,19 +517,130 @@ def strong_4k_x4(args, dev, world, rank, backend, group=None):
     }
 
 
-def cpu_baseline(sd, H, W, budget_s=25.0):
-    """Oracle on the host cores, bounded sample: for a few thread counts (all cores is often NOT the fastest
-    on a many-core host), 1 warm-up + 3 timed 1080p forwards each; report the best median."""
-    from cfi_amd import synth
+
+class ClockProbe:
+    """vfi_clock_probe wrapper: one record per Winograd launch while installed (include/vfi_hip.h)."""
+
+    def __init__(self, dev, capacity):
+        import ctypes as C_
+
+        from cfi_amd import _lib
+
+        self.lib, self._lib = _lib.load(), _lib
+        self.rec = torch.zeros((capacity, 8), dtype=torch.int64, device=dev)
+        _lib.check(self.lib.vfi_clock_probe(C_.c_void_p(self.rec.data_ptr()), capacity), "vfi_clock_probe")
+
+    def finish(self):
+        """-> {trace name: [(cycles, ticks), ...]} of the launches that completed a record."""
+        torch.cuda.synchronize()
+        self._lib.check(self.lib.vfi_clock_probe(None, 0), "vfi_clock_probe")
+        names = self._lib.clock_probe_names()
+        r = self.rec.cpu().numpy().astype("uint64")
+        out = {}
+        for row in r:
+            t0, r0, t1, r1, tag = (int(v) for v in row[:5])
+            if t1 > t0 and r1 > r0 and tag < len(names):
+                out.setdefault(names[tag], []).append((t1 - t0, r1 - r0))
+        return out
+
+
+def clock_summary(by_name, dom):
+    def mhz(pairs):
+        return [c / t * 100.0 for c, t in pairs if t > 0]
+
+    d = mhz(by_name.get(dom, []))
+    allw = [m for v in by_name.values() for m in mhz(v)]
+    if not d:
+        return None
+    return {"shader_mhz": round(sum(d) / len(d), 1), "min": round(min(d), 1), "max": round(max(d), 1), "launches": len(d),
+            "all_winograd_launches_mhz": round(sum(allw) / len(allw), 1) if allw else None,
+            "avg_ticks_per_launch": round(sum(t for _, t in by_name[dom]) / len(by_name[dom]), 1),
+            "avg_cycles_per_launch": round(sum(c for c, _ in by_name[dom]) / len(by_name[dom]), 1)}
+
+
+class SysfsSampler:
+    """Side thread: sclk (MHz) and socket power (W) of the GPU from sysfs every ~10 ms while running.  Best effort — a box that does
+    not expose the files yields None; the in-kernel clock above does not depend on it."""
+
+    def __init__(self, dev_index=0):
+        import glob
+        import threading
+
+        self.freq_files, self.power_files, self.dpm_files = [], [], []
+        try:
+            cards = []
+            for c in sorted(glob.glob("/sys/class/drm/card[0-9]*")):
+                try:
+                    if open(os.path.join(c, "device/vendor")).read().strip() == "0x1002":
+                        cards.append(c)
+                except OSError:
+                    pass
+            if cards:
+                c = cards[min(dev_index, len(cards) - 1)]
+                self.freq_files = sorted(glob.glob(os.path.join(c, "device/hwmon/hwmon*/freq1_input")))
+                self.power_files = sorted(glob.glob(os.path.join(c, "device/hwmon/hwmon*/power1_average")) +
+                                          glob.glob(os.path.join(c, "device/hwmon/hwmon*/power1_input")))
+                self.dpm_files = [f for f in [os.path.join(c, "device/pp_dpm_sclk")] if os.path.exists(f)]
+        except Exception:
+            pass
+        self.sclk, self.power = [], []
+        self._stop = threading.Event()
+        self._thr = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                if self.freq_files:
+                    self.sclk.append(int(open(self.freq_files[0]).read()) / 1e6)
+                elif self.dpm_files:
+                    for line in open(self.dpm_files[0]):
+                        if "*" in line:
+                            self.sclk.append(float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip()))
+                if self.power_files:
+                    self.power.append(int(open(self.power_files[0]).read()) / 1e6)
+            except Exception:
+                pass
+            self._stop.wait(0.01)
+
+    def __enter__(self):
+        if self.freq_files or self.dpm_files or self.power_files:
+            self._thr.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        if self._thr.is_alive():
+            self._thr.join(timeout=1.0)
+
+    def summary(self):
+        avg = lambda v: round(sum(v) / len(v), 1) if v else None
+        return {"sclk_mhz": avg(self.sclk), "sclk_mhz_min": round(min(self.sclk), 1) if self.sclk else None, "socket_power_w": avg(self.power),
+                "samples": max(len(self.sclk), len(self.power)),
+                "source": (self.freq_files or self.dpm_files or ["-"])[0] + " | " + (self.power_files or ["-"])[0]}
+
+
+def parity_of(got, want, tol=1e-3):
+    """got / want: [H,W,3] fp32 (host).  The north-star gate: per-pixel |d| <= 1e-3."""
+    d = (got - want).abs()
+    return {"max_abs": float(d.max().item()), "mean_abs": float(d.mean().item()), "n_over_1e-3": int((d > tol).sum().item()),
+            "values": int(d.numel()), "tol": tol, "ok": bool((d <= tol).all().item())}
+
+def cpu_baseline(sd, f0, f1, budget_s=25.0, timing=True):
+    """Oracle on the host cores, on the pair (f0, f1) the GPU leg's parity check looks at ([H,W,3] fp32 host tensors, t = 0.5):
+    for a few thread counts (all cores is often NOT the fastest on a many-core host), 1 warm-up + 3 timed 1080p forwards each;
+    reports the best median and returns (dict, the oracle's frame [H,W,3] clamped as the node clamps it).  ``timing`` False: one
+    forward, no baseline figure (N > 1 runs: the parity reference only)."""
     from oracle import rife_oracle
 
-    frames = synth.smooth_frames(2, H, W, seed=2, shift=4.0)
-    x = frames.permute(0, 3, 1, 2)
+    H, W = f0.shape[0], f0.shape[1]
+    x0 = f0.permute(2, 0, 1).unsqueeze(0).contiguous()
+    x1 = f1.permute(2, 0, 1).unsqueeze(0).contiguous()
     ts = torch.tensor([0.5]).view(1, 1, 1, 1)
     default = torch.get_num_threads()
-    cands = sorted({default, max(1, default // 2), max(1, default // 4)}, reverse=True)
+    cands = sorted({default, max(1, default // 2), max(1, default // 4)}, reverse=True) if timing else [default]
     best = None
     tried = []
+    ref = None
     t_begin = time.time()
     with torch.inference_mode():
         for nt in cands:
@@ -528,16 +648,20 @@ def cpu_baseline(sd, H, W, budget_s=25.0):
                 break
             torch.set_num_threads(nt)
             times = []
-            for i in range(4):
+            for i in range(4 if timing else 1):
                 t0 = time.time()
-                rife_oracle.ifnet47_forward(sd, x[0:1], x[1:2], ts)
-                if i > 0:
+                o = rife_oracle.ifnet47_forward(sd, x0, x1, ts)
+                if i > 0 or not timing:
                     times.append(time.time() - t0)
+                if ref is None:
+                    ref = o.clamp(0, 1)[0].permute(1, 2, 0).contiguous()      # rife/__init__.py: the node clamps the new frame
             med = sorted(times)[len(times) // 2]
             tried.append((nt, round(med, 3)))
             if best is None or med < best[1]:
                 best = (nt, med)
     torch.set_num_threads(default)
+    if not timing:
+        return None, ref
     return {
         "value": round(1.0 / best[1], 4),
         "unit": "interpolated frames/s",
@@ -546,9 +670,9 @@ def cpu_baseline(sd, H, W, budget_s=25.0):
         "host_logical_cpus": os.cpu_count(),
         "kind": "port",
         "sample": f"oracle.rife_oracle.ifnet47_forward (torch-CPU fp32 restatement, bit-exact vs the reference's IFNet('4.7') "
-                  f"in the build container), 1 pair {H}x{W}; per thread count 1 warm-up + 3 timed forwards (median), "
-                  f"(threads, median s/frame) tried: {tried}; best reported",
-    }
+                  f"in the build container) on frames 0 and 1 of the GPU leg's own clip (identical tensors), 1 pair {H}x{W}, t = 0.5, run BEFORE the "
+                  f"GPU leg; per thread count 1 warm-up + 3 timed forwards (median), (threads, median s/frame) tried: {tried}; best reported",
+    }, ref
 
 
 def main_single_process(args):
@@ -688,8 +812,9 @@ def main_single_process(args):
     print(json.dumps(res), flush=True)
 
 
-def result_line(args, world, elapsed, traced, rep, eng, collective):
-    """The JSON line's common part (metric, roofline of the dominant kernel, per-kernel table)."""
+def result_line(args, world, elapsed, traced, rep, eng, collective, clock=None):
+    """The JSON line's common part (metric, roofline of the dominant kernel, per-kernel table).  ``clock``: {"timed": ..., "traced": ...,
+    "sysfs": ...} from the clock probe (None where it was not run)."""
     B, H, W, K, Wm = args.batch, args.height, args.width, args.steps, args.warmup
     conv_flop, _ = eng.work_per_task()
     hp, wp = -(-H // 64) * 64, -(-W // 64) * 64
@@ -747,6 +872,27 @@ def result_line(args, world, elapsed, traced, rep, eng, collective):
         roofline_hbm.insert(0, hbm_entry("encode_fused: frame pack of ONE frame per launch", enc_frame_bytes, m / c, c))
     total_ms = sum(v[1] for v in rep.values())
     kernels = {k: {"calls": v[0], "ms": round(v[1], 3), "share": round(v[1] / total_ms, 4)} for k, v in rep.items()}
+    # the clock the chip sustained inside the dominant kernel: timed region (what `value` ran at) and traced pass (what avg_launch_ms ran at)
+    clock_obj, frac_at_clock, mhz_traced = None, None, None
+    if clock and clock.get("traced"):
+        ct, cm = clock["traced"], clock.get("timed")
+        mhz_traced = ct["shader_mhz"]
+        frac_at_clock = round(achieved / exec_div / (PEAK_FP32_MFMA_TFLOPS * mhz_traced / 2400.0), 4) if calls else None
+        clock_obj = {
+            "shader_mhz": (cm or ct)["shader_mhz"],
+            "shader_mhz_min_max": [(cm or ct)["min"], (cm or ct)["max"]],
+            "region": "timed region" if cm else "traced pass",
+            "traced_pass_shader_mhz": ct["shader_mhz"],
+            "all_winograd_launches_mhz": (cm or ct)["all_winograd_launches_mhz"],
+            "kernel": dom,
+            "launches": (cm or ct)["launches"],
+            "source": "s_memtime (shader cycles) / s_memrealtime (100 MHz) deltas of workgroup 0 of every launch of the dominant kernel (vfi_clock_probe); "
+                      "peak clock 2400 MHz (MI355X_MICROARCH.md)",
+            # s_memrealtime ticks per microsecond of HIP-event time of the same launches: 100 if the constant-rate counter runs at 100 MHz
+            # (workgroup 0 lives a little shorter than the launch, so slightly below)
+            "realtime_ticks_per_event_us": round(ct["avg_ticks_per_launch"] / (avg_ms * 1e3), 3) if calls and avg_ms else None,
+            "sysfs": clock.get("sysfs"),
+        }
     return {
         # BASELINE.json's metric; `value` is the whole-job aggregate over n_gpus (== per GPU at N=1), the per-GPU rate is
         # config.per_gpu_frames_per_s
@@ -780,6 +926,10 @@ def result_line(args, world, elapsed, traced, rep, eng, collective):
             "peak": PEAK_FP32_MFMA_TFLOPS,
             "unit": "TFLOP/s",
             "frac": round(achieved / exec_div / PEAK_FP32_MFMA_TFLOPS, 4),
+            # the same launches against the peak AT THE CLOCK THEY RAN AT (64 FLOP/clk/SIMD x 1024 SIMDs x measured MHz): what the kernel
+            # makes of the cycles it is given; `frac` additionally carries the box's clock / power state
+            "frac_at_clock": frac_at_clock,
+            "clock_mhz": mhz_traced,
             "flop_per_launch": flop_per_launch / exec_div,
             "flop_definition": ("executed: the Winograd F(2x2,3x3) form issues 16 MFMA multiplications per 2x2 output tile and channel pair instead "
                                 "of 36 = direct / 2.25, on whole 16x8-pixel regions") if wino else "direct form: every algorithmic FLOP is an MFMA FLOP",
@@ -796,6 +946,7 @@ def result_line(args, world, elapsed, traced, rep, eng, collective):
             },
             "traced_ms_per_step": round(traced / K * 1e3, 3),
         },
+        "clock": clock_obj,
         "roofline_hbm": roofline_hbm,
         "conv_tflops_whole_net": round(conv_flop * B * K / elapsed / 1e12, 3),
         "kernels": kernels,
@@ -810,9 +961,10 @@ def extras_watchdog(res, rank, deadline_s):
 
     def bail():
         if rank == 0 and res is not None:
+            res["incomplete"] = True
             res.setdefault("notes", []).append(f"legs after the timed region did not finish within {deadline_s:.0f} s; line printed by the watchdog")
             print(json.dumps(res), flush=True)
-        os._exit(0)
+        os._exit(0)      # the headline line above is valid and complete; `"incomplete": true` in it says that later legs are missing
 
     t = threading.Timer(deadline_s + (0.0 if rank == 0 else 5.0), bail)   # rank 0 first, so its line is out before peers drop
     t.daemon = True
@@ -828,7 +980,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="frame pairs per step per GPU (1..32)")
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle's timing (one forward still runs for the parity gate)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the in-run parity gate (and with it every oracle forward): profiling passes only")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive node leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the FILM / M2M device-resident numbers")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather of new frames")
@@ -842,7 +995,7 @@ def main():
     ap.add_argument("--strong-height", type=int, default=2160)
     ap.add_argument("--strong-width", type=int, default=3840)
     ap.add_argument("--strong-frames", type=int, default=17)
-    ap.add_argument("--strong-reps", type=int, default=2)
+    ap.add_argument("--strong-reps", type=int, default=3)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) | gloo (plumbing test on one GPU)")
     ap.add_argument("--device-threads", action="store_true",
                     help="route --gpus 1 through the one-process / device-thread path too (what --gpus N > 1 uses without a launcher)")
@@ -905,7 +1058,18 @@ def main():
     # (seed + rank for N>1)
     n_clip = clip_frames(B)
     g = torch.Generator(device="cpu").manual_seed(rank)
-    raw = torch.rand((n_clip, H, W, 3), generator=g, dtype=torch.float32).to(dev)
+    raw_host = torch.rand((n_clip, H, W, 3), generator=g, dtype=torch.float32)
+    raw = raw_host.to(dev)
+    # The oracle on the pair the parity check will look at — task 0 of the LAST timed step — run BEFORE the GPU leg on the identical
+    # tensors; at N = 1 the same forwards are the cpu_baseline sample.
+    par_base = clip_base(B, (K - 1) & 1)
+    cpu_base, oracle_frame = None, None
+    if rank == 0 and not args.no_parity:
+        try:
+            cpu_base, oracle_frame = cpu_baseline(sd, raw_host[par_base], raw_host[par_base + 1], timing=(world == 1 and not args.no_cpu_baseline))
+        except Exception as e:  # noqa: BLE001  (the line then says so: parity.error)
+            cpu_base, oracle_frame = {"error": f"{type(e).__name__}: {e}"}, None
+    del raw_host
     outs = [torch.empty((B, H, W, 3), dtype=torch.float32, device=dev) for _ in range(2)]
     gathered = [torch.empty((world * B, H, W, 3), dtype=torch.float32, device=dev) for _ in range(2)] \
         if world > 1 and not args.no_gather and args.backend == "nccl" else None
@@ -970,27 +1134,58 @@ def main():
             reserve_trials[cand] = float(t.item()) / 3
         reserve = min(reserve_trials, key=lambda c: (reserve_trials[c], c))
         _lib.check(_lib.load().vfi_set_reserved_cus(reserve), "vfi_set_reserved_cus")
-    elapsed = timed(K)
+    # the timed region, with the clock probe installed (workgroup 0 of every Winograd launch stamps two counters: no launch, no sync,
+    # no extra kernel) and a side thread reading sclk / power from sysfs where the box has them
+    clock = {}
+    probe = None
+    try:
+        probe = ClockProbe(dev, K * 40 + 8)
+    except Exception as e:  # noqa: BLE001
+        clock["error"] = f"{type(e).__name__}: {e}"
+    with SysfsSampler(local_rank % ndev) as sampler:
+        elapsed = timed(K)
+    clock["sysfs"] = sampler.summary()
+    if probe is not None:
+        clock["timed"] = clock_summary(probe.finish(), "resconv_c64")
+    last_frame = outs[(K - 1) & 1][0].cpu() if rank == 0 and oracle_frame is not None else None      # frame 0 of the LAST timed step
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- roofline leg: same K steps with per-kernel HIP events recorded on the launch stream
+    # ---- roofline leg: same K steps with per-kernel HIP events recorded on the launch stream (and the clock probe again: the
+    # event durations and the clock then belong to the same launches)
     lib = _lib.load()
+    try:
+        probe = ClockProbe(dev, K * 40 + 8)
+    except Exception:  # noqa: BLE001
+        probe = None
     lib.vfi_trace_reset()
     lib.vfi_trace_enable(1)
     traced = timed(K)
     lib.vfi_trace_enable(0)
     rep = _lib.trace_report()
     lib.vfi_trace_reset()
+    if probe is not None:
+        clock["traced"] = clock_summary(probe.finish(), "resconv_c64")
     lib.vfi_set_reserved_cus(0)       # the later legs gather after their compute, not beside it
 
     res = None
     if rank == 0:
         res = result_line(args, world, elapsed, traced, rep, eng,
                           "none" if world == 1 or args.no_gather else
-                          ("all_gather(RCCL), overlapped" if gathered is not None else "all_gather(gloo, host)"))
+                          ("all_gather(RCCL), overlapped" if gathered is not None else "all_gather(gloo, host)"), clock=clock)
+        # ---- in-run parity gate: the timed workload itself against the oracle (per-pixel fp32 |d| <= 1e-3, north_star)
+        if args.no_parity:
+            res["parity"] = {"skipped": "--no-parity"}
+        elif oracle_frame is None:
+            res["parity"] = {"ok": False, "error": (cpu_base or {}).get("error", "no oracle frame")}
+        else:
+            res["parity"] = parity_of(last_frame, oracle_frame)
+            res["parity"]["what"] = (f"frame 0 of the last timed step (pair = clip frames {par_base}, {par_base + 1}, t = 0.5, one of {B} tasks of the launch) vs "
+                                     f"oracle.rife_oracle.ifnet47_forward on the same host tensors, all {H}x{W}x3 values")
+        if cpu_base is not None and "error" not in cpu_base:
+            res["cpu_baseline"] = cpu_base
         res["config"]["launch"] = "one process per GPU (torch.distributed)" if world > 1 else "one process, one GPU"
         if world > 1:
             res["config"]["reserved_cus"] = reserve
@@ -1000,6 +1195,7 @@ def main():
     # The headline is measured; every later leg is extra.  A leg that RAISES is recorded as an error string; a leg that STALLS
     # (a collective whose peer died) cannot be recovered from inside the process, so a watchdog prints the headline line as it
     # stands and ends the rank instead of losing it to the launcher's timeout.
+    parity_failed = False
     guard = extras_watchdog(res, rank, args.extras_deadline) if world > 1 else None
     strong = None
     if not args.no_strong:       # every rank takes part (strong scaling over the ranks)
@@ -1033,12 +1229,13 @@ def main():
                 res["e2e"] = e2e_leg(sd, dev, H, W)
             if not args.no_extras:
                 res["other_paths"] = other_paths(dev, H, W)
-            if not args.no_cpu_baseline:
-                res["cpu_baseline"] = cpu_baseline(sd, H, W)
         print(json.dumps(res), flush=True)
+        parity_failed = not res.get("parity", {}).get("ok", True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and parity_failed:
+        raise SystemExit("bench.py: the timed workload does not match the oracle within 1e-3 (see `parity` in the line above)")
 
 
 if __name__ == "__main__":

@@ -22,6 +22,8 @@ PROTOTYPES = {
     "vfi_trace_enable": (C.c_int, [C.c_int]),
     "vfi_trace_reset": (C.c_int, []),
     "vfi_trace_report": (C.c_int, [C.c_char_p, C.c_int]),
+    "vfi_clock_probe": (C.c_int, [C.c_void_p, C.c_int]),
+    "vfi_clock_probe_names": (C.c_int, [C.c_char_p, C.c_int]),
     "vfi_warp_border": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vfi_conv3x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
@@ -32,6 +34,7 @@ PROTOTYPES = {
     "vfi_test_pack_deconv3x3": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64]),
     "vfi_test_set_option": (C.c_int, [C.c_char_p, C.c_int64]),
     "vfi_test_variant_override": (C.c_int, [C.c_char_p]),
+    "vfi_test_wino_probe_read": (C.c_int, [C.POINTER(C.c_uint32)]),
     "vfi_deconv4x4_ps2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_void_p]),
     "vfi_conv_create": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
@@ -230,6 +233,14 @@ def stream_ptr():
     import torch
 
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def clock_probe_names():
+    buf = C.create_string_buffer(1 << 18)
+    n = load().vfi_clock_probe_names(buf, len(buf))
+    if n < 0:
+        raise RuntimeError(f"vfi_clock_probe_names failed: {last_error()}")
+    return buf.value.decode().splitlines()
 
 
 def trace_report():

@@ -32,6 +32,11 @@
 
 #include <atomic>
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "../../include/vfi_hip.h"
+#include "../../include/vfi_hip_test.h"
 
 namespace vfi {
 
@@ -50,7 +55,21 @@ struct WinoArgs {
     float inv_NY, inv_per, inv_rx;   // 1 / NY, 1 / (rx * ry), 1 / rx: the work decode divides by multiplication (see wino_div)
     int LO;                          // SHUF epilogue: channels per parity group (Cout / 4) and
     float inv_LO;                    //   its reciprocal (an integer division in the epilogue keeps a hoisted reciprocal alive — spilled — through the K loop)
+    int clk_tag;                     // clock probe: the host's index of this launch (read at the kernel's first instructions only)
 };
+
+// Clock probe state of the device (vfi_clock_probe): record buffer, capacity, next free record.  Device globals, not kernel arguments:
+// a pointer argument that is used again at the kernel's end stays live through the K loop and cost nine more spilled SGPRs there.
+__device__ unsigned long long* g_clk_buf_dev = nullptr;
+__device__ unsigned g_clk_cap_dev = 0, g_clk_next_dev = 0;
+constexpr int kClkRecWords = 8;      // u64 per record: t0, r0, t1, r1, tag, 0, 0, 0 (one 64-byte line)
+
+// Cycle ledger of the K loop (test option wino_probe, docs/design/winograd.md "cycle ledger"): the PROBE instantiations of the hot kernel
+// sum s_memtime stamps (mod 2^32) taken at fixed points of every chunk / item by the waves of workgroup 0; differences of the sums are
+// the cycles spent between the points.  Each stamp is consumed at the NEXT point where the loop waits lgkmcnt(0) anyway (s_memtime
+// returns through lgkmcnt, out of order with LDS reads: consuming it earlier would add a full LDS drain to the thing being measured),
+// and one PROBE value takes at most four stamps per chunk (SGPR pressure).  [wave][0..7] sums, written at the kernel's end.
+__device__ unsigned g_wino_probe_out[4][8];
 
 template <int RTX>
 struct WinoGeom {
@@ -66,7 +85,7 @@ struct WinoGeom {
     static constexpr int TAB_FLOATS = 4 * NA * 64;       // per wave: the DMA cursor's NA byte offsets per lane (kept in LDS, not in VGPRs)
     static constexpr int NBUF = 3;                       // LDS chunk buffers: the DMA queue runs two chunks ahead of the MFMAs
     static constexpr int MAXCO = 1024;                   // output channels whose epilogue constants (bias, beta, PReLU slope) sit in LDS
-    static constexpr int LDS_BYTES = (NBUF * BUF_FLOATS + TAB_FLOATS + 3 * MAXCO) * 4;
+    static constexpr int LDS_BYTES = (NBUF * BUF_FLOATS + TAB_FLOATS + 3 * MAXCO + 4) * 4;      // + the clock probe's record index
     static_assert(NITEM % 4 == 0 && PW % 2 == 0, "swizzle stays inside the image and inside a row");
 };
 
@@ -221,7 +240,7 @@ __device__ __forceinline__ void wino_epilogue(const f32x16 (&acc)[16], const Con
     }
 }
 
-template <int RTX, int MODE, int SHUF = 0>
+template <int RTX, int MODE, int SHUF = 0, int PROBE = 0>
 __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr bool EXT = MODE != 0;      // a general epilogue (wino_epilogue's MODE 10 + act): one kernel per activation, no switch in the item loop
@@ -234,6 +253,24 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int C8 = a.Cin_p >> 3;
     const int H = a.Hin, W = a.Win;
+    // clock probe: workgroup 0 stamps shader cycles + the constant-rate counter at its start (drained before the first LDS-DMA piece
+    // is issued: the K loop's vmcnt arithmetic counts DMA pieces only) and at its end
+    int* const clk_slot = (int*)(smem + G::NBUF * G::BUF_FLOATS + G::TAB_FLOATS + 3 * G::MAXCO);      // the record index waits in LDS
+    if (blockIdx.x == 0 && tid == 0) {
+        unsigned long long* const cb = g_clk_buf_dev;
+        int slot = -1;
+        if (cb) {
+            const unsigned sl = atomicAdd(&g_clk_next_dev, 1u);
+            if (sl < g_clk_cap_dev) {
+                slot = (int)sl;
+                cb[kClkRecWords * sl + 4] = (unsigned long long)p.clk_tag;
+                cb[kClkRecWords * sl + 1] = __builtin_amdgcn_s_memrealtime();
+                cb[kClkRecWords * sl + 0] = __builtin_amdgcn_s_memtime();
+            }
+        }
+        *clk_slot = slot;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     // Lane-derived address pieces are cheap to recompute and expensive to keep: 256 AGPRs hold the accumulators, the 256 VGPRs are
     // for the patch / operands.  LICM would hoist every lane-only expression out of the loops and then SPILL it (a scratch reload in
     // the hot loop waits vmcnt(0), i.e. for the LDS-DMA in flight): an opaque copy of the lane id per use keeps them local.
@@ -472,8 +509,19 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
         acc[(G_) * 4 + e_] = __builtin_amdgcn_mfma_f32_32x32x2f32(V_[(G_) * 4 + e_].C_, B_[G_][e_], acc[(G_) * 4 + e_], 0, 0, 0);
 #define WINO_A(I_) if ((I_) < NA) issue_a(drsrc, (I_), avp[(I_) < NA ? (I_) : 0], d_k, buf)
 #define WINO_B(I_) issue_b(dwrsrc, (I_), dcur.nb, d_k, buf)
+        // PROBE: sums of stamps (see g_wino_probe_out).  1: q0 / q1 = before / after sub-step 1's vmcnt wait.  2: q0 / q1 = before sub-step 3's
+        // wait / after its barrier.  4: q0..q3 = the starts of sub-steps 0..3.  3: q0..q3 = item start, K loop start, K loop end, epilogue end.
+        unsigned q0 = 0, q1 = 0, q2 = 0, q3 = 0, qn = 0;
+        unsigned long long sa = 0, sb = 0, sc = 0, sd = 0;
+#define WINO_STAMP(COND_, V_)                                    \
+    if (PROBE != 0 && (COND_)) {                                 \
+        __builtin_amdgcn_sched_barrier(0);                       \
+        V_ = __builtin_amdgcn_s_memtime();                       \
+        __builtin_amdgcn_sched_barrier(0);                       \
+    }
         unsigned gchunk = 0;                 // chunk counter of this workgroup's stream: LDS buffer = gchunk % 3
         for (int it = 0; item(it, ccur); ++it) {
+            WINO_STAMP(PROBE == 3, sa);
             // An item starts from LDS (nothing but the accumulators crosses the previous item's epilogue): its first chunk landed and
             // became visible in the previous chunk's sub-steps 1 / 3 (or the prologue).
             lane16 = opaque_lane() * 16;
@@ -487,9 +535,11 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
                 for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
             tf1(0);
             tf2(VA);
+            WINO_STAMP(PROBE == 3, sb);
             for (int k = 0; k < C8; ++k, ++gchunk) {
                 const int buf = (int)(gchunk % G::NBUF), nbuf = buf == G::NBUF - 1 ? 0 : buf + 1;
                 // ---- sub-step 0
+                WINO_STAMP(PROBE == 4, sa);
                 WINO_MF4(0, VA, x, Be);
                 read_b(buf, 1, Bo);
                 load_avoff(avp);
@@ -503,7 +553,10 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
                 pk_bases(nbuf);
                 // ---- sub-step 1
                 __builtin_amdgcn_sched_barrier(0);
+                WINO_STAMP(PROBE == 1, sa);
+                WINO_STAMP(PROBE == 4, sb);
                 __builtin_amdgcn_s_waitcnt(wino_waitcnt(W1, 15));
+                WINO_STAMP(PROBE == 1, sb);
                 WINO_MF4(0, VA, y, Bo);
                 read_b(buf, 2, Be);
                 read_patch_row(0);
@@ -517,6 +570,7 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
                 read_patch_row(3);
                 WINO_A(4);
                 // ---- sub-step 2
+                WINO_STAMP(PROBE == 4, sc);
                 WINO_MF4(0, VB, x, Be);
                 read_b(buf, 3, Bo);
                 WINO_A(5);
@@ -528,8 +582,15 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
                 WINO_A(6);
                 // ---- sub-step 3
                 __builtin_amdgcn_sched_barrier(0);
+                if (PROBE == 2) { q1 += (unsigned)sb; }      // the previous chunk's "after the barrier" (0 before the first: sb starts at 0)
+                WINO_STAMP(PROBE == 2, sa);
+                WINO_STAMP(PROBE == 4, sd);
                 __builtin_amdgcn_s_waitcnt(wino_waitcnt(W3, 0));
                 __builtin_amdgcn_s_barrier();
+                if (PROBE == 1) { q0 += (unsigned)sa; q1 += (unsigned)sb; ++qn; }
+                if (PROBE == 2) { q0 += (unsigned)sa; ++qn; }
+                if (PROBE == 4) { q0 += (unsigned)sa; q1 += (unsigned)sb; q2 += (unsigned)sc; q3 += (unsigned)sd; ++qn; }
+                WINO_STAMP(PROBE == 2, sb);
                 WINO_MF4(0, VB, y, Bo);
                 read_b(nbuf, 0, Be);
                 WINO_B(0);
@@ -547,6 +608,7 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
                 dma_advance();
             }
         // ---- epilogue: Y = A^T M A per tile in registers, + bias, * beta, (+ residual), activation, NHWC store
+            WINO_STAMP(PROBE == 3, sc);
             if (ccur.valid) {
                 const int ole = opaque_lane();
                 const int half = ole >> 5;
@@ -557,16 +619,63 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
                 else
                     wino_epilogue<RTX, MODE, false, SHUF>(acc, a, ccur.n, ccur.Ry0, ccur.Rx0, co, coc, half, cst[co], cst[G::MAXCO + co], cst[2 * G::MAXCO + co], p.LO, p.inv_LO);
             }
+            if (PROBE == 3) {
+                WINO_STAMP(true, sd);
+                q0 += (unsigned)sa, q1 += (unsigned)sb, q2 += (unsigned)sc, q3 += (unsigned)sd, ++qn;
+            }
         }
+        if (PROBE != 0 && blockIdx.x == 0) {
+            if (PROBE == 2) q1 += (unsigned)sb;      // the last chunk's
+            unsigned long long tend = __builtin_amdgcn_s_memtime();
+            const int l = opaque_lane();
+            if (l < 8) {
+                const unsigned v = l == 0 ? q0 : l == 1 ? q1 : l == 2 ? q2 : l == 3 ? q3 : l == 4 ? qn : l == 5 ? (unsigned)tend : l == 6 ? (unsigned)gchunk : (unsigned)PROBE;
+                g_wino_probe_out[wave][l] = v;
+            }
+        }
+#undef WINO_STAMP
 #undef WINO_MF4
 #undef WINO_A
 #undef WINO_B
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the tail's dummy pieces write (zeros) into this workgroup's LDS: drain before exit
+    if (blockIdx.x == 0) {
+        __builtin_amdgcn_s_barrier();      // the workgroup's last wave is the launch's end (workgroup 0 takes items to the last round)
+        if (tid == 0 && *clk_slot >= 0) {
+            unsigned long long* const cb = g_clk_buf_dev + kClkRecWords * *clk_slot;
+            cb[2] = __builtin_amdgcn_s_memtime();
+            cb[3] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
 #endif
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------
+// ---- shader-clock probe ----------------------------------------------------------------------------------------------------------
+static std::mutex g_clk_mu;
+static std::vector<const char*> g_clk_names;
+static std::atomic<bool> g_clk_on{false};
+int clock_probe_tag(const char* name) {
+    if (!g_clk_on.load(std::memory_order_acquire)) return -1;
+    std::lock_guard<std::mutex> lk(g_clk_mu);
+    g_clk_names.push_back(name);
+    return (int)g_clk_names.size() - 1;
+}
+
+int wino_probe_read(unsigned* out32) {      // [4 waves][8]: the sums of the LAST probed launch on the current device
+    VFI_CHECK_HIP(hipDeviceSynchronize());
+    VFI_CHECK_HIP(hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_wino_probe_out), 32 * sizeof(unsigned)));
+    return 0;
+}
+
+int clock_probe_install(unsigned long long* dev_records, int capacity) {      // on the CURRENT device
+    const unsigned cap = dev_records ? (unsigned)capacity : 0u, zero = 0u;
+    VFI_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_clk_next_dev), &zero, sizeof(zero)));
+    VFI_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_clk_cap_dev), &cap, sizeof(cap)));
+    VFI_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_clk_buf_dev), &dev_records, sizeof(dev_records)));
+    return 0;
+}
+
 // U = G g G^T per (co, ci), laid out [Cout_p/32][Cin_p/8][j][xi/4][half][co%32][xi%4]; physical input channel
 // pc = c8 * 8 + half * 4 + j.  chan_map translates logical to physical input channels (concat windows), nullptr = identity.
 void pack_wino3x3(const float* w_oihw, int Cout, int Cin, const int* chan_map, int Cin_p, int Cout_p, std::vector<float>& wp) {
@@ -650,7 +759,7 @@ bool conv_wino_eligible(const ConvArgs& a) {
     return regions / 4 * (a.Cout_p / 32) >= 192;
 }
 
-template <int RTX, int MODE, int SHUF = 0>
+template <int RTX, int MODE, int SHUF = 0, int PROBE = 0>
 static int wino_launch_t(WinoArgs& p, hipStream_t s, const char* name) {
     using G = WinoGeom<RTX>;
     ConvArgs& a = p.a;
@@ -668,7 +777,7 @@ static int wino_launch_t(WinoArgs& p, hipStream_t s, const char* name) {
     VFI_REQUIRE(dev >= 0 && dev < kMaxDevices, "conv_wino %s: device index %d out of range", name, dev);
     static std::atomic<int> attr_set[kMaxDevices];
     if (!attr_set[dev].load(std::memory_order_acquire)) {
-        VFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<RTX, MODE, SHUF>),
+        VFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<RTX, MODE, SHUF, PROBE>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
         attr_set[dev].store(1, std::memory_order_release);
     }
@@ -677,8 +786,9 @@ static int wino_launch_t(WinoArgs& p, hipStream_t s, const char* name) {
     int grid = (int)(items < cus ? items : cus);
     grid = round_up(grid, 8);
     p.xcd_map = option(kOptWinoXcd) ? 1 : 0;
+    p.clk_tag = clock_probe_tag(name);
     TraceScope ts(name, s);
-    hipLaunchKernelGGL((conv_wino_kernel<RTX, MODE, SHUF>), dim3(grid), dim3(256), G::LDS_BYTES, s, p);
+    hipLaunchKernelGGL((conv_wino_kernel<RTX, MODE, SHUF, PROBE>), dim3(grid), dim3(256), G::LDS_BYTES, s, p);
     VFI_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -720,6 +830,15 @@ int conv_wino_launch(const ConvArgs& a, int variant, hipStream_t s, const char* 
         VFI_REQUIRE(!a.res && a.Cout % 4 == 0 && mode == 0, "conv_wino %s: the transposed-convolution form takes none / LeakyReLU only", name);
         return wino_launch_t<8, 0, 2>(p, s, name);
     }
+    if (variant == 8 && mode == 0) {      // the hot instantiation's cycle-ledger forms (test option wino_probe; same results, + stamps)
+        switch ((int)option(kOptWinoProbe)) {
+            case 1: return wino_launch_t<8, 0, 0, 1>(p, s, name);
+            case 2: return wino_launch_t<8, 0, 0, 2>(p, s, name);
+            case 3: return wino_launch_t<8, 0, 0, 3>(p, s, name);
+            case 4: return wino_launch_t<8, 0, 0, 4>(p, s, name);
+            default: break;
+        }
+    }
 #define WINO_DISPATCH(R_)                                              \
     switch (mode) {                                                    \
         case 0: return wino_launch_t<R_, 0>(p, s, name);               \
@@ -738,3 +857,35 @@ int conv_wino_launch(const ConvArgs& a, int variant, hipStream_t s, const char* 
 }
 
 }  // namespace vfi
+
+using namespace vfi;
+
+extern "C" {
+
+int vfi_clock_probe(void* dev_records, int capacity) {
+    VFI_REQUIRE(capacity >= 0 && (dev_records || capacity == 0), "vfi_clock_probe: bad arguments");
+    std::lock_guard<std::mutex> lk(g_clk_mu);
+    const bool on = dev_records != nullptr && capacity > 0;
+    if (clock_probe_install(on ? (unsigned long long*)dev_records : nullptr, on ? capacity : 0) != 0) return -1;
+    if (on) g_clk_names.clear();       // (uninstalling keeps the names: they are read after the measured region)
+    g_clk_on.store(on, std::memory_order_release);
+    return 0;
+}
+
+int vfi_clock_probe_names(char* buf, int buf_len) {
+    std::lock_guard<std::mutex> lk(g_clk_mu);
+    std::string out;
+    for (const char* n : g_clk_names) {
+        out += n ? n : "?";
+        out += "\n";
+    }
+    VFI_REQUIRE(buf && (int)out.size() + 1 <= buf_len, "vfi_clock_probe_names: buffer too small (%d needed)", (int)out.size() + 1);
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return (int)g_clk_names.size();
+}
+
+int vfi_test_wino_probe_read(uint32_t* out32) {
+    VFI_REQUIRE(out32, "vfi_test_wino_probe_read: null buffer");
+    return wino_probe_read(out32);
+}
+}  // extern "C"

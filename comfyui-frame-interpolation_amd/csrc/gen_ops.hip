@@ -304,7 +304,10 @@ vfi_conv_t* vfi_conv_create_ex(int kind, const float* w_host, const float* bias_
         for (int co = 0; co < Cout; ++co) pp[co] = prelu_host[co];
         ok = upload(&c->prelu, pp);
     }
-    if (ok && kind == 1 && 4 * Cout <= 1024) {
+    // the transposed convolution's 3x3 / Winograd form (4x the U-transform weight memory): packed only for layers that can ever take it —
+    // vfi_conv_forward_ex sends per-channel-PReLU layers (general epilogue: slower than the grouped direct kernel, conv_wino.hip) and
+    // replicate-padded ones to the direct kernel whatever the image
+    if (ok && kind == 1 && 4 * Cout <= 1024 && !prelu_host && !pad_mode) {
         std::vector<float> w3, b3, ww;
         pack_deconv_as_conv3x3(w_host, bias_host, Cin, Cout, w3, b3);
         c->Cout3_p = round_up(4 * Cout, 32);

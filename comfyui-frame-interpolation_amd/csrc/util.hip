@@ -28,7 +28,7 @@ const char* get_error() { return g_err; }
 // ---- A/B options (vfi_common.h: enum Option) ---------------------------------------------------------------------------------
 static const struct { const char* name; long dflt; } kOptTable[kOptCount] = {
     {"stage_quad", 14}, {"fuse_encode", 1}, {"fuse0a", 1}, {"m2n2_px", -1}, {"grouped_variant", -1}, {"splitk", 1},
-    {"splat_atomic", 0}, {"splat_spill_cap", -1}, {"wino_xcd", 1}, {"deconv_wino", 1}, {"encode_batched", 1},
+    {"splat_atomic", 0}, {"splat_spill_cap", -1}, {"wino_xcd", 1}, {"deconv_wino", 1}, {"encode_batched", 1}, {"wino_probe", 0},
 };
 static std::atomic<long> g_opt[kOptCount];
 static std::atomic<bool> g_opt_init{false};
@@ -108,6 +108,7 @@ void trace_end(hipStream_t s) {
     if (!g_recs.empty()) (void)hipEventRecord(g_recs.back().e1, s);
 }
 
+
 }  // namespace vfi
 
 using namespace vfi;
@@ -161,16 +162,23 @@ int vfi_get_reserved_cus(void) { return g_reserved_cus.load(std::memory_order_re
 int vfi_memcpy_async(void* dst, const void* src, int64_t bytes, int kind, void* stream) {
     VFI_REQUIRE(dst && src && bytes >= 0 && (kind == 1 || kind == 2 || kind == 3), "vfi_memcpy_async: bad arguments (kind %d)", kind);
     if (bytes == 0) return 0;
-    if (stream) {       // worker threads never chose a device: the copy must be issued with the stream's device current
+    // worker threads never chose a device: the copy must be issued with the stream's device current.  The caller's current device is
+    // restored afterwards (a public entry point must not leave a side effect on the calling thread — ADVICE r4; comm.hip's DeviceScope)
+    int cur = -1, sdev_i = -1;
+    if (stream) {
         hipDevice_t sdev = 0;
-        int cur = 0;
-        if (hipStreamGetDevice((hipStream_t)stream, &sdev) != hipSuccess || hipGetDevice(&cur) != hipSuccess)
+        if (hipStreamGetDevice((hipStream_t)stream, &sdev) != hipSuccess || hipGetDevice(&cur) != hipSuccess) {
             (void)hipGetLastError();      // (only these queries' own failure is read away: the copy below then reports what is wrong with the stream)
-        else if (cur != (int)sdev)
-            VFI_CHECK_HIP(hipSetDevice((int)sdev));
+            cur = -1;
+        } else if (cur != (int)sdev) {
+            sdev_i = (int)sdev;
+            VFI_CHECK_HIP(hipSetDevice(sdev_i));
+        }
     }
-    VFI_CHECK_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, kind == 1 ? hipMemcpyHostToDevice : (kind == 2 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice),
-                                 (hipStream_t)stream));
+    const hipError_t ce = hipMemcpyAsync(dst, src, (size_t)bytes, kind == 1 ? hipMemcpyHostToDevice : (kind == 2 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice),
+                                         (hipStream_t)stream);
+    if (sdev_i >= 0 && cur >= 0) (void)hipSetDevice(cur);
+    VFI_CHECK_HIP(ce);
     return 0;
 }
 

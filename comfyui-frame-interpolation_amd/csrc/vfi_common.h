@@ -44,6 +44,15 @@ struct TraceScope {
     }
 };
 
+// ---- shader-clock probe (vfi_clock_probe) -------------------------------------------------------------------------------------
+// While a probe buffer is installed, every launch of the Winograd kernel takes one record (8 x u64, conv_wino.hip): workgroup 0 stamps
+// s_memtime (shader cycles) and s_memrealtime (constant-rate counter) when it starts and when it ends.  The ratio of the two deltas is
+// the clock the chip actually sustained while THIS kernel ran (it clocks to its power budget: 1.9-2.3 GHz under MFMA load,
+// MI355X_MICROARCH.md "DVFS give-back").  clock_probe_tag: the host's index of the launch (its trace name is kept under it), -1 = off.
+int clock_probe_tag(const char* name);
+int clock_probe_install(unsigned long long* dev_records, int capacity);      // conv_wino.hip: the device-side state, current device
+int wino_probe_read(unsigned* out32);                                         // conv_wino.hip: [4][8] stamp sums of the last probed launch
+
 // ---- A/B options of tools/ and tests/ (include/vfi_hip_test.h: vfi_test_set_option) ----------------------------------------
 // Every option selects between two CORRECT forms of a kernel or launch (fused / unfused, tile variant, ...).  They are set through
 // the test C entry point only — the product library reads NO experiment switch from the environment, so a stray variable cannot
@@ -60,6 +69,7 @@ enum Option {
     kOptWinoXcd,         // 1: XCD-aware work order of the Winograd kernel (default), 0: plain order
     kOptDeconvWino,      // 1: ConvTranspose2d(4, 2, 1) + PixelShuffle (RIFE lastconv) as a 96-channel 3x3 layer on the Winograd kernel (default), 0: grouped direct kernel
     kOptEncodeBatched,   // 1: one frame-pack launch for a batch of frames where the caller offers one (default), 0: one launch per frame
+    kOptWinoProbe,       // 1..4: the hot Winograd instantiation takes its cycle-ledger form (conv_wino.hip: g_wino_probe_out; default 0)
     kOptCount
 };
 long option(Option o);

@@ -316,6 +316,17 @@ def run_tasks(engine, frames_cpu, tasks, batch_size, scale_factor=1.0, out_devic
             last_use[f] = bi
     if len(order) != len(set(order)):
         raise AssertionError("frame listed twice in the upload order")
+    # A frame keeps its device slot from its pack to the last launch that reads it (uploaded once, never evicted).  For the task lists
+    # this package builds — sorted by pair — at most 2 * bs + 1 frames are alive at a launch; a list that revisits old pairs can need
+    # more than the slot pool holds, and must be told so before any work is queued rather than by a failed assertion in the loop.
+    first_use = {}
+    for bi, (_, _, need) in enumerate(batches):
+        for f in need:
+            first_use.setdefault(f, bi)
+    alive = max((sum(1 for f in order if first_use[f] <= bi <= last_use[f]) for bi in range(len(batches))), default=0)
+    if alive > n_slots - PACK_AHEAD:
+        raise ValueError(f"run_tasks: {alive} frames are alive at one launch but the frame cache holds {n_slots - PACK_AHEAD} (+ {PACK_AHEAD} packed ahead); "
+                         f"pass the tasks sorted by pair (schedule.rife_task_list order) or a smaller batch_size")
     slots = _FrameSlots(n_slots)
     up = Uploader(frames_cpu, order, dev, main, depth=min(len(order), 2 * bs + 2 + PACK_AHEAD) or 1, on_staged=on_staged,
                   staged_after=min(len(order), len(dict.fromkeys(batches[0][2]))) if batches else 0)
@@ -550,13 +561,16 @@ class RIFE_VFI:
         # ahead of the copies that fill it
         # (starting them only after the first launch was tried: the GPU starts 8 ms earlier and the call ends 15 ms later —
         # the downloads then wait for pages)
-        passthrough, started = [], threading.Event()
+        passthrough, started, start_lock = [], [False], threading.Lock()
 
         def start_host_side():      # first touch of the output + pass-through copies: ~200 ms of host-thread time on a 33-frame 1080p clip
-            if not started.is_set():
-                started.set()
-                passthrough.extend(prefault_async(out))
-                passthrough.extend(copy_rows_async(out, src_rows, frames, src_idx))
+            # called from an uploader worker (on_staged) AND from this thread after the launch loop: test-and-set and the submissions under
+            # one lock, so the work is submitted exactly once and whoever comes second returns only after `passthrough` is complete
+            with start_lock:
+                if not started[0]:
+                    started[0] = True
+                    passthrough.extend(prefault_async(out))
+                    passthrough.extend(copy_rows_async(out, src_rows, frames, src_idx))
 
         batch_size = effective_batch(batch_size, frames.shape[1], frames.shape[2], len(tasks))
         rank, ws = world()

@@ -40,6 +40,18 @@ int vfi_trace_enable(int on);
 int vfi_trace_reset(void);
 int vfi_trace_report(char* buf, int buf_len);
 
+/* Shader-clock probe (bench.py `clock`, `roofline.frac_at_clock`).  The chip clocks to its power budget, so a launch duration alone
+ * cannot tell a slower kernel from a slower box.  While a buffer is installed, every launch of the dominant (Winograd 3x3) kernel is
+ * given one record of 8 x uint64 in it — { t0 = s_memtime at start, r0 = s_memrealtime at start, t1, r1 at end, tag, 0, 0, 0 } of
+ * workgroup 0 (persistent: it lives as long as the launch) — until `capacity` records are used.  s_memtime ticks at the shader clock,
+ * s_memrealtime at a constant rate (100 MHz; bench.py checks it against the HIP-event duration of the same launches):
+ *   sustained MHz of launch i = (t1 - t0) / (r1 - r0) x 100.
+ * dev_records: buffer of capacity * 8 uint64 on the CURRENT device, zeroed by the caller; NULL / 0 uninstalls (the names stay
+ * readable).  vfi_clock_probe_names writes the trace names of the probed launches, one per line; line `tag` names record `tag`;
+ * returns their count (< 0 on error). */
+int vfi_clock_probe(void* dev_records, int capacity);
+int vfi_clock_probe_names(char* buf, int buf_len);
+
 /* ---- single-op entry points (parity tests, reuse by other nodes) ----------------------- */
 
 /* RIFE backward warp: bilinear, padding_mode="border", align_corners=True, in the reference's

@@ -36,10 +36,15 @@ int64_t vfi_test_pack_deconv3x3(const float* weight_host, const float* bias_host
 
 /* A/B options of tools/ and tests/: each selects between two CORRECT forms of a kernel or launch (csrc/vfi_common.h, enum Option):
  *   stage_quad (bit mask, default 14), fuse_encode (1), fuse0a (1), m2n2_px (-1), grouped_variant (-1), splitk (1), splat_atomic (0),
- *   splat_spill_cap (-1), wino_xcd (1), deconv_wino (1), encode_batched (1).
+ *   splat_spill_cap (-1), wino_xcd (1), deconv_wino (1), encode_batched (1), wino_probe (0; 1..4 = the cycle-ledger forms of the hot
+ *   Winograd instantiation: same results, s_memtime stamps summed per wave of workgroup 0).
  * The product library reads NO experiment switch from the environment; this call is the only way to leave the defaults.
  * Returns 0, or -2 for an unknown name. */
 int vfi_test_set_option(const char* name, int64_t value);
+/* The stamp sums of the last launch made under wino_probe != 0 on the current device: [4 waves][8] uint32 = q0, q1, q2, q3 (sums mod
+ * 2^32 of the stamps the probe form takes, csrc/conv_wino.hip), stamps per sum, s_memtime at the wave's end, chunks, probe id.
+ * Synchronises the device.  tools/wino_ledger.py turns them into the cycle ledger of docs/design/winograd.md. */
+int vfi_test_wino_probe_read(uint32_t* out32);
 /* Force direct-conv tile variants by trace name: "conv0a_b3=42,resconv_c128=36"; NULL / "" clears (tools/variant_sweep.sh). */
 int vfi_test_variant_override(const char* spec);
 

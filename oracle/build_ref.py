@@ -15,8 +15,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 # NCHW shapes of tenIn (softsplat) / tenOne (costvol) the tests use
-SOFTSPLAT_SHAPES = [(1, 4, 64, 96), (2, 4, 50, 70), (2, 3, 33, 47), (8, 4, 128, 192), (1, 4, 272, 480)]
-COSTVOL_SHAPES = [(2, 32, 17, 30), (2, 32, 34, 60), (1, 32, 20, 24), (2, 32, 68, 120)]
+# (r5: + SURVEY 8d config 5's splat stress shape [1,4,1088,1920] and the two finest cost-volume levels of M2M at 1080p, so that every
+# level 17x30 ... 272x480 and the benchmarked splat size are checked against an execution of the reference's kernel text)
+SOFTSPLAT_SHAPES = [(1, 4, 64, 96), (2, 4, 50, 70), (2, 3, 33, 47), (8, 4, 128, 192), (1, 4, 272, 480), (1, 4, 1088, 1920)]
+COSTVOL_SHAPES = [(2, 32, 17, 30), (2, 32, 34, 60), (1, 32, 20, 24), (2, 32, 68, 120), (2, 32, 136, 240), (2, 32, 272, 480)]
 
 
 def main():

@@ -182,6 +182,9 @@ def main():
                 do_film(fr)
             if "m2m" in which:
                 do_m2m(fr)
+        # the goldens are bit-exact pins only on a host whose torch-CPU kernels are the ones that ran here (golden_stats.host_signature)
+        sig = golden_stats.write_host_signature(os.path.join(OUT, "bocchi1080_host.json"))
+        log(f"host signature {sig}: {golden_stats.host_signature()[1]}")
     finally:
         with open(LOG, "a") as f:
             f.write("\n".join(_lines) + "\n")

@@ -31,7 +31,7 @@ def test_watchdog_prints_headline_and_exits_on_rank0():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and "not reached" not in r.stdout
     d = json.loads(lines[0])
-    assert d["value"] == 1.0 and "watchdog" in d["notes"][0]
+    assert d["value"] == 1.0 and "watchdog" in d["notes"][0] and d["incomplete"] is True
 
 
 def test_watchdog_other_ranks_exit_quietly_and_cancel_works():

@@ -17,7 +17,7 @@ def header_functions(name="vfi_hip.h"):
 def test_header_and_binding_agree(hip_lib):
     product, taps = header_functions(), header_functions("vfi_hip_test.h")
     names = sorted(product + taps)
-    assert len(product) >= 15 and taps == ["vfi_conv3x3_naive", "vfi_film_debug_read_flow", "vfi_m2m_debug_read", "vfi_rife_debug_keep", "vfi_rife_debug_read", "vfi_test_conv_algo", "vfi_test_film_schedule", "vfi_test_linspace01", "vfi_test_pack_deconv3x3", "vfi_test_pack_wino3x3", "vfi_test_set_option", "vfi_test_variant_override"]   # test taps live apart
+    assert len(product) >= 15 and taps == ["vfi_conv3x3_naive", "vfi_film_debug_read_flow", "vfi_m2m_debug_read", "vfi_rife_debug_keep", "vfi_rife_debug_read", "vfi_test_conv_algo", "vfi_test_film_schedule", "vfi_test_linspace01", "vfi_test_pack_deconv3x3", "vfi_test_pack_wino3x3", "vfi_test_set_option", "vfi_test_variant_override", "vfi_test_wino_probe_read"]   # test taps live apart
     assert sorted(_lib.PROTOTYPES) == names
     for n in names:
         assert getattr(hip_lib, n) is not None

@@ -41,6 +41,14 @@ def test_single_gpu_line(hip_lib):
     assert any("micro-benchmark" in e["kernel"] and "error" not in e for e in op)
     cv = [e for e in op if e.get("bound") == "valu"][0]
     assert 0 < cv["frac"] <= 1.0 and cv["valu_floor_ms"] > 0
+    # r5: the line verifies itself — the timed workload against the oracle on identical tensors — and carries the shader clock
+    par = res["parity"]
+    assert par["ok"] and par["n_over_1e-3"] == 0 and 0 < par["max_abs"] <= 1e-3 and par["values"] == 272 * 480 * 3, par
+    ck = res["clock"]
+    assert ck and 500 < ck["shader_mhz"] <= 2500 and ck["launches"] >= 8 and ck["region"] == "timed region", ck
+    assert 30 <= ck["realtime_ticks_per_event_us"] <= 101, ck          # s_memrealtime = 100 MHz (workgroup 0 lives a little shorter than the launch)
+    assert rf["clock_mhz"] == ck["traced_pass_shader_mhz"] and 0 < rf["frac_at_clock"] <= 1.0
+    assert abs(rf["frac_at_clock"] * rf["clock_mhz"] / 2400.0 - rf["frac"]) < 2e-3
 
 
 def test_two_rank_line_shards_the_strong_leg(hip_lib):
@@ -51,6 +59,7 @@ def test_two_rank_line_shards_the_strong_leg(hip_lib):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     res = _line(r.stdout)
     assert res["n_gpus"] == 2 and res["scaling"] == "weak"
+    assert res["parity"]["ok"] and "cpu_baseline" not in res, res.get("parity")      # N > 1: the gate runs (one oracle forward on rank 0), the baseline does not
     st = res["strong_4k_x4"]
     assert st["tasks_per_rank"] == [5, 4] and st["n_gpus"] == 2 and st["value"] > 0, st
     # the reserve for an overlapped collective is chosen from untimed trials (planned, none, twice as many) and reported

@@ -80,7 +80,8 @@ def test_two_ranks_equal_single_process(hip_lib, tmp_path):
         for k, want in single.items():
             g = got[rank][k]
             assert g.shape == want.shape, (rank, k, g.shape, want.shape)
-            # same arithmetic per task; the conv tile variant (fp32 summation order) can depend on how many tasks share a
-            # launch, and the M2M splat accumulates with LDS atomics (order not fixed)
+            # same arithmetic per task whatever the sharding (kernel and tile choice depend on the image, never on how many tasks
+            # share a launch — batch invariance is asserted bit-exact elsewhere); the only order that is not fixed is the M2M splat's
+            # global-atomic spill pass, hence a rounding-level tolerance instead of torch.equal
             tol = 2e-5
             assert (g - want).abs().max().item() <= tol, (rank, k, (g - want).abs().max().item())

@@ -125,6 +125,35 @@ def test_hip_ops_vs_prebuilt_reference_kernels(lib):
         assert torch.equal(got, want), describe_diff(got, want, f"costvol {shp} (bit-exact expected)")
 
 
+def test_softsplat_config5_stress_field(lib):
+    """SURVEY 8(d) config 5 — the input bench.py's splat micro-benchmark times: in [1,4,1088,1920] U[0,1), flow i.i.d. N(0, 8 px),
+    torch seed 2 (cupy_ops/softsplat.py:140-192's stress case: an INCOHERENT field) — against the plain-C oracle AND, where
+    oracle/_ref holds the shape, against an execution of the reference's own kernel text."""
+    from oracle import ref_kernels as R
+
+    hp, wp = 1088, 1920
+    g = torch.Generator(device="cpu").manual_seed(2)
+    x = torch.rand(1, hp, wp, 4, generator=g)                     # exactly bench.py other_paths()'s tensors (NHWC)
+    fl = torch.randn(1, hp, wp, 2, generator=g) * 8.0
+    a = np.ascontiguousarray(x.numpy().transpose(0, 3, 1, 2))
+    f = np.ascontiguousarray(fl.numpy().transpose(0, 3, 1, 2))
+    got = _hip_splat(lib, a, f)
+    want = _nhwc(M.softsplat_sum(a, f))
+    tol = 1e-5 * max(1.0, want.abs().max().item())                # summation order of the scatter differs
+    assert (got - want).abs().max().item() <= tol, describe_diff(got, want, "config-5 splat vs C oracle")
+    # mass: every source lands with bilinear weights summing to 1 unless part of its footprint leaves the frame
+    assert got.double().sum().item() <= float(a.astype(np.float64).sum()) * (1 + 1e-6)
+    if R.available() and (1, 4, hp, wp) in [tuple(s_) for s_ in R.shapes("softsplat_out")]:
+        ref = _nhwc(R.softsplat_out(a, f))
+        assert (got - ref).abs().max().item() <= tol, describe_diff(got, ref, "config-5 splat vs the reference kernel text")
+        assert (want - ref).abs().max().item() <= tol      # and the C oracle agrees with the text it restates, at this size
+    # the far-displacement tail of the same benchmark family: sigma 64 px sends most sources beyond the list kernel's window
+    f64 = (f * 8.0).astype(np.float32)
+    got = _hip_splat(lib, a, f64)
+    want = _nhwc(M.softsplat_sum(a, f64))
+    assert (got - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item()), describe_diff(got, want, "sigma-64 splat vs C oracle")
+
+
 # ---- the list splat's side paths -------------------------------------------------------------------------------------
 def _smooth_flow(rng, n, h, w, amp, cells=6):
     import torch.nn.functional as F

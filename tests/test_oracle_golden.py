@@ -326,8 +326,10 @@ def test_rife_oracle_vs_reference_node_bocchi_1080p(golden_dir, tag, m, k):
     out = rife_oracle.rife_vfi(sd, _bocchi(golden_dir), multiplier=m)
     npz = np.load(os.path.join(golden_dir, "rife47_bocchi1080.npz"))
     fp = {f: npz[f"{tag}_x{m}_{k}/{f}"] for f in ("crops", "crop_pos", "pool_mean", "pool_max")}
-    d = golden_stats.check(out[k].numpy(), fp, tol=0.0, name=f"oracle vs reference node, RIFE 4.7 {tag} x{m}")
-    assert d[0] == 0.0 and d[2] == 0.0          # bit-exact on the crops and the block maxima
+    # bit-exact on the host that wrote the golden (signature beside it), cross-host spread of torch-CPU elsewhere (golden_stats.golden_tol)
+    tol = golden_stats.golden_tol(os.path.join(golden_dir, "bocchi1080_host.json"))
+    d = golden_stats.check(out[k].numpy(), fp, tol=tol, name=f"oracle vs reference node, RIFE 4.7 {tag} x{m}")
+    assert d[0] <= tol and d[2] <= tol
 
 
 def test_m2m_oracle_vs_reference_node_bocchi_1080p(golden_dir):
@@ -338,5 +340,6 @@ def test_m2m_oracle_vs_reference_node_bocchi_1080p(golden_dir):
     out = m2m_model_oracle.m2m_vfi(synth.m2m_synth_state_dict(1234), _bocchi(golden_dir), multiplier=2)
     npz = np.load(os.path.join(golden_dir, "m2m_bocchi1080.npz"))
     fp = {f: npz[f"default_x2_1/{f}"] for f in ("crops", "crop_pos", "pool_mean", "pool_max")}
-    d = golden_stats.check(out[1].numpy(), fp, tol=0.0, name="oracle vs reference node, M2M default x2")
-    assert d[0] == 0.0 and d[2] == 0.0
+    tol = golden_stats.golden_tol(os.path.join(golden_dir, "bocchi1080_host.json"))
+    d = golden_stats.check(out[1].numpy(), fp, tol=tol, name="oracle vs reference node, M2M default x2")
+    assert d[0] <= tol and d[2] <= tol

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 mkdir -p gpurun_out
 TAG=${1:-r01}
-CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-extras --no-strong"
+CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-e2e --no-extras --no-strong"
 run() {  # name, rocprof args...
   local name=$1; shift
   rm -rf gpurun_out/prof_$name
