@@ -41,8 +41,9 @@ Rank 0 prints ONE JSON line.  Extra objects:
                  (torch.manual_seed(0); torch.rand) through the node class RIFE_VFI.vfi to a host tensor, wall clock from the
                  call to the returned tensor (first H2D ... last D2H + host assembly), warm, median of 3; plus the measured
                  pinned H2D / D2H rates of this box.
-  other_paths  — device-resident ms per interpolated 1080p frame of FILM (configs[2]) and M2M (configs[4]), same box, same
-                 process (not the headline metric).
+  other_paths  — device-resident ms per interpolated 1080p frame of FILM (configs[2]) and M2M (configs[4]) and of the SURVEY 8(f)
+                 nodes (GMFSS Fortuna, IFUNet, IFRNet_L) with their direct-form convolution TFLOP/s, same box, same process (not the
+                 headline metric).
 """
 import argparse
 import contextlib
@@ -233,8 +234,16 @@ def other_paths(dev, H, W):
     hbm = []
     if "softsplat_sum" in rep:
         calls, ms = rep["softsplat_sum"]
-        hbm.append(hbm_entry("softsplat_sum (M2M render: 8 summation splats [%d,%d,4] per launch, list-gather kernel)" % (hp, wp),
-                             8 * 40.0 * hp * wp, ms / calls, calls))
+        e = hbm_entry("softsplat_sum (M2M render: 8 summation splats [%d,%d,4] per launch, list-gather kernel)" % (hp, wp),
+                      8 * 40.0 * hp * wp, ms / calls, calls)
+        try:      # HBM bytes from the committed PMC passes of this kernel (they cannot share a run with this timing), scaled to this size
+            tj = json.load(open(os.path.join(ROOT, "profiles", "roofline_traffic.json")))["m2m_softsplat_sum"]
+            e["traffic"] = int(tj["bytes_per_launch"] * (hp * wp) / float(tj["pixels"]))
+            e["traffic_over_algorithmic"] = round(e["traffic"] / e["algorithmic_bytes_per_launch"], 3)
+            e["traffic_source"] = "profiles/roofline_traffic.json (" + tj["source"] + "), not measured in this run"
+        except Exception:  # noqa: BLE001
+            e["traffic"] = None
+        hbm.append(e)
     if "costvol9x9" in rep:
         calls, ms = rep["costvol9x9"]
         levels = [(hp >> k, wp >> k) for k in range(2, 7)]             # 272x480 ... 17x30, both directions in one launch
@@ -277,6 +286,78 @@ def other_paths(dev, H, W):
         hbm.append({"kernel": "softsplat_sum micro-benchmark", "error": f"{type(ex).__name__}: {ex}"})
     out["roofline_hbm"] = hbm
     return out
+
+
+def other_nodes(dev, H, W):
+    """The SURVEY 8(f) nodes — GMFSS Fortuna (union), IFUNet, IFRNet_L — device-resident at the bench resolution: ms per interpolated
+    frame and the direct-form convolution TFLOP/s they sustain (same box, same process; not the headline metric).  Each leg is
+    independent: one that fails is reported as an error string."""
+    from cfi_amd import synth
+
+    fr = synth.smooth_frames(2, H, W, seed=2, shift=4.0)
+    x0, x1 = fr[0].to(dev).contiguous(), fr[1].to(dev).contiguous()
+    out = torch.empty(H, W, 3, device=dev)
+    res = {}
+
+    def timed(fn, n, warm=2):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / n
+
+    def counted(eng, fn):
+        eng.conv_flop = 0.0
+        fn()
+        f, eng.conv_flop = eng.conv_flop, None
+        return f
+
+    try:      # GMFSS Fortuna: matched ("coherent") weights + a textured pair, so that GMFlow finds a true small motion as a trained model does
+        from cfi_amd.gmfss import GMFSSEngine
+
+        eng = GMFSSEngine(synth.gmfss_coherent_state_dicts(3, "union"))
+        tx = synth.texture_frames(2, H, W, seed=5)
+        g0, g1 = tx[0].to(dev).contiguous(), tx[1].to(dev).contiguous()
+        tp = timed(lambda: eng.prepare(g0, g1), 3)
+        tr = timed(lambda: eng.render(0.5, out), 5)
+        fp, frn = counted(eng, lambda: eng.prepare(g0, g1)), counted(eng, lambda: eng.render(0.5, out))
+        res["gmfss_fortuna_union"] = {"prepare_ms_per_pair": round(tp * 1e3, 2), "render_ms_per_frame": round(tr * 1e3, 2),
+                                      "frames_per_s_2x": round(1 / (tp + tr), 1), "conv_gflop_direct_form": {"prepare": round(fp / 1e9, 1), "render": round(frn / 1e9, 1)},
+                                      "conv_tflops_direct_form": round((fp + frn) / (tp + tr) / 1e12, 1),
+                                      "note": "convolution FLOP only (GMFlow's attention matmuls and the splats are not counted)"}
+        eng.close()
+        del eng
+    except Exception as e:  # noqa: BLE001
+        res["gmfss_fortuna_union"] = {"error": f"{type(e).__name__}: {e}"}
+    try:
+        from cfi_amd.ifunet import IFUNetEngine
+
+        eng = IFUNetEngine(synth.ifunet_synth_state_dict(1234))
+        t = timed(lambda: eng.forward(x0, x1, 0.5, out, scale=1.0, ensemble=True), 3)
+        f = counted(eng, lambda: eng.forward(x0, x1, 0.5, out, scale=1.0, ensemble=True))
+        res["ifunet"] = {"ms_per_frame": round(t * 1e3, 2), "frames_per_s": round(1 / t, 1), "ensemble": True, "conv_gflop_direct_form": round(f / 1e9, 1),
+                         "conv_tflops_direct_form": round(f / t / 1e12, 1)}
+        eng.close()
+        del eng
+    except Exception as e:  # noqa: BLE001
+        res["ifunet"] = {"error": f"{type(e).__name__}: {e}"}
+    try:
+        from cfi_amd.ifrnet import IFRNetEngine
+
+        eng = IFRNetEngine(synth.ifrnet_synth_state_dict("L", 1234), "L")
+        o4 = out.view(1, H, W, 3)
+        t = timed(lambda: eng.forward([x0], [x1], 0.5, 1.0, o4), 5)      # the node's default call (multiplier 2): working resolution 0.5, embedding 1.0
+        res["ifrnet_L"] = {"ms_per_frame": round(t * 1e3, 2), "frames_per_s": round(1 / t, 1), "call": "node default (multiplier 2): working resolution x0.5",
+                           "conv_tflops_direct_form": round(0.80 * (H * W) / (1080 * 1920) / t, 1), "flop_per_frame": "0.80 TFLOP @1080p (docs/design/ifrnet.md)"}
+        eng.close()
+        del eng
+    except Exception as e:  # noqa: BLE001
+        res["ifrnet_L"] = {"error": f"{type(e).__name__}: {e}"}
+    torch.cuda.empty_cache()
+    return res
 
 
 def other_paths_dist(dev, H, W, world, rank, backend):
@@ -986,7 +1067,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the FILM / M2M device-resident numbers")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather of new frames")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling 4K x4 leg (BASELINE configs[3])")
-    ap.add_argument("--no-peer-copy-leg", action="store_true", help="N>1: skip the extra weak-scaling leg that exchanges frames by IPC-mapped peer copies")
+    ap.add_argument("--peer-copy-leg", action="store_true",
+                    help="N>1: also run the extra weak-scaling leg that exchanges frames by IPC-mapped peer copies instead of a collective (opt-in: "
+                         "it has only ever run with its ranks on one GPU)")
     ap.add_argument("--reserve-cus", type=int, default=16,
                     help="N>1 over RCCL: compute units the persistent kernels leave to the overlapped all-gather's kernel (also caps "
                          "RCCL's channels to the same number unless NCCL_MAX_NCHANNELS is set); 0 = none")
@@ -998,10 +1081,35 @@ def main():
     ap.add_argument("--strong-reps", type=int, default=3)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) | gloo (plumbing test on one GPU)")
     ap.add_argument("--device-threads", action="store_true",
-                    help="route --gpus 1 through the one-process / device-thread path too (what --gpus N > 1 uses without a launcher)")
+                    help="one process driving N devices with host threads (multidev.py) instead of one process per GPU: opt-in for any N")
+    ap.add_argument("--dry-run-ranks", type=int, default=0,
+                    help="plumbing check on ONE GPU: run the full N-rank control flow (weight broadcast, reserve trials, gather, strong leg, watchdog) "
+                         "as N gloo ranks that all use device 0; the numbers in the line mean nothing")
     args = ap.parse_args()
-    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.device_threads):
+    if "WORLD_SIZE" not in os.environ and args.device_threads:
         return main_single_process(args)
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.dry_run_ranks > 1):
+        # One process per GPU over RCCL is THE multi-GPU path (the driver launches it that way itself); asked for N > 1 without a launcher,
+        # become that launch.  --dry-run-ranks N: the same N ranks, gloo, all on device 0.
+        import socket
+
+        n = args.dry_run_ranks if args.dry_run_ranks > 1 else args.gpus
+        argv, skip = [], 0
+        for a in sys.argv[1:]:
+            if skip:
+                skip -= 1
+            elif a in ("--gpus", "--dry-run-ranks", "--backend"):
+                skip = 1
+            elif not a.startswith(("--gpus=", "--dry-run-ranks=", "--backend=")):
+                argv.append(a)
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__), "--gpus", str(n), "--backend", "gloo" if args.dry_run_ranks > 1 else args.backend] + argv
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
 
     import __graft_entry__ as ge
 
@@ -1205,7 +1313,7 @@ def main():
             strong = {"error": f"{type(e).__name__}: {e}"}
         if rank == 0:
             res["strong_4k_x4"] = strong
-    if world > 1 and not args.no_gather and not args.no_peer_copy_leg:
+    if world > 1 and not args.no_gather and args.peer_copy_leg:
         try:
             pc = peer_copy_gather_leg(eng, raw, B, H, W, max(2, min(K, 10)), dev, world, rank, args.backend)
         except Exception as e:
@@ -1229,6 +1337,10 @@ def main():
                 res["e2e"] = e2e_leg(sd, dev, H, W)
             if not args.no_extras:
                 res["other_paths"] = other_paths(dev, H, W)
+                try:
+                    res["other_paths"].update(other_nodes(dev, H, W))
+                except Exception as e:  # noqa: BLE001  (never lose the line to an extra leg)
+                    res["other_paths"]["other_nodes_error"] = f"{type(e).__name__}: {e}"
         print(json.dumps(res), flush=True)
         parity_failed = not res.get("parity", {}).get("ok", True)
     if world > 1:

@@ -96,6 +96,7 @@ class OpsEngine:
         # for in, or when dropped explicitly; un-pooled engines keep every named tensor for the life of the workspace
         self._pool = _Pool(self.device) if pooled else None
         self._live = [{}]
+        self.conv_flop = None      # set to 0 to count the direct-form FLOP of every convolution launched from here on (bench.py other_paths)
 
     # ---- plumbing ---------------------------------------------------------------------------------------------------
     def _c(self, name, *args):
@@ -177,12 +178,14 @@ class OpsEngine:
         if not h:
             raise RuntimeError("vfi_conv_create_ex failed: " + self.be.last_error())
         self.handles.append(h)
-        return dict(h=h, kind=kind, stride=stride, cout=cout, act=3 if pr is not None else 0)
+        return dict(h=h, kind=kind, stride=stride, cout=cout, cin=cin, k=int(w.shape[2]), act=3 if pr is not None else 0)
 
     def _conv(self, L, src, soff, dst, doff, act=None, slope=0.0, res=None):
         n, hin, win, cs = src.shape
         want = (hin * 2, win * 2) if L["kind"] == 1 else (hin // L["stride"], win // L["stride"])
         assert tuple(dst.shape[1:3]) == want and dst.shape[0] == n, (src.shape, dst.shape, want)
+        if self.conv_flop is not None:      # direct form: 2 x taps x Cin x Cout per output pixel (a ConvTranspose2d(4, 2, 1) has 4 taps per output pixel)
+            self.conv_flop += 2.0 * (4 if L["kind"] == 1 else L["k"] * L["k"]) * L["cin"] * L["cout"] * n * want[0] * want[1]
         self._c("vfi_conv_forward_ex", L["h"], _p(src, soff), cs, hin, win, _p(dst, doff), dst.shape[-1], n,
                 L["act"] if act is None else act, slope, 0.0, 0.0, _p(res) if res is not None else None,
                 res.shape[-1] if res is not None else 0)

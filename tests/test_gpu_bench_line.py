@@ -41,6 +41,8 @@ def test_single_gpu_line(hip_lib):
     assert any("micro-benchmark" in e["kernel"] and "error" not in e for e in op)
     cv = [e for e in op if e.get("bound") == "valu"][0]
     assert 0 < cv["frac"] <= 1.0 and cv["valu_floor_ms"] > 0
+    for k in ("gmfss_fortuna_union", "ifunet", "ifrnet_L"):       # r5: the SURVEY 8(f) nodes are in the driver-run line
+        assert "error" not in res["other_paths"][k] and res["other_paths"][k]["conv_tflops_direct_form"] > 0, res["other_paths"][k]
     # r5: the line verifies itself — the timed workload against the oracle on identical tensors — and carries the shader clock
     par = res["parity"]
     assert par["ok"] and par["n_over_1e-3"] == 0 and 0 < par["max_abs"] <= 1e-3 and par["values"] == 272 * 480 * 3, par
@@ -54,7 +56,7 @@ def test_single_gpu_line(hip_lib):
 def test_two_rank_line_shards_the_strong_leg(hip_lib):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29731",
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--no-extras"] + SMALL
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--no-extras", "--peer-copy-leg"] + SMALL
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     res = _line(r.stdout)
@@ -69,3 +71,21 @@ def test_two_rank_line_shards_the_strong_leg(hip_lib):
     # the extra weak-scaling leg that exchanges frames by IPC-mapped peer copies (no collective kernel): ran, validated what arrived
     pc = res["weak_peer_copy_gather"]
     assert "error" not in pc and pc["value"] > 0 and "fingerprints" in pc["validated"], pc
+
+
+@pytest.mark.parametrize("n", [4, 8])
+def test_dry_run_ranks(hip_lib, n):
+    """the full N-rank control flow (weight broadcast, reserve trials, gather, strong leg with uneven blocks, the
+    sharded FILM / M2M legs) for N = 4 and 8 as gloo ranks on the one GPU, launched by bench.py itself — so that the first run on an
+    8-GPU node cannot die on plumbing.  The numbers mean nothing."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run-ranks", str(n)] + SMALL, capture_output=True, text=True, timeout=1500, cwd=ROOT,
+                       env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    res = _line(r.stdout)
+    assert res["n_gpus"] == n and res["scaling"] == "weak" and res["value"] > 0 and not res.get("incomplete")
+    assert res["parity"]["ok"]
+    st = res["strong_4k_x4"]
+    assert st["n_gpus"] == n and sum(st["tasks_per_rank"]) == 9 and len(st["tasks_per_rank"]) == n and st["value"] > 0, st
+    assert set(res["config"]["reserved_cus_trials_ms_per_step"]) == {"16", "0", "32"}
+    op = res["other_paths"]
+    assert "error" not in op and op["film_2x"]["frames_per_s"] > 0 and op["m2m_2x"]["frames_per_s"] > 0, op
