@@ -548,8 +548,7 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
                 WINO_MF4(2, VA, x, Be);
                 tf2(VB);
                 WINO_MF4(3, VA, x, Be);
-                WINO_A(0);
-                WINO_A(1);
+                WINO_A(0); WINO_A(1);
                 pk_bases(nbuf);
                 // ---- sub-step 1
                 __builtin_amdgcn_sched_barrier(0);

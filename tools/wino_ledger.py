@@ -28,7 +28,7 @@ from cfi_amd import _lib  # noqa: E402
 lib = _lib.load()
 _lib.check(lib.vfi_init(0), "init")
 N, H, W, CIN, COUT = 32, 272, 480, 64, 64
-if len(sys.argv) > 1:
+if len(sys.argv) > 1 and sys.argv[1].isdigit():
     N = int(sys.argv[1])
 MFMA_CYCLES = 64          # v_mfma_f32_32x32x2_f32: 16 passes x 4 cycles
 u32 = lambda x: x & 0xFFFFFFFF
@@ -121,3 +121,4 @@ try:
     print(f"  workgroup 0 lives {wg} cycles in the product kernel; {n_it} items x {tot:.0f} = {n_it * tot:.0f} ({n_it * tot / wg:.3f}: the probe forms' own cost and the prologue / tail are the difference)")
 except Exception as e:  # noqa: BLE001
     print(f"  (incomplete: {type(e).__name__}: {e})")
+
