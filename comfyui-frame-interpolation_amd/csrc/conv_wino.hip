@@ -144,6 +144,8 @@ __device__ __forceinline__ f32x2 wino_pk_mul(f32x2 x, f32x2 y) {
 // m = 8 * (r >> 2) + 4 * half + (r & 3) (MFMA 32x32 D layout).  Stores and residual loads go through buffer descriptors of the
 // image: an out-of-image pixel (or a padded output channel) gets offset 0x80000000 and the hardware drops / zero-fills it —
 // no per-value branches.  MODE 0: the hot form (no residual, none / LeakyReLU with a slope in [0,1]: lrelu(v) = max(v, v*slope));
+// MODE 1 (r5): the hot form with a PER-CHANNEL negative slope (PReLU(c): v > 0 ? v : v * slope[co] — the lane IS the output channel, so
+// the slope is one register; M2M's / IFUNet's conv + PReLU and ConvTranspose2d + PReLU layers, which used to take the general form);
 // MODE 10 + act: the general form (residual, any activation of ConvArgs::act, post affine).
 // FULL: the region lies completely inside the image (wave-uniform, true for all but the last row / column of regions): no
 // row branches and no per-store column test (they were ~260 of the epilogue's 1350 instructions).
@@ -185,7 +187,7 @@ __device__ __forceinline__ void wino_epilogue(const f32x16 (&acc)[16], const Con
     }
     // Two tiles (accumulator registers r, r + 1 = neighbours in x) per step, in packed fp32: the epilogue's VALU work is not hidden by
     // anything (the wave's MFMAs are over), v_pk_* does two values per instruction in the same order of operations as the scalar form.
-    const f32x2 bsbt = {bs, bt}, sl2 = {uslope, uslope};
+    const f32x2 bsbt = {bs, bt}, sl2 = {MODE == 1 ? pre : uslope, MODE == 1 ? pre : uslope};
 #pragma unroll
     for (int rp = 0; rp < 8; ++rp) {
         const int r = 2 * rp;
@@ -213,7 +215,7 @@ __device__ __forceinline__ void wino_epilogue(const f32x16 (&acc)[16], const Con
                 for (int ex = 0; ex < 2; ++ex) {
                     f32x2 v2 = wino_pk_mul_hi(wino_pk_add_lo(y[ey * 2 + ex], bsbt), bsbt);
                     f32x2 w2 = v2;
-                    if (MODE == 0) w2 = wino_pk_mul(v2, sl2);
+                    if (MODE == 0 || MODE == 1) w2 = wino_pk_mul(v2, sl2);
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt) {       // tile r (tt = 0) and tile r + 1
                         const int tx = txx0 + tt;
@@ -222,6 +224,8 @@ __device__ __forceinline__ void wino_epilogue(const f32x16 (&acc)[16], const Con
                         float v = tt ? v2.y : v2.x;
                         if (MODE == 0) {
                             asm("v_max_f32 %0, %1, %2" : "=v"(v) : "v"(v), "v"(tt ? w2.y : w2.x));      // (fmaxf on asm results: + 2 canonicalising v_max each)
+                        } else if (MODE == 1) {
+                            v = v > 0.f ? v : (tt ? w2.y : w2.x);                                          // PReLU with this lane's slope (any sign / size)
                         } else {
                             if (has_res) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrsrc, ok ? lane_r : (int)0x80000000, rowr + xq * a.res_cs * 4, 0));
                             if (MODE == 11) v = v > 0.f ? v : v * a.slope;
@@ -243,7 +247,7 @@ __device__ __forceinline__ void wino_epilogue(const f32x16 (&acc)[16], const Con
 template <int RTX, int MODE, int SHUF = 0, int PROBE = 0>
 __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr bool EXT = MODE != 0;      // a general epilogue (wino_epilogue's MODE 10 + act): one kernel per activation, no switch in the item loop
+    constexpr bool EXT = MODE >= 10;     // a general epilogue (wino_epilogue's MODE 10 + act): one kernel per activation, no switch in the item loop
     using G = WinoGeom<RTX>;
     constexpr int PW = G::PW, RW = G::RW, RH = G::RH, NA = G::NA;
     const ConvArgs& a = p.a;
@@ -386,7 +390,7 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
         const bool real = c < a.Cout;
         cst[c] = real ? a.bias[c] : 0.f;
         cst[G::MAXCO + c] = (real && a.beta) ? a.beta[c] : 1.f;
-        cst[2 * G::MAXCO + c] = (real && EXT && a.act == 3) ? a.prelu[c] : 0.f;
+        cst[2 * G::MAXCO + c] = (real && (EXT || MODE == 1) && a.act == 3) ? a.prelu[c] : 0.f;
     }
     // ---- prologue: three chunks of DMA in flight
     Cur dcur, ccur;
@@ -815,9 +819,10 @@ int conv_wino_launch(const ConvArgs& a, int variant, hipStream_t s, const char* 
     VFI_REQUIRE((a.out_mode == 1 || (long)a.Hin * a.Win * a.out_cs * 4 * (a.out_mode == 2 ? 4 : 1) < 0x7fffffffL) && (!a.res || (long)a.Hin * a.Win * a.res_cs * 4 < 0x7fffffffL),
                 "conv_wino %s: output / residual image larger than 2 GiB", name);
     // the hot epilogue: no residual, no post affine, none / LeakyReLU with a slope in [0,1]
-    const bool ext = a.res != nullptr || a.post_scale != 0.f || !(a.act == 0 || (a.act == 1 && a.slope >= 0.f && a.slope <= 1.f));
+    // ... or per-channel PReLU (MODE 1)
+    const bool ext = a.res != nullptr || a.post_scale != 0.f || !(a.act == 0 || (a.act == 1 && a.slope >= 0.f && a.slope <= 1.f) || a.act == 3);
     VFI_REQUIRE(a.act >= 0 && a.act <= 5, "conv_wino %s: activation code %d", name, a.act);
-    const int mode = ext ? 10 + a.act : 0;      // wino_epilogue's MODE: one kernel per general activation
+    const int mode = ext ? 10 + a.act : (a.act == 3 ? 1 : 0);      // wino_epilogue's MODE: one kernel per general activation
     if (a.out_mode == 1) {      // transposed convolution + PixelShuffle as a 3x3 layer (pack_deconv_as_conv3x3): hot epilogue, 16x8 regions
         VFI_REQUIRE(!ext && a.Cout % 4 == 0 && a.act == 0 && !a.beta, "conv_wino %s: the pixel-shuffle output takes the plain epilogue (bias only)", name);
         VFI_REQUIRE((long)(a.out_planes ? a.out_planes : 2) * 16 * a.Hin * a.Win * 16 < 0x7fffffffL, "conv_wino %s: block output larger than 2 GiB", name);
@@ -826,8 +831,8 @@ int conv_wino_launch(const ConvArgs& a, int variant, hipStream_t s, const char* 
     if (a.out_mode == 2) {      // transposed convolution of a layer object as a 3x3 layer: parities interleaved into NHWC at twice the resolution
         // (hot epilogue only: with the general epilogue — per-channel PReLU, IFUNet's decoders — the form measured SLOWER than the grouped
         // direct kernel, 3.2 vs 2.5 ms per IFUNet frame: two spilled registers in an epilogue that already carries the parity addressing)
-        VFI_REQUIRE(!a.res && a.Cout % 4 == 0 && mode == 0, "conv_wino %s: the transposed-convolution form takes none / LeakyReLU only", name);
-        return wino_launch_t<8, 0, 2>(p, s, name);
+        VFI_REQUIRE(!a.res && a.Cout % 4 == 0 && (mode == 0 || mode == 1), "conv_wino %s: the transposed-convolution form takes none / LeakyReLU / per-channel PReLU only", name);
+        return mode == 1 ? wino_launch_t<8, 1, 2>(p, s, name) : wino_launch_t<8, 0, 2>(p, s, name);
     }
     if (variant == 8 && mode == 0) {      // the hot instantiation's cycle-ledger forms (test option wino_probe; same results, + stamps)
         switch ((int)option(kOptWinoProbe)) {
@@ -841,6 +846,7 @@ int conv_wino_launch(const ConvArgs& a, int variant, hipStream_t s, const char* 
 #define WINO_DISPATCH(R_)                                              \
     switch (mode) {                                                    \
         case 0: return wino_launch_t<R_, 0>(p, s, name);               \
+        case 1: return wino_launch_t<R_, 1>(p, s, name);               \
         case 10: return wino_launch_t<R_, 10>(p, s, name);             \
         case 11: return wino_launch_t<R_, 11>(p, s, name);             \
         case 12: return wino_launch_t<R_, 12>(p, s, name);             \

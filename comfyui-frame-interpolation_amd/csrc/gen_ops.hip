@@ -158,9 +158,10 @@ struct vfi_conv {
     float* bias = nullptr;
     float* prelu = nullptr;  // per-channel PReLU slopes [Cout_p] (optional)
     // ConvTranspose2d(4, 2, 1) as ONE 3x3 layer with 4 * Cout channels on the Winograd kernel (conv_wino.hip: pack_deconv_as_conv3x3):
-    // ww holds that pack, bias3 the bias repeated per parity group (none / LeakyReLU layers take this form; per-channel PReLU stays
-    // on the grouped direct kernel)
+    // ww holds that pack, bias3 / prelu3 the bias / per-channel PReLU slopes repeated per parity group (none / LeakyReLU / PReLU layers
+    // take this form)
     float* bias3 = nullptr;
+    float* prelu3 = nullptr;
     int Cout3_p = 0;
     int Cout = 0, Cout_p = 0, Cin = 0, Cin_p = 0, kh = 0, kw = 0, taps = 0;
     int stride = 1, pad_mode = 0, kind = 0;  // kind 0: Conv2d, 1: ConvTranspose2d(4, 2, 1)
@@ -239,6 +240,7 @@ void vfi_conv_destroy(vfi_conv_t* c) {
     if (c->bias) (void)hipFree(c->bias);
     if (c->prelu) (void)hipFree(c->prelu);
     if (c->bias3) (void)hipFree(c->bias3);
+    if (c->prelu3) (void)hipFree(c->prelu3);
     delete c;
 }
 
@@ -305,15 +307,21 @@ vfi_conv_t* vfi_conv_create_ex(int kind, const float* w_host, const float* bias_
         ok = upload(&c->prelu, pp);
     }
     // the transposed convolution's 3x3 / Winograd form (4x the U-transform weight memory): packed only for layers that can ever take it —
-    // vfi_conv_forward_ex sends per-channel-PReLU layers (general epilogue: slower than the grouped direct kernel, conv_wino.hip) and
-    // replicate-padded ones to the direct kernel whatever the image
-    if (ok && kind == 1 && 4 * Cout <= 1024 && !prelu_host && !pad_mode) {
+    // vfi_conv_forward_ex sends replicate-padded ones to the direct kernel whatever the image.  Per-channel PReLU layers take it
+    // since r5 (conv_wino.hip MODE 1): their slopes are repeated per parity group like the bias.
+    if (ok && kind == 1 && 4 * Cout <= 1024 && !pad_mode) {
         std::vector<float> w3, b3, ww;
         pack_deconv_as_conv3x3(w_host, bias_host, Cin, Cout, w3, b3);
         c->Cout3_p = round_up(4 * Cout, 32);
         pack_wino3x3(w3.data(), 4 * Cout, Cin, chan_map, Cin_phys, c->Cout3_p, ww);
         b3.resize(c->Cout3_p, 0.f);
         ok = upload(&c->ww, ww) && upload(&c->bias3, b3);
+        if (ok && prelu_host) {
+            std::vector<float> p3(c->Cout3_p, 0.f);
+            for (int g = 0; g < 4; ++g)
+                for (int co = 0; co < Cout; ++co) p3[(size_t)g * Cout + co] = prelu_host[co];
+            ok = upload(&c->prelu3, p3);
+        }
     }
     if (!ok) {
         set_error("vfi_conv_create_ex: device allocation/upload failed");
@@ -377,18 +385,22 @@ int vfi_conv_forward_ex(const vfi_conv_t* c, const float* in_dev, int in_cs, int
         a.w = c->ww;
         return conv_wino_launch(a, 0, (hipStream_t)stream, it->second);
     }
-    if (c->ww && c->kind == 1 && option(kOptDeconvWino) && conv_wino_mode(-1) != 1 && !c->pad_mode && post_scale == 0.f &&
-        (act == 0 || (act == 1 && slope >= 0.f && slope <= 1.f))) {
+    if (c->ww && c->kind == 1 && option(kOptDeconvWino) && conv_wino_mode(-1) != 1 && !c->pad_mode && post_scale == 0.f && !res_dev &&
+        (act == 0 || (act == 1 && slope >= 0.f && slope <= 1.f) || (act == 3 && c->prelu3))) {
         // the transposed convolution as one 3x3 layer with 4 * Cout channels (no padding of Cout to a 32-wide N tile per parity group);
         // chosen from the image, never from the batch
         ConvArgs b = a;
         conv3x3_taps(b);
         b.w = c->ww;
         b.bias = c->bias3;
+        b.prelu = c->prelu3;
         b.Cout = 4 * c->Cout;
         b.Cout_p = c->Cout3_p;
         const long regions = 2L * cdiv(Hin, 8) * cdiv(Win, 16);
-        if (regions / 4 * (b.Cout_p / 32) >= 192 && (long)4 * Hin * Win * out_cs * 4 < 0x7fffffffL && (long)Hin * Win * in_cs * 4 < 0x7fffffffL)
+        // ... and from 128 x 128 input pixels up: below that (the 34x60 / 68x120 pyramid levels at 1080p, K = 256 ... 768) the direct kernel's
+        // split-K wins by 10-75 % whatever the item count (profiles/r05_deconv_ab.txt: 512->256 @34x60 153 vs 267 us, 256->128 @68x120 114 vs 143 us;
+        // from 136x240 up the Winograd form wins: 64->16 @544x960 339 vs 696 us)
+        if (regions / 4 * (b.Cout_p / 32) >= 192 && (long)Hin * Win >= 16384 && (long)4 * Hin * Win * out_cs * 4 < 0x7fffffffL && (long)Hin * Win * in_cs * 4 < 0x7fffffffL)
             return conv_wino_launch(b, 8, (hipStream_t)stream, it->second);
     }
     return conv_launch(a, c->kind == 1 ? 1 : c->stride, c->kind == 1, -1, (hipStream_t)stream, it->second);
