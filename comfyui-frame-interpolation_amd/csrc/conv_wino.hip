@@ -759,7 +759,19 @@ bool conv_wino_eligible(const ConvArgs& a) {
     // decided from the IMAGE, never from the launch's batch (the two kernels sum in different orders: a frame's bits must not depend
     // on its launch mates): work items of a nominal two-image launch — what FILM / M2M / IFRNet / GMFSS issue per pair
     const long regions = 2L * cdiv(a.Hin, 8) * cdiv(a.Win, 16);
-    return regions / 4 * (a.Cout_p / 32) >= 192;
+    const long items = regions / 4 * (a.Cout_p / 32);
+    if (items < 192) return false;
+    // r5: ... and not a launch of at most two rounds whose last round is nearly empty.  The kernel is persistent, one workgroup per CU:
+    // 288 items on 256 CUs (FILM's 256-channel layers at 67x120) are two rounds at 56 % — the direct kernel with split-K is 1.3-1.5x faster
+    // there (profiles/r05_film_algo_ab.txt: 1920 -> 256 @67x120 1.88 vs 1.28 ms, 256 -> 256 0.83 vs 0.62), while 576 items (512 channels,
+    // 2.25 rounds) stay 1.6x faster on this kernel.
+    if (option(kOptWinoQuant)) {
+        int dev = 0;
+        const long cus = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDevices ? wino_cus(dev) : 256;
+        const long rounds = (items + cus - 1) / cus;
+        if (rounds <= 2 && items * 100 < rounds * cus * 60) return false;
+    }
+    return true;
 }
 
 template <int RTX, int MODE, int SHUF = 0, int PROBE = 0>

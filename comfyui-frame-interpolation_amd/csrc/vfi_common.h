@@ -69,6 +69,7 @@ enum Option {
     kOptWinoXcd,         // 1: XCD-aware work order of the Winograd kernel (default), 0: plain order
     kOptDeconvWino,      // 1: ConvTranspose2d(4, 2, 1) + PixelShuffle (RIFE lastconv) as a 96-channel 3x3 layer on the Winograd kernel (default), 0: grouped direct kernel
     kOptEncodeBatched,   // 1: one frame-pack launch for a batch of frames where the caller offers one (default), 0: one launch per frame
+    kOptWinoQuant,       // 1: layer objects leave launches of <= 2 rounds with a nearly empty last round to the direct kernel (default), 0: item count only
     kOptWinoProbe,       // 1..4: the hot Winograd instantiation takes its cycle-ledger form (conv_wino.hip: g_wino_probe_out; default 0)
     kOptCount
 };
