@@ -136,7 +136,14 @@ class GMFSSEngine(OpsEngine):
             blk = {}
             for part in ("self_attn", "cross_attn_ffn"):
                 p = f"transformer.layers.{i}.{part}."
-                d = {n: mk(fl[p + n + ".weight"]) for n in ("q_proj", "k_proj", "v_proj", "merge")}
+                d = {n: mk(fl[p + n + ".weight"]) for n in ("q_proj", "merge")}
+                # r5: the projections that share an input are ONE layer with concatenated output channels (every output channel's sum over
+                # K is what it was): self part q | k | v (128 -> 384), cross part k | v (128 -> 256) — these Linear layers are launch-latency
+                # bound (1 GFLOP each at 1080p), so three launches cost three times one
+                if part == "self_attn":
+                    d["qkv"] = mk(torch.cat([fl[p + n + ".weight"] for n in ("q_proj", "k_proj", "v_proj")], 0))
+                else:
+                    d["kv"] = mk(torch.cat([fl[p + n + ".weight"] for n in ("k_proj", "v_proj")], 0))
                 d["norm1"] = (dev(fl[p + "norm1.weight"]), dev(fl[p + "norm1.bias"]))
                 if part == "cross_attn_ffn":
                     d["mlp0"], d["mlp2"] = mk(fl[p + "mlp.0.weight"]), mk(fl[p + "mlp.2.weight"])
@@ -230,15 +237,16 @@ class GMFSSEngine(OpsEngine):
             self._instnorm(b, c, True, short, True, y)
         return y
 
-    def _attention(self, q, k, v, out, h, w, splits, shifted):
-        """single_head_split_window_attention (:367-436) on [B,h,w,C] token maps"""
-        B, c = q.shape[0], q.shape[-1]
+    def _attention(self, q, qoff, k, koff, v, voff, out, h, w, splits, shifted):
+        """single_head_split_window_attention (:367-436) on [B,h,w,C] token maps; q / k / v are channel windows (offset, 128 wide) of
+        tensors that may hold several projections side by side"""
+        B, c = q.shape[0], out.shape[-1]
         wh, ww = h // splits, w // splits
         sh, sw = (wh // 2, ww // 2) if shifted else (0, 0)
         # softmax(q k^T / sqrt(c) + mask) v as one flash-style MFMA kernel (csrc/attention.hip): no score matrix in HBM, and the
         # roll / window split / merge / roll back are the kernel's addressing — no partitioned copies either
         labels = self._const(("labels", h, w, splits), lambda: shift_labels(h, w, splits)) if shifted else None
-        self._c("vfi_window_attention", _p(q), q.shape[-1], _p(k), k.shape[-1], _p(v), v.shape[-1], _p(out), out.shape[-1], B, h, w, splits,
+        self._c("vfi_window_attention", _p(q, qoff), q.shape[-1], _p(k, koff), k.shape[-1], _p(v, voff), v.shape[-1], _p(out), out.shape[-1], B, h, w, splits,
                 sh, sw, c, 1.0 / c ** 0.5, _p(labels) if shifted else None)
 
     def _pair_swap(self, a, o):
@@ -250,29 +258,27 @@ class GMFSSEngine(OpsEngine):
         """FeatureTransformer.forward on a [2D, h, w, 128] (per direction: source, target), in place"""
         B, h, w, c = a.shape
         with self._scope():      # q / k / v / message / FFN buffers: 1.2 GiB at 1080p, dead when the transformer returns
-            q, ks, vs, m = (self._t("tf_" + n, B, h, w, c) for n in ("q", "k", "v", "m"))
+            q, m = (self._t("tf_" + n, B, h, w, c) for n in ("q", "m"))
+            qkv = self._t("tf_qkv", B, h, w, 3 * c)      # self part: q | k | v of one launch
+            kvx = self._t("tf_kvx", B, h, w, 2 * c)      # cross part: k | v of the OTHER image of the pair
             cat = self._t("tf_cat", B, h, w, 2 * c)
             hid = self._t("tf_hid", B, h, w, 8 * c)
-            kx, vx = self._t("tf_kx", B, h, w, c), self._t("tf_vx", B, h, w, c)
             for i, blk in enumerate(self.tf):
                 shifted = i % 2 == 1
                 # The cross part attends to the OTHER image's features as they were when the block started (concat1 is rebuilt only
                 # after a whole block, :664-678): its key / value projections are taken here, before the self part updates `a`, with
                 # the (source, target) swap as the batch index of the projection's input — no swapped copy of the features.
                 for j in range(B):
-                    self._conv(blk["cross_attn_ffn"]["k_proj"], a[j ^ 1:(j ^ 1) + 1], 0, kx[j:j + 1], 0)
-                    self._conv(blk["cross_attn_ffn"]["v_proj"], a[j ^ 1:(j ^ 1) + 1], 0, vx[j:j + 1], 0)
+                    self._conv(blk["cross_attn_ffn"]["kv"], a[j ^ 1:(j ^ 1) + 1], 0, kvx[j:j + 1], 0)
                 for part in ("self_attn", "cross_attn_ffn"):
                     L = blk[part]
                     ffn = part == "cross_attn_ffn"
-                    self._conv(L["q_proj"], a, 0, q, 0)
                     if ffn:
-                        k, v = kx, vx
+                        self._conv(L["q_proj"], a, 0, q, 0)
+                        self._attention(q, 0, kvx, 0, kvx, c, m, h, w, splits, shifted)
                     else:
-                        k, v = ks, vs
-                        self._conv(L["k_proj"], a, 0, k, 0)
-                        self._conv(L["v_proj"], a, 0, v, 0)
-                    self._attention(q, k, v, m, h, w, splits, shifted)
+                        self._conv(L["qkv"], a, 0, qkv, 0)
+                        self._attention(qkv, 0, qkv, c, qkv, 2 * c, m, h, w, splits, shifted)
                     self._conv(L["merge"], m, 0, q, 0)
                     n1 = L["norm1"]
                     if not ffn:      # a = a + norm1(merge(msg)), and the same value into the FFN's concat slot [a | .] of the cross part
