@@ -658,6 +658,15 @@ class SysfsSampler:
                     pass
             if cards:
                 c = cards[min(dev_index, len(cards) - 1)]
+                try:      # the card whose PCI address is this process's device (a box exposes all its GPUs in sysfs, visible to HIP or not)
+                    pr = torch.cuda.get_device_properties(dev_index)
+                    want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}."
+                    for cand in cards:
+                        if os.path.basename(os.path.realpath(os.path.join(cand, "device"))).startswith(want):
+                            c = cand
+                            break
+                except Exception:
+                    pass
                 self.freq_files = sorted(glob.glob(os.path.join(c, "device/hwmon/hwmon*/freq1_input")))
                 self.power_files = sorted(glob.glob(os.path.join(c, "device/hwmon/hwmon*/power1_average")) +
                                           glob.glob(os.path.join(c, "device/hwmon/hwmon*/power1_input")))
