@@ -136,7 +136,7 @@ def test_layer_object_winograd_matches_direct_and_torch(lib, act, post, pad_mode
     x = torch.rand(n, cin, h, w, generator=g) * 2 - 1
     wt = (torch.rand(cout, cin, 3, 3, generator=g) * 2 - 1) / (cin * 9) ** 0.5
     b = torch.rand(cout, generator=g) - 0.5
-    slopes = 0.1 + 0.3 * torch.rand(cout, generator=g)
+    slopes = -0.5 + 2.0 * torch.rand(cout, generator=g)        # any sign / size: r5's per-channel hot epilogue (conv_wino MODE 1) is an exact PReLU
     r = torch.rand(n, cout, h, w, generator=g) - 0.5
     xp = F.pad(x, (1, 1, 1, 1), mode="replicate" if pad_mode else "constant")
     y = F.conv2d(xp.double(), wt.double(), b.double())
@@ -185,17 +185,19 @@ def test_layer_object_winograd_matches_direct_and_torch(lib, act, post, pad_mode
 
 
 @pytest.mark.parametrize("act", [0, 1, 3])
-@pytest.mark.parametrize("cin,cout,n,h,w", [(64, 16, 2, 40, 56), (24, 32, 1, 33, 70), (128, 32, 2, 17, 30), (256, 64, 1, 34, 60)])
+@pytest.mark.parametrize("cin,cout,n,h,w", [(64, 16, 2, 40, 56), (24, 32, 1, 33, 70), (128, 32, 2, 17, 30), (256, 64, 1, 34, 60),
+                                            (64, 16, 1, 136, 240), (24, 32, 1, 131, 133)])   # r5: the last two are >= 128 x 128 input pixels: the Winograd form's sizes
 def test_layer_object_deconv_winograd_matches_direct_and_torch(lib, act, cin, cout, n, h, w):
     """vfi_conv_create_ex(kind = 1): ConvTranspose2d(4, 2, 1) of the layer objects (M2M / IFRNet / IFUNet / GMFSS decoders) in both forms —
     the grouped direct kernel (A/B option deconv_wino = 0) and ONE 3x3 layer with 4 * Cout channels on the Winograd kernel whose
-    epilogue interleaves the parities into NHWC at twice the resolution (default) — vs torch: none / LeakyReLU / per-channel PReLU,
-    a channel window on both sides, odd sizes (partial regions), small layers that stay on the direct kernel by size."""
+    epilogue interleaves the parities into NHWC at twice the resolution (default from 128 x 128 input pixels up) — vs torch: none / LeakyReLU /
+    per-channel PReLU with slopes of any sign and size, a channel window on both sides, odd sizes (partial regions), small layers that
+    stay on the direct kernel by size.  The two forms must also DIFFER where the Winograd form is expected to run (the A/B option is live)."""
     g = torch.Generator().manual_seed(cin + cout + act)
     x = torch.rand(n, cin, h, w, generator=g) * 2 - 1
     wt = ((torch.rand(cin, cout, 4, 4, generator=g) * 2 - 1) / (cin * 4) ** 0.5).contiguous()
     b = (torch.rand(cout, generator=g) - 0.5).contiguous()
-    slopes = (0.1 + 0.3 * torch.rand(cout, generator=g)).contiguous()
+    slopes = (-0.5 + 2.0 * torch.rand(cout, generator=g)).contiguous()
     y = F.conv_transpose2d(x.double(), wt.double(), b.double(), 2, 1)
     if act == 1:
         y = F.leaky_relu(y, 0.25)
@@ -225,6 +227,10 @@ def test_layer_object_deconv_winograd_matches_direct_and_torch(lib, act, cin, co
     for form, got in outs.items():
         assert not torch.isnan(got).any(), f"deconv_wino={form}: unwritten outputs"
         assert (got - want).abs().max().item() <= tol, describe_diff(got, want, f"deconv_wino={form} act {act}")
+    if h * w >= 16384:      # the 3x3 / Winograd form really ran: its summation order differs from the grouped direct kernel's
+        assert not torch.equal(outs[0], outs[1]), "deconv_wino = 1 took the direct kernel at a size where the Winograd form is the rule"
+    else:
+        assert torch.equal(outs[0], outs[1]), "below 128 x 128 input pixels both settings take the direct kernel"
 
 
 @pytest.mark.parametrize("gvariant", [None, "direct", 12, 13, 43, 44])
@@ -257,3 +263,43 @@ def _deconv_case(lib, cin, h, w):
     assert not torch.isnan(got).any()
     tol = 2e-5 * max(1.0, want.abs().max().item())
     assert (got - want).abs().max().item() <= tol, describe_diff(got, want, "deconv+ps")
+
+
+def test_clock_probe_records(lib):
+    """vfi_clock_probe (include/vfi_hip.h, r5): while a buffer is installed every launch of the Winograd kernel fills one record —
+    s_memtime / s_memrealtime of workgroup 0 at its start and end + the host's launch index — and bench.py turns the two deltas into the
+    shader clock.  Checks the record contents, the names, that a full buffer stops recording, and that uninstalling stops it."""
+    import ctypes as C
+
+    from cfi_amd import _lib
+
+    n, h, w, c = 4, 136, 240, 64
+    x = torch.rand(n, h, w, c, device="cuda")
+    wt, b = (torch.rand(c, c, 3, 3) - 0.5) * 0.1, torch.rand(c) - 0.5
+    out = torch.empty(n, h, w, c, device="cuda")
+
+    def launch():
+        _check(lib, lib.vfi_conv3x3(C.c_void_p(x.data_ptr()), C.c_void_p(wt.data_ptr()), C.c_void_p(b.data_ptr()), None, C.c_void_p(out.data_ptr()),
+                                    n, h, w, c, c, 1, 1, 0.2, 100, None), "vfi_conv3x3")
+
+    launch()
+    torch.cuda.synchronize()
+    rec = torch.zeros((3, 8), dtype=torch.int64, device="cuda")
+    _check(lib, lib.vfi_clock_probe(C.c_void_p(rec.data_ptr()), 3), "vfi_clock_probe")
+    try:
+        for _ in range(5):          # two more launches than records: the extra ones must not write anywhere
+            launch()
+        torch.cuda.synchronize()
+    finally:
+        _check(lib, lib.vfi_clock_probe(None, 0), "vfi_clock_probe off")
+    names = _lib.clock_probe_names()
+    assert len(names) == 5 and len(set(names)) == 1, names
+    r = rec.cpu().numpy().astype("uint64")
+    for i, (t0, r0, t1, r1, tag, *rest) in enumerate(r.tolist()):
+        assert t1 > t0 and r1 > r0 and tag == i and rest == [0, 0, 0], (i, t0, r0, t1, r1, tag, rest)
+        mhz = (t1 - t0) / (r1 - r0) * 100.0
+        assert 400.0 < mhz < 2600.0, mhz          # s_memrealtime = 100 MHz; the shader clock of an MI355X under load
+    before = rec.clone()
+    launch()
+    torch.cuda.synchronize()
+    assert torch.equal(rec, before), "a launch after the probe was uninstalled wrote a record"
