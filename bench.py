@@ -947,16 +947,33 @@ def result_line(args, world, elapsed, traced, rep, eng, collective, clock=None):
     # the frame pack (clamp / pad + encode.0 + encode.1 in one kernel): per FRAME, RGB fp32 in, the two planar4 planes out; B + 1 frames per step
     enc_frame_bytes = 12.0 * H * W + 32.0 * full
     roofline_hbm = []
+    hbm_traffic, hbm_traffic_src = {}, None      # PMC bytes per launch of these kernels from the committed passes (they cannot share a run with this timing)
+    try:
+        hk = json.load(open(tpath))["hbm_kernels"]
+        hbm_traffic = {k: v * B / float(hk["batch"]) * (hp * wp) / float(hk["padded_pixels"]) for k, v in hk["bytes_per_launch"].items()}
+        hbm_traffic_src = "profiles/roofline_traffic.json (" + hk["source"] + "), not measured in this run"
+    except Exception:  # noqa: BLE001
+        pass
+
+    def with_traffic(e, name):
+        if name in hbm_traffic:
+            e["traffic"] = int(hbm_traffic[name])
+            e["traffic_over_algorithmic"] = round(e["traffic"] / e["algorithmic_bytes_per_launch"], 3)
+            e["traffic_source"] = hbm_traffic_src
+        return e
+
     for name, (what, per_task) in hbm_bytes.items():
         if name in rep and rep[name][0]:
             c, m = rep[name]
-            roofline_hbm.append(hbm_entry(f"{name}: {what}; {B} tasks per launch", per_task * B, m / c, c))
+            roofline_hbm.append(with_traffic(hbm_entry(f"{name}: {what}; {B} tasks per launch", per_task * B, m / c, c), name))
     if "encode_batch" in rep and rep["encode_batch"][0]:
         c, m = rep["encode_batch"]
         e = hbm_entry(f"encode_batch: frame pack (clamp / pad + encode.0 Conv 3->16 s2 + encode.1 Deconv 16->4) of {B + 1} frames in one persistent "
                       f"launch: RGB fp32 in, planar4 image + feature planes out", enc_frame_bytes * (B + 1), m / c, c)
         e["valu_floor_ms"] = round((B + 1) * (hp * wp / 1024.0) * 256 * (2 * 27 * 16 + 1024) / VALU_LANE_OPS_PER_S * 1e3, 4)      # per 32x32 tile: 2 rounds x 432 + 1024 FMA per thread
-        roofline_hbm.insert(0, e)
+        if "encode_batch" in hbm_traffic:      # (recorded for B + 1 = 33 frames)
+            hbm_traffic["encode_batch"] = hbm_traffic["encode_batch"] * (B + 1) / float(B) * 32.0 / 33.0
+        roofline_hbm.insert(0, with_traffic(e, "encode_batch"))
     elif "encode_fused" in rep and rep["encode_fused"][0]:
         c, m = rep["encode_fused"]
         roofline_hbm.insert(0, hbm_entry("encode_fused: frame pack of ONE frame per launch", enc_frame_bytes, m / c, c))

@@ -33,6 +33,7 @@ def test_single_gpu_line(hip_lib):
     assert names[0] == "encode_batch" and {"stage_trans4", "stage_trans2", "trans1_conv0a", "final_blend"} <= set(names)
     for e in res["roofline_hbm"]:
         assert e["bound"] == "hbm" and 0 < e["frac"] <= 1.0
+        assert 0.9 < e["traffic_over_algorithmic"] < 3.0, e          # r5: PMC bytes of the committed passes beside the algorithmic ones
     st = res["strong_4k_x4"]
     assert st["scaling"] == "strong" and st["n_gpus"] == 1 and st["tasks_per_rank"] == [9] and st["value"] > 0      # 3 pairs x 3 timesteps
     op = res["other_paths"]["roofline_hbm"]
