@@ -1324,6 +1324,8 @@ def main():
         if world > 1:
             res["config"]["reserved_cus"] = reserve
             res["config"]["nccl_max_nchannels"] = os.environ.get("NCCL_MAX_NCHANNELS")
+            res["config"]["reserved_cus_note"] = ("reserved_cus was chosen in-run from the untimed trials below (the same step loop); RCCL's channel cap is bound when the "
+                                                  "communicator is created and stays at the planned reserve whatever the trials choose")
             if reserve_trials is not None:
                 res["config"]["reserved_cus_trials_ms_per_step"] = {str(c): round(v * 1e3, 3) for c, v in reserve_trials.items()}
     # The headline is measured; every later leg is extra.  A leg that RAISES is recorded as an error string; a leg that STALLS
