@@ -303,3 +303,35 @@ def test_clock_probe_records(lib):
     launch()
     torch.cuda.synchronize()
     assert torch.equal(rec, before), "a launch after the probe was uninstalled wrote a record"
+
+
+def test_wino_probe_forms_are_bit_identical(lib):
+    """The cycle-ledger forms of the hot Winograd instantiation (test option wino_probe = 1..4, tools/wino_ledger.py,
+    docs/design/winograd.md section 5b) compute exactly what the product kernel computes, and each leaves its stamp sums."""
+    import ctypes as C
+
+    n, h, w, c = 8, 136, 240, 64
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(n, h, w, c, generator=g) - 0.5).cuda()
+    wt, b = (torch.rand(c, c, 3, 3, generator=g) - 0.5) * 0.1, torch.rand(c, generator=g) - 0.5
+
+    def run(probe):
+        assert lib.vfi_test_set_option(b"wino_probe", probe) == 0
+        out = torch.empty(n, h, w, c, device="cuda")
+        _check(lib, lib.vfi_conv3x3(C.c_void_p(x.data_ptr()), C.c_void_p(wt.data_ptr()), C.c_void_p(b.data_ptr()), None, C.c_void_p(out.data_ptr()),
+                                    n, h, w, c, c, 1, 1, 0.2, 100, None), "vfi_conv3x3")
+        torch.cuda.synchronize()
+        return out
+
+    try:
+        base = run(0)
+        for probe in (1, 2, 3, 4):
+            out = run(probe)
+            assert torch.equal(out, base), f"probe form {probe} changed the output"
+            sums = (C.c_uint32 * 32)()
+            _check(lib, lib.vfi_test_wino_probe_read(sums), "vfi_test_wino_probe_read")
+            for wave in range(4):
+                q = list(sums[wave * 8:(wave + 1) * 8])
+                assert q[7] == probe and q[4] > 0 and q[6] > 0, (probe, wave, q)      # probe id, stamps taken, chunks walked
+    finally:
+        lib.vfi_test_set_option(b"wino_probe", 0)
