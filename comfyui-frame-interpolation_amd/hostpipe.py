@@ -167,6 +167,25 @@ def _rings_grow(r, device, shape, n_up, n_down):
     return r
 
 
+def prewarm_rings_async(device, shape, up_dtype, down_dtype, n_up, n_down):
+    """First call of a process: pin the staging rings on a side thread WHILE the caller loads and packs the checkpoint (pinning ~1 GB
+    is as long as building the engine: the two used to run back to back).  Returns the thread; the caller joins it before it builds
+    its Uploader / Downloader, which then find the grown sets in the cache."""
+    def work():
+        try:
+            torch.cuda.set_device(device)
+            up = _rings_grow(_rings_acquire(device, shape, up_dtype, "up"), device, shape, n_up, 0)
+            _rings_release(up)
+            down = _rings_grow(_rings_acquire(device, shape, down_dtype, "down"), device, shape, 0, n_down)
+            _rings_release(down)
+        except Exception:      # best effort: the pipelines allocate what is missing themselves
+            pass
+
+    t = threading.Thread(target=work, name="vfi-prewarm", daemon=True)
+    t.start()
+    return t
+
+
 class Uploader:
     """Stages ``frames[order[i]]`` (host, [H,W,C>=3]) to the device ahead of use.  ``get(i)`` returns a device tensor
     [H,W,3] valid on ``main`` until ``release(i)``; items must be consumed in order."""

@@ -520,7 +520,19 @@ class RIFE_VFI:
             return (out.to(torch_dtype).to(torch.float32),)
         arch_ver = CKPT_NAME_VER_DICT[ckpt_name]
         cache_key = (ckpt_name,)
+        prewarm = None
         if cache_key not in _model_cache:
+            if arch_ver != "4.0" and world()[1] == 1 and os.environ.get("VFI_DEVICES", "current") == "current" and torch.cuda.is_available() \
+                    and frames.dim() == 4 and len(frames) >= 2:
+                # the process's first call: pin the host staging rings beside the checkpoint load / weight pack (hostpipe.prewarm_rings_async)
+                from .hostpipe import prewarm_rings_async
+
+                _, tasks_ = rife_task_list(len(frames), multiplier, optional_interpolation_states)
+                bs_ = effective_batch(batch_size, frames.shape[1], frames.shape[2], len(tasks_))
+                u8_ = frames.dtype == torch.uint8
+                prewarm = prewarm_rings_async(torch.device("cuda", torch.cuda.current_device()), (frames.shape[1], frames.shape[2], 3),
+                                              torch.uint8 if u8_ else torch.float32, torch.uint8 if u8_ else torch.float32,
+                                              min(len(frames), 2 * bs_ + 2 + PACK_AHEAD), 2 * bs_)
             model_path = load_file_from_github_release(MODEL_TYPE, ckpt_name)
             sd = torch.load(model_path, map_location="cpu", weights_only=False)
             if arch_ver == "4.0":
@@ -601,6 +613,8 @@ class RIFE_VFI:
             # ~25 worker threads move frames while this thread feeds the GPU: at CPython's default 5 ms switch interval a thread that
             # wants the GIL can wait that long for it — the launch loop lost 10 ms between two launches that way
             # (profiles/r04_e2e_timeline.txt)
+            if prewarm is not None:
+                prewarm.join()
             with _short_switch_interval():
                 run_tasks(engine, frames, tasks, batch_size, scale_factor, out=out, out_rows=new_rows, on_staged=start_host_side)
             start_host_side()
