@@ -79,7 +79,10 @@ def valu_entry(kernel, lane_ops_per_launch, ms_per_launch, launches, note):
     return {"kernel": kernel, "bound": "valu", "lane_ops_per_launch": int(lane_ops_per_launch), "avg_launch_ms": round(ms_per_launch, 4),
             "launches": launches, "valu_floor_ms": round(floor_ms, 4), "peak": round(VALU_LANE_OPS_PER_S / 1e12, 1), "unit": "T lane-ops/s",
             "achieved": round(lane_ops_per_launch / (ms_per_launch * 1e-3) / 1e12, 2) if ms_per_launch else None,
-            "frac": round(floor_ms / ms_per_launch, 4) if ms_per_launch else None, "note": note}
+            "frac": round(floor_ms / ms_per_launch, 4) if ms_per_launch else None,
+            # the same against the UNPACKED VALU rate (16 lanes per clock and SIMD: half of `peak`) — what a kernel whose operations have no
+            # packed form can reach (the cost volume's |a - b|: VOP3P carries no abs modifier); `frac` keeps the packed peak
+            "frac_unpacked_rate": round(2.0 * floor_ms / ms_per_launch, 4) if ms_per_launch else None, "note": note}
 
 
 def clip_frames(B):
