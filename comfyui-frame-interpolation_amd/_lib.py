@@ -2,19 +2,40 @@
 
 There is deliberately no fallback: if the library is missing or a call fails, a
 ``RuntimeError`` is raised — the product path never routes through torch ops or the oracle.
+
+Two builds of the same sources exist (csrc/build.py): ``libvfi_hip.so`` — the product, exactly the entry points of
+include/vfi_hip.h — and ``libvfi_hip_test.so``, which adds the test taps of include/vfi_hip_test.h (A/B switches between
+two correct kernel forms, read-back of internal tensors).  The package loads the product library; ``use_test_build()`` —
+called by tests/conftest.py and tools/, never by the package — selects the other one before the first ``load()``.
 """
 import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvfi_hip.so")
+TEST_LIB_PATH = os.path.join(_HERE, "libvfi_hip_test.so")
 
 _lib = None
+_test_build = False
+
+
+def use_test_build():
+    """Select libvfi_hip_test.so for this process (tests/ and tools/ only).  One process uses ONE library — it owns per-device
+    workspaces — so this must come before the first load()."""
+    global _test_build
+    if _lib is not None and not _test_build:
+        raise RuntimeError("use_test_build(): the product library is already loaded in this process")
+    _test_build = True
+
+
+def is_test_build():
+    return _test_build
 
 c_float_p = C.POINTER(C.c_float)
 c_int_p = C.POINTER(C.c_int)
 
-# name -> (restype, argtypes); mirrors include/vfi_hip.h one to one
+# name -> (restype, argtypes); PROTOTYPES mirrors include/vfi_hip.h one to one, TEST_PROTOTYPES include/vfi_hip_test.h
+TEST_NAMES = ("vfi_conv3x3_naive", "vfi_test_conv_algo", "vfi_test_pack_wino3x3", "vfi_test_pack_deconv3x3", "vfi_test_set_option", "vfi_test_variant_override", "vfi_test_wino_probe_read", "vfi_rife_debug_keep", "vfi_rife_debug_read", "vfi_test_film_schedule", "vfi_test_linspace01", "vfi_film_debug_read_flow", "vfi_m2m_debug_read")
 PROTOTYPES = {
     "vfi_init": (C.c_int, [C.c_int]),
     "vfi_last_error": (C.c_char_p, []),
@@ -167,6 +188,8 @@ PROTOTYPES = {
     "vfi_comm_all_gather_mode": (C.c_int, []),
 }
 
+TEST_PROTOTYPES = {k: PROTOTYPES.pop(k) for k in TEST_NAMES}
+
 
 # The runtime variables this package honours — all of them select resources or diagnostics, none changes a frame's values
 # (INTEGRATION.md "Environment").  Kernel A/B switches are NOT environment variables: include/vfi_hip_test.h, vfi_test_set_option.
@@ -201,22 +224,35 @@ def load():
     if _lib is not None:
         return _lib
     audit_environment()
-    if not os.path.exists(LIB_PATH):
+    path = TEST_LIB_PATH if _test_build else LIB_PATH
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} not found: the HIP extension is not built. Run `python __graft_entry__.py build` "
+            f"{path} not found: the HIP extension is not built. Run `python __graft_entry__.py build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the VFI hot path.")
     # torch ships its own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7 — the same SONAME as the ROCm
     # install this library was linked against).  Whichever is mapped first serves both; if ours came first, torch would
     # run on a runtime it was not built with and the second initialisation finds no device.  So: torch first, always.
     import torch  # noqa: F401
 
-    lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in PROTOTYPES.items():
+    lib = C.CDLL(path)
+    protos = dict(PROTOTYPES)
+    if _test_build:
+        protos.update(TEST_PROTOTYPES)
+    for name, (res, args) in protos.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def test_tap(name):
+    """A test tap of include/vfi_hip_test.h, or a RuntimeError that says why it is not there (the product library has none)."""
+    lib = load()
+    if not _test_build:
+        raise RuntimeError(f"{name} is a test tap (include/vfi_hip_test.h): only libvfi_hip_test.so has it — call "
+                           "cfi_amd._lib.use_test_build() before the library is first loaded (tests/conftest.py does)")
+    return getattr(lib, name)
 
 
 def last_error():

@@ -13,8 +13,10 @@ import sys
 
 CSRC = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(CSRC)
-LIB = os.path.join(PKG, "libvfi_hip.so")
+LIB = os.path.join(PKG, "libvfi_hip.so")                # the product library: exactly the entry points of include/vfi_hip.h
+LIB_TEST = os.path.join(PKG, "libvfi_hip_test.so")      # the same objects + the test taps of include/vfi_hip_test.h (-DVFI_TEST_TAPS): tests/ and tools/ only
 STAMP = LIB + ".stamp"
+TAPS_MACRO = "VFI_TEST_TAPS"
 ARCH = "gfx950"
 # per-file flags.  conv_wino.hip: hipcc's SLP vectoriser packs the input-transform adds into v_pk_add_f32 with v_mov shuffles
 # — packed f32 VALU beside MFMAs is an anti-lever on gfx950 (MI355X_MICROARCH.md, per-instruction constants) and costs registers
@@ -40,27 +42,46 @@ def _digest():
     return h.hexdigest()
 
 
+def _has_taps(src):
+    with open(src) as fh:
+        return TAPS_MACRO in fh.read()
+
+
 def build_lib(force=False, verbose=True):
+    """Builds BOTH libraries; returns the product one.  Translation units that carry test taps (`#ifdef VFI_TEST_TAPS`) are compiled
+    twice — without the macro for libvfi_hip.so, with it for libvfi_hip_test.so; every other object is shared.  The product library
+    therefore has no entry point that changes a kernel choice (vfi_test_set_option, vfi_test_variant_override, vfi_test_conv_algo) and
+    none of the read-back taps."""
     d = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read().strip() == d:
+    if not force and os.path.exists(LIB) and os.path.exists(LIB_TEST) and os.path.exists(STAMP) and open(STAMP).read().strip() == d:
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
+    objs, objs_test = [], []
     procs = []
     for src in _sources():
-        obj = os.path.join(CSRC, os.path.basename(src)[:-4] + ".o")
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"] + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        procs.append((subprocess.Popen(cmd), src))
+        base = os.path.basename(src)
+        obj = os.path.join(CSRC, base[:-4] + ".o")
+        common = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"] + EXTRA_FLAGS.get(base, [])
+        jobs = [(common + ["-c", src, "-o", obj], obj)]
         objs.append(obj)
+        if _has_taps(src):
+            tobj = os.path.join(CSRC, base[:-4] + ".taps.o")
+            jobs.append((common + ["-D" + TAPS_MACRO, "-c", src, "-o", tobj], tobj))
+            objs_test.append(tobj)
+        else:
+            objs_test.append(obj)
+        for cmd, _ in jobs:
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((subprocess.Popen(cmd), src))
     for p, src in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]   # dl: comm.hip binds RCCL at first use
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    for lib, ob in ((LIB, objs), (LIB_TEST, objs_test)):
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib] + ob + ["-ldl"]   # dl: comm.hip binds RCCL at first use
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
     with open(STAMP, "w") as f:
         f.write(d + "\n")
     return LIB

@@ -101,7 +101,12 @@ int vfi_conv3x3(const float* in_dev, const float* weight_host, const float* bias
     return 0;
 }
 
+#ifdef VFI_TEST_TAPS      // include/vfi_hip_test.h: only in libvfi_hip_test.so
 int vfi_test_conv_algo(int mode) { return conv_wino_mode(mode); }
+int vfi_test_wino_probe_read(uint32_t* out32) {
+    VFI_REQUIRE(out32, "vfi_test_wino_probe_read: null buffer");
+    return wino_probe_read(out32);
+}
 
 int64_t vfi_test_pack_wino3x3(const float* weight_host, int Cout, int Cin, const int* chan_map, int Cin_p, float* out_host, int64_t cap) {
     if (!weight_host || !out_host || Cout <= 0 || Cin <= 0 || Cin_p % 8 || Cin_p < Cin) {
@@ -155,6 +160,7 @@ int vfi_conv3x3_naive(const float* in_dev, const float* weight_host, const float
     VFI_CHECK_HIP(hipStreamSynchronize(st));
     return 0;
 }
+#endif  // VFI_TEST_TAPS
 
 int vfi_deconv4x4_ps2(const float* in_dev, const float* weight_host, const float* bias_host, float* out_dev, int N,
                       int H, int W, int Cin, int Cout, void* stream) {

@@ -100,6 +100,7 @@ static void film_schedule(int inter, std::vector<int>& triples) {
 
 extern "C" {
 
+#ifdef VFI_TEST_TAPS      // include/vfi_hip_test.h: only in libvfi_hip_test.so
 int vfi_test_linspace01(int n, float* out) {
     if (n < 1 || !out) {
         set_error("vfi_test_linspace01: bad arguments");
@@ -124,6 +125,7 @@ int vfi_test_film_schedule(int inter_frames, int* triples, int cap) {
     if (!t.empty()) memcpy(triples, t.data(), t.size() * sizeof(int));
     return (int)t.size() / 3;
 }
+#endif  // VFI_TEST_TAPS
 
 int vfi_film_run(vfi_film_t* net, const float* frames_host, int N, int H, int W, int C, int multiplier, const int* multipliers,
                  int n_multipliers, const uint8_t* skip, float* out_host, int64_t* n_out) {

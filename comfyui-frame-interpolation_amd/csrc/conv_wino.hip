@@ -658,9 +658,11 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const WinoArgs p) {
 static std::mutex g_clk_mu;
 static std::vector<const char*> g_clk_names;
 static std::atomic<bool> g_clk_on{false};
+static int g_clk_cap_host = 0;      // records the installed buffer holds (guarded by g_clk_mu)
 int clock_probe_tag(const char* name) {
     if (!g_clk_on.load(std::memory_order_acquire)) return -1;
     std::lock_guard<std::mutex> lk(g_clk_mu);
+    if ((int)g_clk_names.size() >= g_clk_cap_host) return -1;      // the buffer is full: later launches take no record and no name
     g_clk_names.push_back(name);
     return (int)g_clk_names.size() - 1;
 }
@@ -673,6 +675,9 @@ int wino_probe_read(unsigned* out32) {      // [4 waves][8]: the sums of the LAS
 
 int clock_probe_install(unsigned long long* dev_records, int capacity) {      // on the CURRENT device
     const unsigned cap = dev_records ? (unsigned)capacity : 0u, zero = 0u;
+    // A probed launch still in flight reads these symbols again at its end (workgroup 0's closing stamp): changing them under it would
+    // send that stamp to the new buffer or to nullptr.  hipMemcpyToSymbol does not order with non-blocking streams, so drain the device.
+    VFI_CHECK_HIP(hipDeviceSynchronize());
     VFI_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_clk_next_dev), &zero, sizeof(zero)));
     VFI_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_clk_cap_dev), &cap, sizeof(cap)));
     VFI_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_clk_buf_dev), &dev_records, sizeof(dev_records)));
@@ -766,8 +771,10 @@ bool conv_wino_eligible(const ConvArgs& a) {
     // there (profiles/r05_film_algo_ab.txt: 1920 -> 256 @67x120 1.88 vs 1.28 ms, 256 -> 256 0.83 vs 0.62), while 576 items (512 channels,
     // 2.25 rounds) stay 1.6x faster on this kernel.
     if (option(kOptWinoQuant)) {
-        int dev = 0;
-        const long cus = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDevices ? wino_cus(dev) : 256;
+        // against the NOMINAL 256 compute units of the MI355X this library is built for — not the calling thread's current device, not
+        // the reserved-CU setting: the two kernels sum in different orders, so the choice (and with it a frame's low-order bits) must be a
+        // function of the layer and the image alone, the same on every device, thread and launch
+        const long cus = 256;
         const long rounds = (items + cus - 1) / cus;
         if (rounds <= 2 && items * 100 < rounds * cus * 60) return false;
     }
@@ -885,6 +892,7 @@ int vfi_clock_probe(void* dev_records, int capacity) {
     const bool on = dev_records != nullptr && capacity > 0;
     if (clock_probe_install(on ? (unsigned long long*)dev_records : nullptr, on ? capacity : 0) != 0) return -1;
     if (on) g_clk_names.clear();       // (uninstalling keeps the names: they are read after the measured region)
+    if (on) g_clk_cap_host = capacity;
     g_clk_on.store(on, std::memory_order_release);
     return 0;
 }
@@ -901,8 +909,4 @@ int vfi_clock_probe_names(char* buf, int buf_len) {
     return (int)g_clk_names.size();
 }
 
-int vfi_test_wino_probe_read(uint32_t* out32) {
-    VFI_REQUIRE(out32, "vfi_test_wino_probe_read: null buffer");
-    return wino_probe_read(out32);
-}
 }  // extern "C"

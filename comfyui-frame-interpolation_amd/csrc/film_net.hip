@@ -331,7 +331,8 @@ int vfi_film_forward(vfi_film_t* net, const float* x0_dev, const float* x1_dev, 
     return conv_raw(net->out_conv, *cur, 0, out_dev, 3, H, W, clamp ? 2 : 0, st);
 }
 
-// test tap (include/vfi_hip_test.h): the synthesised flow pyramid of the LAST forward, direction d (0 forward, 1 backward), level l
+#ifdef VFI_TEST_TAPS
+// test tap (include/vfi_hip_test.h, libvfi_hip_test.so only): the synthesised flow pyramid of the LAST forward, direction d (0 forward, 1 backward), level l
 int64_t vfi_film_debug_read_flow(vfi_film_t* net, int d, int level, float* host_buf, int64_t cap) {
     if (!net || net->H == 0 || d < 0 || d > 1 || level < 0 || level >= PYR) {
         set_error("vfi_film_debug_read_flow: nothing to read (d=%d level=%d)", d, level);
@@ -345,5 +346,6 @@ int64_t vfi_film_debug_read_flow(vfi_film_t* net, int d, int level, float* host_
     }
     return n;
 }
+#endif  // VFI_TEST_TAPS
 
 }  // extern "C"

@@ -380,7 +380,8 @@ int vfi_m2m_render(vfi_m2m_t* m, float t, float* out_dev, void* stream) {
     return vfi_m2m_combine(m->sout.p, m->d0.p, 8, m->stats, t, out_dev, Hp, Wp, m->H, m->W, st);
 }
 
-// test tap (include/vfi_hip_test.h): internal tensors of the LAST prepare — what 0: PWC flows at 1/4 of the padded size
+#ifdef VFI_TEST_TAPS
+// test tap (include/vfi_hip_test.h, libvfi_hip_test.so only): internal tensors of the LAST prepare — what 0: PWC flows at 1/4 of the padded size
 // [2,Hp/4,Wp/4,2]; 1: d0 [2,Hp,Wp,8] (refined-flow base | normalised image | warped partner); 2: r [2,Hp,Wp,12] (8 residuals | mask)
 int64_t vfi_m2m_debug_read(vfi_m2m_t* m, int what, float* host_buf, int64_t cap) {
     if (!m || !m->prepared || what < 0 || what > 2) {
@@ -395,5 +396,6 @@ int64_t vfi_m2m_debug_read(vfi_m2m_t* m, int what, float* host_buf, int64_t cap)
     }
     return n;
 }
+#endif  // VFI_TEST_TAPS
 
 }  // extern "C"

@@ -657,6 +657,7 @@ int vfi_rife_interpolate(vfi_rife_t* net, int B, const int* slot0, const int* sl
     return 0;
 }
 
+#ifdef VFI_TEST_TAPS      // include/vfi_hip_test.h: only in libvfi_hip_test.so
 int vfi_rife_debug_keep(vfi_rife_t* net, int on) {
     VFI_REQUIRE(net, "null handle");
     net->keep = on != 0;
@@ -692,6 +693,7 @@ int64_t vfi_rife_debug_read(vfi_rife_t* net, int what, int stage, float* host_bu
     }
     return (int64_t)n;
 }
+#endif  // VFI_TEST_TAPS
 
 int vfi_rife_work(vfi_rife_t* net, double* conv_flop_per_task, double* hbm_bytes_per_task) {
     VFI_REQUIRE(net && net->Hp > 0, "vfi_rife_work: network not configured");

@@ -46,6 +46,7 @@ long option(Option o) {
     opt_init();
     return g_opt[o].load(std::memory_order_relaxed);
 }
+#ifdef VFI_TEST_TAPS      // the product library has no way to leave the defaults (include/vfi_hip_test.h; csrc/build.py builds the test library)
 int option_set(const char* name, long value) {
     opt_init();
     for (int i = 0; i < kOptCount; ++i)
@@ -56,12 +57,14 @@ int option_set(const char* name, long value) {
     set_error("vfi_test_set_option: unknown option '%s'", name ? name : "(null)");
     return -2;
 }
+#endif
 int variant_override(const char* trace_name) {
     if (!trace_name || !g_variant_override_n.load(std::memory_order_acquire)) return -1;
     std::lock_guard<std::mutex> lk(g_opt_mu);
     auto it = g_variant_override.find(trace_name);
     return it == g_variant_override.end() ? -1 : it->second;
 }
+#ifdef VFI_TEST_TAPS
 static void variant_override_set(const char* spec) {      // "conv0a_b3=42,resconv_c128=36"; empty / null clears
     std::lock_guard<std::mutex> lk(g_opt_mu);
     g_variant_override.clear();
@@ -75,6 +78,7 @@ static void variant_override_set(const char* spec) {      // "conv0a_b3=42,resco
     }
     g_variant_override_n.store((int)g_variant_override.size(), std::memory_order_release);
 }
+#endif
 
 struct TraceRec {
     const char* name;
@@ -182,11 +186,13 @@ int vfi_memcpy_async(void* dst, const void* src, int64_t bytes, int kind, void* 
     return 0;
 }
 
+#ifdef VFI_TEST_TAPS
 int vfi_test_set_option(const char* name, int64_t value) { return option_set(name, (long)value); }
 int vfi_test_variant_override(const char* spec) {
     variant_override_set(spec);
     return 0;
 }
+#endif
 
 int vfi_trace_enable(int on) {
     g_trace = on != 0;

@@ -64,7 +64,7 @@ class FilmEngine:
     def debug_flow(self, d, level, h, w):
         """test tap: flow pyramid level of the last forward, direction d (0 forward, 1 backward) -> [h,w,2] host tensor"""
         buf = torch.empty(h * w * 2, dtype=torch.float32)
-        n = self.lib.vfi_film_debug_read_flow(self.handle, d, level, buf.data_ptr(), buf.numel())
+        n = _lib.test_tap("vfi_film_debug_read_flow")(self.handle, d, level, buf.data_ptr(), buf.numel())
         if n != buf.numel():
             raise RuntimeError("vfi_film_debug_read_flow: " + _lib.last_error())
         return buf.view(h, w, 2)

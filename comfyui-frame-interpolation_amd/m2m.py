@@ -97,7 +97,7 @@ class M2MEngine:
     # -- test taps (include/vfi_hip_test.h) ------------------------------------------------------------------------------
     def _debug(self, what, shape):
         buf = torch.empty(shape, dtype=torch.float32)
-        n = self.lib.vfi_m2m_debug_read(self.handle, what, buf.data_ptr(), buf.numel())
+        n = _lib.test_tap("vfi_m2m_debug_read")(self.handle, what, buf.data_ptr(), buf.numel())
         if n != buf.numel():
             raise RuntimeError("vfi_m2m_debug_read: " + _lib.last_error())
         return buf

@@ -159,11 +159,11 @@ class RifeEngine:
 
     # -- test taps -----------------------------------------------------------------------
     def debug_keep(self, on=True):
-        _lib.check(self.lib.vfi_rife_debug_keep(self.handle, int(on)), "vfi_rife_debug_keep")
+        _lib.check(_lib.test_tap("vfi_rife_debug_keep")(self.handle, int(on)), "vfi_rife_debug_keep")
 
     def debug_read(self, what, stage, numel):
         buf = torch.empty(numel, dtype=torch.float32)
-        n = self.lib.vfi_rife_debug_read(self.handle, what, stage, buf.data_ptr(), numel)
+        n = _lib.test_tap("vfi_rife_debug_read")(self.handle, what, stage, buf.data_ptr(), numel)
         if n < 0:
             raise RuntimeError("vfi_rife_debug_read: " + _lib.last_error())
         return buf[:n]
@@ -323,7 +323,14 @@ def run_tasks(engine, frames_cpu, tasks, batch_size, scale_factor=1.0, out_devic
     for bi, (_, _, need) in enumerate(batches):
         for f in need:
             first_use.setdefault(f, bi)
-    alive = max((sum(1 for f in order if first_use[f] <= bi <= last_use[f]) for bi in range(len(batches))), default=0)
+    delta = [0] * (len(batches) + 1)      # one sweep: +1 at a frame's first launch, -1 after its last (O(frames + launches))
+    for f in order:
+        delta[first_use[f]] += 1
+        delta[last_use[f] + 1] -= 1
+    alive = live = 0
+    for d in delta[:-1]:
+        live += d
+        alive = max(alive, live)
     if alive > n_slots - PACK_AHEAD:
         raise ValueError(f"run_tasks: {alive} frames are alive at one launch but the frame cache holds {n_slots - PACK_AHEAD} (+ {PACK_AHEAD} packed ahead); "
                          f"pass the tasks sorted by pair (schedule.rife_task_list order) or a smaller batch_size")

@@ -47,7 +47,9 @@ int vfi_trace_report(char* buf, int buf_len);
  * s_memrealtime at a constant rate (100 MHz; bench.py checks it against the HIP-event duration of the same launches):
  *   sustained MHz of launch i = (t1 - t0) / (r1 - r0) x 100.
  * dev_records: buffer of capacity * 8 uint64 on the CURRENT device, zeroed by the caller; NULL / 0 uninstalls (the names stay
- * readable).  vfi_clock_probe_names writes the trace names of the probed launches, one per line; line `tag` names record `tag`;
+ * readable).  Installing / uninstalling SYNCHRONISES the device first (a probed launch in flight re-reads the installed buffer for its
+ * closing stamp), so the buffer may be freed as soon as the uninstalling call has returned.  At most `capacity` launches take a record
+ * and a name.  vfi_clock_probe_names writes the trace names of the probed launches, one per line; line `tag` names record `tag`;
  * returns their count (< 0 on error). */
 int vfi_clock_probe(void* dev_records, int capacity);
 int vfi_clock_probe_names(char* buf, int buf_len);

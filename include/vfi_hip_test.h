@@ -1,9 +1,11 @@
 /*
- * vfi_hip_test.h — TEST TAPS of libvfi_hip.so: entry points that exist for the parity tests only (a naive cross-check
- * convolution, read-back of internal tensors of the RIFE network).  Not part of the drop-in boundary: nothing in the node
- * classes' product path calls them; they are declared apart from include/vfi_hip.h so that the boundary header lists only
- * what a host application binds.  (Per-kernel tracing, vfi_trace_*, and vfi_rife_work stay in vfi_hip.h: bench.py's
- * roofline figures are part of the deliverable.)
+ * vfi_hip_test.h — TEST TAPS: entry points that exist for the parity tests and A/B tools only (a naive cross-check convolution,
+ * read-back of internal tensors, switches between two correct kernel forms).  They are NOT in the product library: csrc/build.py
+ * compiles them (`#ifdef VFI_TEST_TAPS`) into a second library, libvfi_hip_test.so — the product objects + these — which
+ * tests/conftest.py and tools/ select with cfi_amd._lib.use_test_build().  libvfi_hip.so exports exactly include/vfi_hip.h
+ * (tests/test_capi_symbols.py::test_product_library_has_no_test_taps): nothing loaded beside a node can flip a model's kernel choice.
+ * (Per-kernel tracing, vfi_trace_*, the clock probe and vfi_rife_work stay in vfi_hip.h: bench.py's roofline figures are part of
+ * the deliverable, and none of them changes a result.)
  */
 #ifndef VFI_HIP_TEST_H
 #define VFI_HIP_TEST_H
@@ -38,7 +40,7 @@ int64_t vfi_test_pack_deconv3x3(const float* weight_host, const float* bias_host
  *   stage_quad (bit mask, default 14), fuse_encode (1), fuse0a (1), m2n2_px (-1), grouped_variant (-1), splitk (1), splat_atomic (0),
  *   splat_spill_cap (-1), wino_xcd (1), deconv_wino (1), encode_batched (1), wino_quant (1), wino_probe (0; 1..4 = the cycle-ledger forms of the hot
  *   Winograd instantiation: same results, s_memtime stamps summed per wave of workgroup 0).
- * The product library reads NO experiment switch from the environment; this call is the only way to leave the defaults.
+ * The product library reads NO experiment switch from the environment and does not contain this call: the defaults are all it can run.
  * Returns 0, or -2 for an unknown name. */
 int vfi_test_set_option(const char* name, int64_t value);
 /* The stamp sums of the last launch made under wino_probe != 0 on the current device: [4 waves][8] uint32 = q0, q1, q2, q3 (sums mod

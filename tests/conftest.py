@@ -11,6 +11,13 @@ from pkgload import load_package  # noqa: E402
 
 load_package()  # registers the hyphen-named package directory as ``cfi_amd``
 
+from cfi_amd import _lib as _vfi_lib  # noqa: E402
+
+# The suite runs on libvfi_hip_test.so: the product objects + the test taps of include/vfi_hip_test.h (A/B switches, read-backs).
+# The product library itself (libvfi_hip.so, what the package loads everywhere else) is covered by tests/test_capi_symbols.py
+# (exports), tests/test_gpu_product_build.py (parity, in a child process), bench.py and __graft_entry__.smoke().
+_vfi_lib.use_test_build()
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

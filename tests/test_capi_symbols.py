@@ -18,9 +18,36 @@ def test_header_and_binding_agree(hip_lib):
     product, taps = header_functions(), header_functions("vfi_hip_test.h")
     names = sorted(product + taps)
     assert len(product) >= 15 and taps == ["vfi_conv3x3_naive", "vfi_film_debug_read_flow", "vfi_m2m_debug_read", "vfi_rife_debug_keep", "vfi_rife_debug_read", "vfi_test_conv_algo", "vfi_test_film_schedule", "vfi_test_linspace01", "vfi_test_pack_deconv3x3", "vfi_test_pack_wino3x3", "vfi_test_set_option", "vfi_test_variant_override", "vfi_test_wino_probe_read"]   # test taps live apart
-    assert sorted(_lib.PROTOTYPES) == names
+    assert sorted(_lib.PROTOTYPES) == product and sorted(_lib.TEST_PROTOTYPES) == taps
+    assert _lib.is_test_build()      # tests/conftest.py: the suite runs on libvfi_hip_test.so
     for n in names:
         assert getattr(hip_lib, n) is not None
+
+
+def test_product_library_has_no_test_taps(hip_lib):
+    """libvfi_hip.so — what the package, bench.py and smoke() load — exports every function of include/vfi_hip.h and NONE of
+    include/vfi_hip_test.h: nothing in the product can switch a kernel form or read an internal tensor back.
+    dlopen only, no call: the process keeps using the test build."""
+    import ctypes
+
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in header_functions():
+        assert hasattr(lib, n), n
+    for n in header_functions("vfi_hip_test.h"):
+        assert not hasattr(lib, n), f"{n} is exported by the product library"
+
+
+def test_product_build_is_the_default_in_a_fresh_process():
+    import subprocess
+    import sys
+
+    code = ("import sys; sys.path.insert(0, %r); from pkgload import load_package; load_package(); from cfi_amd import _lib; "
+            "lib = _lib.load(); assert not _lib.is_test_build() and not hasattr(lib, 'vfi_test_set_option'); "
+            "import pytest\n"
+            "try:\n    _lib.test_tap('vfi_test_set_option')\nexcept RuntimeError as e:\n    assert 'test tap' in str(e)\nelse:\n    raise SystemExit(1)\n"
+            "print('ok')") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
 
 
 def test_error_string_is_callable(hip_lib):
@@ -47,6 +74,7 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
 
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libvfi_hip.so"))
+    monkeypatch.setattr(_lib, "TEST_LIB_PATH", str(tmp_path / "libvfi_hip_test.so"))
     with pytest.raises(RuntimeError, match="not built|not found"):
         _lib.load()
 

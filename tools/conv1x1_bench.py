@@ -15,6 +15,7 @@ def child():
     import __graft_entry__ as ge
     ge.load_package()
     from cfi_amd import _lib
+    _lib.use_test_build()      # vfi_test_variant_override lives in libvfi_hip_test.so only
     lib = _lib.load()
     out = []
     for n, h, w, cin, cout, act in SHAPES:

@@ -15,6 +15,7 @@ ge.build()
 ge.load_package()
 from cfi_amd import _lib  # noqa: E402
 
+_lib.use_test_build()      # the A/B taps live in libvfi_hip_test.so only
 lib = _lib.load()
 _lib.check(lib.vfi_init(0), "init")
 

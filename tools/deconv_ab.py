@@ -15,6 +15,7 @@ ge.build()
 ge.load_package()
 from cfi_amd import _lib, synth  # noqa: E402
 
+_lib.use_test_build()      # the A/B taps live in libvfi_hip_test.so only
 lib = _lib.load()
 H, W = 1080, 1920
 fr = synth.smooth_frames(2, H, W, seed=2, shift=4.0)

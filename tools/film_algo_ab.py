@@ -15,6 +15,7 @@ ge.load_package()
 from cfi_amd import _lib, synth  # noqa: E402
 from cfi_amd.film import FilmEngine  # noqa: E402
 
+_lib.use_test_build()      # the A/B taps live in libvfi_hip_test.so only
 lib = _lib.load()
 H, W = 1080, 1920
 eng = FilmEngine(synth.film_synth_state_dict(1234))

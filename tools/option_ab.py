@@ -14,6 +14,7 @@ ge.build()
 ge.load_package()
 from cfi_amd import _lib, synth  # noqa: E402
 
+_lib.use_test_build()      # the A/B taps live in libvfi_hip_test.so only
 lib = _lib.load()
 OPT, OFF = sys.argv[1].encode(), int(sys.argv[2])
 ON = int(sys.argv[3]) if len(sys.argv) > 3 else 1

@@ -25,6 +25,7 @@ ge.build()
 ge.load_package()
 from cfi_amd import _lib  # noqa: E402
 
+_lib.use_test_build()      # the A/B taps live in libvfi_hip_test.so only
 lib = _lib.load()
 _lib.check(lib.vfi_init(0), "init")
 N, H, W, CIN, COUT = 32, 272, 480, 64, 64
