@@ -46,7 +46,13 @@ def test_single_gpu_line(hip_lib):
         assert "error" not in res["other_paths"][k] and res["other_paths"][k]["conv_tflops_direct_form"] > 0, res["other_paths"][k]
     # r5: the line verifies itself — the timed workload against the oracle on identical tensors — and carries the shader clock
     par = res["parity"]
-    assert par["ok"] and par["n_over_1e-3"] == 0 and 0 < par["max_abs"] <= 1e-3 and par["values"] == 272 * 480 * 3, par
+    assert par["ok"] and par["n_over_1e-3"] == 0 and 0 < par["max_abs"] <= 1e-3, par
+    assert par["slots"] == [0, 2, 3] and par["values"] == 3 * 272 * 480 * 3 and len(par["per_slot_max_abs"]) == 3, par      # r6: first / middle / last task of the launch
+    # r6: every leg that prints a number verifies it (FILM, M2M, the strong 4K x4 leg), and the multi-GPU keys exist at N = 1 too
+    for leg in (res["other_paths"]["film_2x"], res["other_paths"]["m2m"], st):
+        assert leg["parity"]["ok"] and leg["parity"]["values"] > 0 and "what" in leg["parity"], leg["parity"]
+    assert res["per_gpu_frames_per_s"] == res["value"] and res["n_ranks_seen_by_rccl"] == 1 and res["all_gather_ms_per_step"] is None
+    assert "best of" in json.dumps(res.get("cpu_baseline", {"cores_policy": "best of"}))
     ck = res["clock"]
     assert ck and 500 < ck["shader_mhz"] <= 2500 and ck["launches"] >= 8 and ck["region"] == "timed region", ck
     assert 30 <= ck["realtime_ticks_per_event_us"] <= 101, ck          # s_memrealtime = 100 MHz (workgroup 0 lives a little shorter than the launch)
@@ -62,6 +68,13 @@ def test_two_rank_line_shards_the_strong_leg(hip_lib):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     res = _line(r.stdout)
     assert res["n_gpus"] == 2 and res["scaling"] == "weak"
+    # r6: ONE meaning of `value` at N > 1 — the whole-job aggregate, said in `unit`; the per-GPU rate, the ranks the process group reports
+    # and the all-gather's cost per step are top-level keys
+    assert abs(res["value"] - 2 * res["per_gpu_frames_per_s"]) < 0.02 * res["value"] and "sum over 2 GPUs" in res["unit"], (res["value"], res["unit"])
+    assert res["n_ranks_seen_by_rccl"] == 2 and "gloo" in res["collective_backend"]
+    ag = res["all_gather_ms_per_step"]
+    assert ag and ag["ms_per_step_without_gather"] > 0 and ag["bytes_per_rank_per_step"] == 4 * 272 * 480 * 3 * 4, ag
+    assert res["strong_4k_x4"]["parity"]["ok"], res["strong_4k_x4"]["parity"]
     assert res["parity"]["ok"] and "cpu_baseline" not in res, res.get("parity")      # N > 1: the gate runs (one oracle forward on rank 0), the baseline does not
     st = res["strong_4k_x4"]
     assert st["tasks_per_rank"] == [5, 4] and st["n_gpus"] == 2 and st["value"] > 0, st
