@@ -168,6 +168,12 @@ PROTOTYPES = {
     "vfi_m2m_render": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "vfi_m2m_release_workspace": (C.c_int, [C.c_void_p]),
     "vfi_m2m_debug_read": (C.c_int64, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
+    "vfi_m2m_image4": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "vfi_m2m_warp_image4": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vfi_m2m_photo_tiles": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_int, C.c_int, C.c_void_p]),
+    "vfi_m2m_render_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int,
+                                       C.c_int, C.c_int, C.c_void_p]),
     "vfi_attention": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
     "vfi_window_attention": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -23,7 +23,14 @@ ARCH = "gfx950"
 EXTRA_FLAGS = {"conv_wino.hip": ["-fno-slp-vectorize"],
                # cost volume: SLP turned |a - b| accumulation (v_sub + v_add with the |x| source modifier, 2 ops) into v_pk_add + 2 v_and +
                # v_pk_add + moves (~3 per element)
-               "m2m_ops.hip": ["-fno-slp-vectorize"]}
+               "m2m_ops.hip": ["-fno-slp-vectorize", "-ffp-contract=off"],
+               # M2M's element-wise kernels restate torch's unfused fp32 sequences with __fmul_rn / __fadd_rn — which HIP defines as plain
+               # `x * y` / `x + y`, so the default -ffp-contract=fast fused them anyway (a grid coordinate lin + flow * scale as one fma moves
+               # a warp tap by an ulp of 1000 px = 6e-5 px).  Off for these files: the sequences now are what their comments say.
+               "m2m_net.hip": ["-ffp-contract=off"],
+               # the one-kernel M2M render sums in * w products exactly as the reference's atomicAdd(out, in * w): no mul + add may become an
+               # fma (a function-scope `#pragma clang fp contract(off)` did not survive inlining: 94 v_fmac_f32 in the first build)
+               "m2m_render.hip": ["-fno-slp-vectorize", "-ffp-contract=off"]}
 
 
 def _sources():

@@ -52,7 +52,9 @@ struct vfi_m2m {
     // workspace
     int H = 0, W = 0, Hp = 0, Wp = 0;
     bool prepared = false;
-    Ten d0, imh, decb[5], flow[5], enc[4], fl[5], s3, pc, ph, pw, cc, ch, cw, xf, r, tf, e, sin, sfl, sout;
+    Ten d0, imh, decb[5], flow[5], enc[4], fl[5], s3, pc, ph, pw, cc, ch, cw, xf, r, tf, e, sin, sfl, sout, img4;
+    float* tile_ranges = nullptr;      // [8][tiles][4]: per 32x32 tile the range of every refined flow field (vfi_m2m_photo_tiles)
+    float* smax = nullptr;             // [8]: max |tf_s|
     float* stats = nullptr;
     void* ws = nullptr;
     int dech[5][2], ench[4][2];
@@ -79,6 +81,8 @@ void free_workspace(vfi_m2m* m) {
     m->owned.clear();
     m->scratch.clear();
     m->stats = nullptr;
+    m->tile_ranges = m->smax = nullptr;
+    m->sin = m->sfl = m->sout = Ten();
     m->ws = nullptr;
     m->H = m->W = 0;
     m->prepared = false;
@@ -114,9 +118,16 @@ int ensure_workspace(vfi_m2m* m, int H, int W) {
     if (alloc_ten(m, m->s3, 2, e3h, e3w, 256) || alloc_ten(m, m->pc, 2, 1, 1, 256) || alloc_ten(m, m->ph, 2, e3h, 1, 256) ||
         alloc_ten(m, m->pw, 2, 1, e3w, 256) || alloc_ten(m, m->cc, 2, 1, 1, 4096) || alloc_ten(m, m->ch, 2, e3h, 1, 16) ||
         alloc_ten(m, m->cw, 2, 1, e3w, 16) || alloc_ten(m, m->xf, 2, Hp, Wp, 16) || alloc_ten(m, m->r, 2, Hp, Wp, 12) ||
-        alloc_ten(m, m->tf, 8, Hp, Wp, 2) || alloc_ten(m, m->e, 8, Hp, Wp, 1) || alloc_ten(m, m->sin, 8, Hp, Wp, 4) ||
-        alloc_ten(m, m->sfl, 8, Hp, Wp, 2) || alloc_ten(m, m->sout, 8, Hp, Wp, 4))
+        alloc_ten(m, m->tf, 8, Hp, Wp, 2) || alloc_ten(m, m->e, 8, Hp, Wp, 1) || alloc_ten(m, m->img4, 2, Hp, Wp, 4))
         return -1;
+    {
+        const size_t tiles = (size_t)((Hp + 31) / 32) * ((Wp + 31) / 32);
+        VFI_CHECK_HIP(hipMalloc((void**)&m->tile_ranges, 8 * tiles * 4 * sizeof(float)));
+        m->owned.push_back(m->tile_ranges);
+        VFI_CHECK_HIP(hipMalloc((void**)&m->smax, 8 * sizeof(float)));
+        m->owned.push_back(m->smax);
+        VFI_CHECK_HIP(hipMemset(m->smax, 0, 8 * sizeof(float)));
+    }
     m->H = H, m->W = W;
     return 0;
 }
@@ -294,6 +305,7 @@ int vfi_m2m_prepare(vfi_m2m_t* m, const float* frame0_dev, const float* frame1_d
     const int Hp = m->Hp, Wp = m->Wp;
     m->prepared = false;
     if (vfi_m2m_normalize(frame0_dev, frame1_dev, C, H, W, Hp, Wp, m->d0.p, 8, 2, m->stats, m->ws, 16384, st)) return -1;
+    if (vfi_m2m_image4(m->d0.p, 8, m->img4.p, Hp, Wp, st)) return -1;
     // ---- flow network on half-resolution images (:936-939, bidir :521-546)
     if (resize(m->d0, 2, m->imh, 0, 3, 1.0f, st)) return -1;
     const Ten* src = &m->imh;
@@ -344,7 +356,7 @@ int vfi_m2m_prepare(vfi_m2m_t* m, const float* frame0_dev, const float* frame1_d
         if (run(m->pyr[l][0], *src, soff, *t, 0, 3, 0.f, st) || run(m->pyr[l][1], *t, 0, m->enc[l], coff[l], 3, 0.f, st)) return -1;
         src = &m->enc[l], soff = coff[l];
     }
-    if (warp(m->d0, 2, 3, m->d0, 0, m->d0, 5, st)) return -1;
+    if (vfi_m2m_warp_image4(m->img4.p, m->d0.p, 8, m->d0.p + 5, 8, Hp, Wp, st)) return -1;
     src = &m->d0;
     const Ten* flow_src = &m->d0;
     for (int l = 0; l < 4; ++l) {
@@ -365,7 +377,7 @@ int vfi_m2m_prepare(vfi_m2m_t* m, const float* frame0_dev, const float* frame1_d
         run(m->up[2], m->enc[1], 0, m->enc[0], 32, 3, 0.f, st) || run(m->up[3], m->enc[0], 0, m->xf, 0, 3, 0.f, st))
         return -1;
     if (run(m->head, m->xf, 0, m->r, 0, 0, 0.f, st)) return -1;
-    if (vfi_m2m_photo(m->d0.p, 8, m->r.p, 12, m->alpha, m->tf.p, m->e.p, Hp, Wp, st)) return -1;
+    if (vfi_m2m_photo_tiles(m->d0.p, 8, m->r.p, 12, m->alpha, m->img4.p, m->tf.p, m->e.p, m->tile_ranges, m->smax, Hp, Wp, st)) return -1;
     m->prepared = true;
     return 0;
 }
@@ -375,6 +387,11 @@ int vfi_m2m_render(vfi_m2m_t* m, float t, float* out_dev, void* stream) {
     VFI_REQUIRE(m->prepared, "vfi_m2m_render: no prepared frame pair (call vfi_m2m_prepare first)");
     hipStream_t st = (hipStream_t)stream;
     const int Hp = m->Hp, Wp = m->Wp;
+    // one kernel: splat inputs, the 8 summation splats and forwarp_mframe_mask's combine per 32x32 tile of the frame (m2m_render.hip)
+    if (option(kOptM2mFused) && t >= 0.f && t <= 1.f)
+        return vfi_m2m_render_fused(m->img4.p, m->tf.p, m->e.p, m->tile_ranges, m->smax, m->stats, t, out_dev, Hp, Wp, m->H, m->W, st);
+    // the three-step form (A/B option m2m_fused = 0, and timesteps outside [0, 1]); its buffers are allocated at first use
+    if (!m->sin.p && (alloc_ten(m, m->sin, 8, Hp, Wp, 4, st) || alloc_ten(m, m->sfl, 8, Hp, Wp, 2, st) || alloc_ten(m, m->sout, 8, Hp, Wp, 4, st))) return -1;
     if (vfi_m2m_splat_inputs(m->d0.p, 8, m->tf.p, m->e.p, t, m->sin.p, m->sfl.p, Hp, Wp, st)) return -1;
     if (vfi_softsplat_sum(m->sin.p, m->sfl.p, m->sout.p, 8, Hp, Wp, 4, st)) return -1;
     return vfi_m2m_combine(m->sout.p, m->d0.p, 8, m->stats, t, out_dev, Hp, Wp, m->H, m->W, st);

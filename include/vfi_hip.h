@@ -197,6 +197,25 @@ int vfi_m2m_cube_apply(const float* s3_dev, int s3_cs, const float* cC_dev, cons
  * d0 [2,H,W,d0_cs] = (flow 0..1 | normalised image 2..4 | ..), r [2,H,W,r_cs] = (8 residuals | mask logit). */
 int vfi_m2m_photo(const float* d0_dev, int d0_cs, const float* r_dev, int r_cs, float alpha, float* tf_dev, float* e_dev, int H,
                   int W, void* stream);
+/* img4_dev [2,H,W,4] = (d0's channels 2..4 = the normalised image, 1): the compact plane the kernels below read with one 16-byte load
+ * per tap / source (round 6, csrc/m2m_render.hip). */
+int vfi_m2m_image4(const float* d0_dev, int d0_cs, float* img4_dev, int H, int W, void* stream);
+/* = vfi_warp_m2m(image, in_swap = 1, C = 3) with the partner image taken from img4 (bit-identical): out[n,y,x,0..2] =
+ * backwarp(img4[n ^ 1], flow[n]) (M2M_arch.py:24-92, :866-890). */
+int vfi_m2m_warp_image4(const float* img4_dev, const float* flow_dev, int flow_cs, float* out_dev, int out_cs, int H, int W, void* stream);
+/* vfi_m2m_photo's results computed per 32x32 tile, plus what the one-kernel render below needs: img4_dev from vfi_m2m_image4
+ * (input); tile_ranges_dev [8][ceil(H/32)*ceil(W/32)][4] =
+ * (fx_min, fx_max, fy_min, fy_max) of every refined flow field tf_s over the tile's finite values (min > max: none);
+ * smax_dev [8] = max |tf_s|.  tf_dev / e_dev as vfi_m2m_photo (bit-identical). */
+int vfi_m2m_photo_tiles(const float* d0_dev, int d0_cs, const float* r_dev, int r_cs, float alpha, const float* img4_dev, float* tf_dev,
+                        float* e_dev, float* tile_ranges_dev, float* smax_dev, int H, int W, void* stream);
+/* forwarp_mframe_mask for one timestep 0 <= t <= 1 as ONE kernel (M2M_arch.py:551-581, :1012-1037 with softsplat_out of
+ * cupy_ops/softsplat.py:140-192 inside): = vfi_m2m_splat_inputs + vfi_softsplat_sum (8 splats) + vfi_m2m_combine, bit-identical to
+ * that sequence wherever a tile's source window fits one LDS stage (1824 sources), same sums in another strip order beyond; no limit
+ * on the displacement, no fallback launches.  Inputs from vfi_m2m_photo_tiles (Hp x Wp = the padded size), stats from
+ * vfi_m2m_normalize; out_dev [H,W,3]. */
+int vfi_m2m_render_fused(const float* img4_dev, const float* tf_dev, const float* e_dev, const float* tile_ranges_dev, const float* smax_dev,
+                         const float* stats_dev, float t, float* out_dev, int Hp, int Wp, int H, int W, void* stream);
 /* Per timestep t: in_dev [8,H,W,4] = (image*td*e, td*e), flow_dev [8,H,W,2] = tf * tm (:1012-1024, :563-567) */
 int vfi_m2m_splat_inputs(const float* d0_dev, int d0_cs, const float* tf_dev, const float* e_dev, float t, float* in_dev,
                          float* flow_dev, int H, int W, void* stream);

@@ -293,7 +293,7 @@ def test_clock_probe_records(lib):
     finally:
         _check(lib, lib.vfi_clock_probe(None, 0), "vfi_clock_probe off")
     names = _lib.clock_probe_names()
-    assert len(names) == 5 and len(set(names)) == 1, names
+    assert len(names) == 3 and len(set(names)) == 1, names      # r6: a full buffer stops the names too
     r = rec.cpu().numpy().astype("uint64")
     for i, (t0, r0, t1, r1, tag, *rest) in enumerate(r.tolist()):
         assert t1 > t0 and r1 > r0 and tag == i and rest == [0, 0, 0], (i, t0, r0, t1, r1, tag, rest)

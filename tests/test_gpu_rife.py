@@ -652,6 +652,7 @@ load_package()
 from cfi_amd import _lib, synth
 from cfi_amd.rife import RifeEngine, run_tasks
 torch.cuda.set_device(0)
+_lib.use_test_build()      # the A/B switch lives in libvfi_hip_test.so only
 assert _lib.load().vfi_test_set_option(b"stage_quad", {mask}) == 0
 outs = []
 for arch, mk in (("4.7", synth.rife47_synth_state_dict), ("4.17", synth.rife417_synth_state_dict)):
