@@ -381,9 +381,13 @@ int conv_pick_variant(const ConvArgs& a, int stride, bool grouped) {
     (void)cus;
     if (stride == 2) {
         if (n2) return kConv2Base + 7;   // d2_m1n2
-        if (n3) return 9;                // s2_m1n3
+        if (n3) return kConv2Base + 9;   // d2_m1n3 (r6: 0.924 -> 0.832 ms on RIFE's conv0b_b2 against the first-generation s2_m1n3, same bits)
         return 10;                       // s2_m1n1
     }
+    // coarse pyramid levels of the layer objects (M2M's PWC decoders at 17x30 / 34x60: 24 .. 80 workgroups of the 64-channel tile on 256
+    // CUs, each walking the whole K loop alone — 46 us for 120 -> 128 @17x30): the 32-channel N tile doubles the workgroups and halves
+    // each one's serial MFMA chain; same K chunk (8), i.e. the same summation order and bits as d1_m1n2
+    if (a.split_ok && (n2 || n3) && px <= 6000) return kConv2Base + 25;   // d1_m1n1
     if (n2) {   // d1_m2n2 (16x16 px tile) / d1_m1n2 (16x8): the larger M tile re-uses each weight fragment twice as often
         // A/B option m2n2_px: pixel count from which wide layers take m2n2.  Measured on FILM / M2M at 1080p
         // (profiles/r02_film_tile_experiment.txt): 100k is the best of {never, 1.5M, 400k, 100k, 20k} by 0.6 % only — not

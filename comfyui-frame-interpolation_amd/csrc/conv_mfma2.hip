@@ -581,6 +581,7 @@ static const ConvVariant kVariants2[] = {
     {"d1_m4n2", 1, 9, 4, 2, 4, 1, 8, 0},      // 54: 32x16 px x 64 ch (8 accumulators per wave)
     {"d1t1_m1n2k32", 1, 1, 1, 2, 4, 1, 32, 0},      // 55: 1x1 with 32-channel K chunks (4 K-steps per barrier instead of 1), 16x8 px x 64 ch
     {"d1t1_m2n2w22k32", 1, 1, 2, 2, 2, 2, 32, 0},   // 56: ... 16x8 px x 128 ch (wide inputs)
+    {"d1_m1n1", 1, 9, 1, 1, 4, 1, 8, 0},            // 57: 3x3, 16x8 px x 32 ch — coarse pyramid levels (r6): twice the workgroups, half the serial K loop
 };
 int conv2_num_variants() { return (int)(sizeof(kVariants2) / sizeof(kVariants2[0])); }
 const ConvVariant& conv2_variant(int i) { return kVariants2[i]; }
@@ -612,6 +613,7 @@ int conv2_launch(const ConvArgs& a, int idx, hipStream_t s, const char* nm) {
         case 22: return launch2_t<1, 9, 4, 2, 4, 1, 8, false>(a, s, nm);
         case 23: return launch2_t<1, 1, 1, 2, 4, 1, 32, false>(a, s, nm);
         case 24: return launch2_t<1, 1, 2, 2, 2, 2, 32, false>(a, s, nm);
+        case 25: return launch2_t<1, 9, 1, 1, 4, 1, 8, false>(a, s, nm);
     }
     set_error("conv2: bad variant %d", idx);
     return -3;

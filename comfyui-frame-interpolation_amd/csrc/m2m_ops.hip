@@ -523,7 +523,13 @@ static int splat_ws(size_t n_blocks, size_t list_pixels, SplatWs** out) {
 
 int softsplat_sum_launch(const float* in, const float* flow, float* out, int N, int H, int W, int C, hipStream_t s) {
     // A/B options (tests of the fallback paths): splat_atomic = 1 forces the LDS-atomic tile kernel, splat_spill_cap shrinks the spill list
-    const int g_splat_mode = option(kOptSplatAtomic) ? 1 : 0;
+    // splat_atomic: 0 = default (the list kernel below), 1 = the LDS-atomic tile kernel, 3 = (C == 4) the staged list gather with source
+    // compaction of m2m_render.hip — the M2M render kernel's machinery as a single splat: correct (tests/test_gpu_m2m_render.py) but a
+    // tile's serial chain of load round trips makes it SLOWER than the list kernel as a stand-alone splat (profiles/r06_splat_bench.txt),
+    // so it stays an A/B form
+    const long mode_opt = option(kOptSplatAtomic);
+    if (mode_opt == 3 && C == 4 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0 && ((uintptr_t)flow & 7) == 0) return softsplat4_launch(in, flow, out, N, H, W, s);
+    const int g_splat_mode = mode_opt == 1 ? 1 : 0;
     const long cap_opt = option(kOptSplatSpillCap);
     const unsigned g_splat_cap = (cap_opt >= 0 && cap_opt < (long)SPLAT_OVF_CAP) ? (unsigned)cap_opt : SPLAT_OVF_CAP;
     const int tiles_x = cdiv(W, SPLAT_T), tiles_y = cdiv(H, SPLAT_T);

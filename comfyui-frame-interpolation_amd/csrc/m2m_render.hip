@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256) void m2m_photo_tiles_kernel(const float* __res
 #pragma unroll
     for (int b = 0; b < 4; ++b) lo_x[b] = big, hi_x[b] = -big, lo_y[b] = big, hi_y[b] = -big, amax[b] = 0.f;
     const float4* other = img4 + (size_t)(d ^ 1) * hw;
+    const bool vec_r = (r_cs & 3) == 0 && ((uintptr_t)r & 15) == 0;
 #pragma unroll 1
     for (int q = 0; q < 4; ++q) {
         const int y = ty * RT + (tid >> 5) + 8 * q;
@@ -79,10 +80,21 @@ __global__ __launch_bounds__(256) void m2m_photo_tiles_kernel(const float* __res
         const long p = (long)y * W + x;
         const long idx = d * hw + p;
         const float* me = d0 + (size_t)idx * d0_cs;
-        const float* rr = r + (size_t)idx * r_cs;
+        const float* rp = r + (size_t)idx * r_cs;
+        // the 9 values of r as wide loads where the layout allows (the object's r: 12 floats per pixel, 16-byte aligned): 3 loads instead
+        // of 9 scalar ones at a 48-byte lane stride
+        float rr[9];
+        if (vec_r) {
+            const float4 q0 = *(const float4*)rp, q1 = *(const float4*)(rp + 4);
+            rr[0] = q0.x, rr[1] = q0.y, rr[2] = q0.z, rr[3] = q0.w, rr[4] = q1.x, rr[5] = q1.y, rr[6] = q1.z, rr[7] = q1.w, rr[8] = rp[8];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 9; ++j) rr[j] = rp[j];
+        }
         const float wei = __fadd_rn(__fmul_rn(1.0f / (1.0f + expf(-rr[8])), 0.8f), 0.1f);
         const float4 im = img4[(size_t)idx];
-        const float f0 = me[0], f1 = me[1];
+        const float2 f01 = *(const float2*)me;      // d0_cs is even and d0 8-byte aligned (checked by the launcher)
+        const float f0 = f01.x, f1 = f01.y;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const float fx = __fadd_rn(f0, rr[2 * b]), fy = __fadd_rn(f1, rr[2 * b + 1]);
@@ -134,7 +146,8 @@ __global__ __launch_bounds__(256) void m2m_photo_tiles_kernel(const float* __res
         }
         const int s = 2 * b + d;
         brange[(size_t)s * tiles + trem] = make_float4(v[0], v[1], v[2], v[3]);
-        if (v[4] > 0.f) atomicMax(&smax_bits[s], __float_as_uint(v[4]));      // non-negative floats order as their bit patterns
+        // non-negative floats order as their bit patterns; a plain look first keeps the workgroups from queueing on one address
+        if (v[4] > 0.f && __float_as_uint(v[4]) > __builtin_nontemporal_load(&smax_bits[s])) atomicMax(&smax_bits[s], __float_as_uint(v[4]));
     }
 }
 
@@ -211,6 +224,94 @@ __device__ static inline void racc(v2f& a01, v2f& a23, const float4& in, float w
     const v2f p01 = i01 * w2, p23 = i23 * w2;
     a01 = a01 + p01;
     a23 = a23 + p23;
+}
+
+// phases 2 and 3 of one strip: order the crowded cells, then every thread gathers its 2x2 pixel block from the 3x3 cells around it.
+// n = sources staged; cells / scell / flags as phase 1 left them (after a barrier).  Ends WITHOUT a barrier.
+__device__ __forceinline__ void render_gather(unsigned char* lds_raw, uint4* cells, const unsigned short* scell, const int* flags, int n,
+                                              int cbase, v2f (&cur01)[4], v2f (&cur23)[4]) {
+    const int tid = threadIdx.x;
+    const RSrc* const stage = (const RSrc*)lds_raw;
+    // ---- phase 2: cells with 3..6 sources: ascending source position (two are ordered when read; more than 6 are scanned)
+    if (flags[0] | flags[1]) {
+        for (int c = tid; c < RCELLS; c += 256) {
+            const unsigned cnt = cells[c].x;
+            if (cnt < 3u) continue;
+            unsigned short* l = (unsigned short*)&cells[c] + 2;
+            const int k = (int)min(cnt, (unsigned)RK);
+            for (int i = 1; i < k; ++i) {
+                const unsigned short v = l[i];
+                int j = i - 1;
+                while (j >= 0 && l[j] > v) {
+                    l[j + 1] = l[j];
+                    --j;
+                }
+                l[j + 1] = v;
+            }
+        }
+        __syncthreads();
+    }
+    const bool overflowed = flags[1] != 0;
+    unsigned ovmask = 0;      // bit cj * 3 + ci: that cell of this thread's 3x3 holds more sources than a cell's list
+    // ---- phase 3: gather the 2x2 block from its 3x3 cells, in raster order of the cells (= SE, SW, NE, NW per pixel)
+#pragma unroll
+    for (int cj = 0; cj < 3; ++cj) {
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) {
+            const int cidx = cbase + cj * RCW + ci;
+            const uint4 c = cells[cidx];
+            const unsigned cnt = c.x;
+            if (__builtin_expect(overflowed, 0) && cnt > (unsigned)RK) {
+                ovmask |= 1u << (cj * 3 + ci);
+                continue;
+            }
+            unsigned e[RK] = {c.y & 0xffffu, c.y >> 16, c.z & 0xffffu, c.z >> 16, c.w & 0xffffu, c.w >> 16};
+            if (cnt == 2u) {
+                const unsigned lo = min(e[0], e[1]), hi = max(e[0], e[1]);
+                e[0] = lo, e[1] = hi;
+            }
+#pragma unroll
+            for (int q = 0; q < RK; ++q) {
+                const bool live = (unsigned)q < cnt;
+                if (!__any(live)) break;
+                if (live) {
+                    const RSrc v = *(const RSrc*)(lds_raw + e[q]);
+#pragma unroll
+                    for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                        for (int pa = 0; pa < 2; ++pa)
+                            if (ci - pa >= 0 && ci - pa <= 1 && cj - pb >= 0 && cj - pb <= 1) {
+                                const int k = (pa + 1 - ci) + 2 * (pb + 1 - cj);
+                                racc(cur01[2 * pb + pa], cur23[2 * pb + pa], v.in, k == 0 ? v.w.x : (k == 1 ? v.w.y : (k == 2 ? v.w.z : v.w.w)));
+                            }
+                }
+            }
+        }
+    }
+    // ---- cells with more sources than a list holds (strongly convergent flow): ONE pass over the strip's sources, in source order,
+    // takes every source filed under one of this thread's overflowed cells (their sums follow the listed cells': a fixed order still)
+    if (__builtin_expect(overflowed, 0) && __any(ovmask != 0u)) {
+        if (ovmask != 0u) {
+            for (int j = 0; j < n; ++j) {
+                const int d = (int)scell[j] - cbase;
+                if ((unsigned)d > (unsigned)(2 * RCW + 2)) continue;
+                const int cj = d >= 2 * RCW ? 2 : (d >= RCW ? 1 : 0);
+                const int ci = d - cj * RCW;
+                if (ci > 2 || !((ovmask >> (cj * 3 + ci)) & 1u)) continue;
+                const RSrc v = stage[j];
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                    for (int pa = 0; pa < 2; ++pa) {
+                        const int ax = pa + 1 - ci, ay = pb + 1 - cj;      // corner of the source this pixel is: 0 / 1 each, else not covered
+                        if ((unsigned)ax <= 1u && (unsigned)ay <= 1u) {
+                            const float wx0 = ay ? v.w.z : v.w.x, wx1 = ay ? v.w.w : v.w.y;
+                            racc(cur01[2 * pb + pa], cur23[2 * pb + pa], v.in, ax ? wx1 : wx0);
+                        }
+                    }
+            }
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void m2m_render_kernel(const RenderArgs a) {
@@ -315,73 +416,7 @@ __global__ __launch_bounds__(256) void m2m_render_kernel(const RenderArgs a) {
                 }
             }
             __syncthreads();
-            // ---- phase 2: cells with 3..6 sources: ascending source position (two are ordered when read; more than 6 are scanned)
-            if (flags[0] | flags[1]) {
-                for (int c = tid; c < RCELLS; c += 256) {
-                    const unsigned cnt = cells[c].x;
-                    if (cnt < 3u) continue;
-                    unsigned short* l = (unsigned short*)&cells[c] + 2;
-                    const int k = (int)min(cnt, (unsigned)RK);
-                    for (int i = 1; i < k; ++i) {
-                        const unsigned short v = l[i];
-                        int j = i - 1;
-                        while (j >= 0 && l[j] > v) {
-                            l[j + 1] = l[j];
-                            --j;
-                        }
-                        l[j + 1] = v;
-                    }
-                }
-                __syncthreads();
-            }
-            const bool overflowed = flags[1] != 0;
-            // ---- phase 3: gather the 2x2 block from its 3x3 cells, in raster order of the cells (= SE, SW, NE, NW per pixel)
-#pragma unroll
-            for (int cj = 0; cj < 3; ++cj) {
-#pragma unroll
-                for (int ci = 0; ci < 3; ++ci) {
-                    const int cidx = cbase + cj * RCW + ci;
-                    const uint4 c = cells[cidx];
-                    const unsigned cnt = c.x;
-                    if (__builtin_expect(overflowed, 0) && cnt > (unsigned)RK) {
-                        // more sources than the cell holds: all of them, in source order, by scanning the strip
-                        for (int j = 0; j < n; ++j) {
-                            if (scell[j] != (unsigned short)cidx) continue;
-                            const RSrc v = stage[j];
-#pragma unroll
-                            for (int pb = 0; pb < 2; ++pb)
-#pragma unroll
-                                for (int pa = 0; pa < 2; ++pa)
-                                    if (ci - pa >= 0 && ci - pa <= 1 && cj - pb >= 0 && cj - pb <= 1) {
-                                        const int k = (pa + 1 - ci) + 2 * (pb + 1 - cj);
-                                        racc(cur01[2 * pb + pa], cur23[2 * pb + pa], v.in, k == 0 ? v.w.x : (k == 1 ? v.w.y : (k == 2 ? v.w.z : v.w.w)));
-                                    }
-                        }
-                        continue;
-                    }
-                    unsigned e[RK] = {c.y & 0xffffu, c.y >> 16, c.z & 0xffffu, c.z >> 16, c.w & 0xffffu, c.w >> 16};
-                    if (cnt == 2u) {
-                        const unsigned lo = min(e[0], e[1]), hi = max(e[0], e[1]);
-                        e[0] = lo, e[1] = hi;
-                    }
-#pragma unroll
-                    for (int q = 0; q < RK; ++q) {
-                        const bool live = (unsigned)q < cnt;
-                        if (!__any(live)) break;
-                        if (live) {
-                            const RSrc v = *(const RSrc*)(lds_raw + e[q]);
-#pragma unroll
-                            for (int pb = 0; pb < 2; ++pb)
-#pragma unroll
-                                for (int pa = 0; pa < 2; ++pa)
-                                    if (ci - pa >= 0 && ci - pa <= 1 && cj - pb >= 0 && cj - pb <= 1) {
-                                        const int k = (pa + 1 - ci) + 2 * (pb + 1 - cj);
-                                        racc(cur01[2 * pb + pa], cur23[2 * pb + pa], v.in, k == 0 ? v.w.x : (k == 1 ? v.w.y : (k == 2 ? v.w.z : v.w.w)));
-                                    }
-                        }
-                    }
-                }
-            }
+            render_gather(lds_raw, cells, scell, flags, n, cbase, cur01, cur23);
         }
         // ---- forwarp_mframe_mask's accumulation (M2M_arch.py:569-581): per branch (fwd + bwd), norm += (fwd.w + 1e-7) + (bwd.w + 1e-7)
         if (!d) {
@@ -422,6 +457,217 @@ __global__ __launch_bounds__(256) void m2m_render_kernel(const RenderArgs a) {
         }
 }
 
+// ---- the generic 4-channel summation splat on the same machinery --------------------------------------------------------------------
+// vfi_softsplat_sum for C == 4 (softsplat_out, cupy_ops/softsplat.py:140-192): one splat, input and flow as given.  Differences from
+// the M2M kernel above, both for INCOHERENT fields (i.i.d. N(0, 8 px) — a tile's window holds 7x as many sources
+// as land in it):
+//   * sources are CLASSIFIED first (flow load, target cell, 18 instructions) in chunks of 1024, and only those that reach the tile are
+//     compacted — by ballot / popcount ranks in raster order, so the stage order stays the source order — into an index list;
+//   * the expensive part (input load, weights, staging, filing) then runs densely over that list, and a strip is flushed (gathered)
+//     only when the list is full: an 86 x 86 window of which 1100 sources land is ONE gather, not five.
+constexpr int GCAP = 1664;             // staged sources per flush (2 workgroups of 79.9 KB per CU)
+constexpr int GU = 6;                  // sources classified per thread and step: 6 flow loads in flight (a whole chunk must fit the stage)
+constexpr int GCHUNK = 256 * GU;       // sources classified per step
+static_assert(GCHUNK <= GCAP, "a chunk whose sources all reach the tile must fit the stage");
+
+struct Splat4Args {
+    const float4* in;        // [N][H*W]
+    const float2* flow;      // [N][H*W]
+    float4* out;             // [N][H*W]
+    const float4* brange;    // [N][tiles]
+    const unsigned* smax;    // [N] float bits
+    int H, W, tiles_x, tiles_y;
+};
+
+// per 32x32 tile: range of the finite flows, and max |f| per image (zeroed before the launch)
+__global__ __launch_bounds__(256) void flow_tile_ranges_kernel(const float2* __restrict__ flow, int H, int W, int tiles_x, int tiles_y,
+                                                               float4* __restrict__ brange, unsigned* __restrict__ smax_bits) {
+    const int tid = threadIdx.x;
+    const int tiles = tiles_x * tiles_y;
+    const int n = blockIdx.x / tiles;
+    const int trem = blockIdx.x - n * tiles;
+    const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+    const int x = tx * RT + (tid & 31);
+    const float big = 3.0e38f;
+    float x0 = big, x1 = -big, y0 = big, y1 = -big, am = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int y = ty * RT + (tid >> 5) + 8 * q;
+        if (x < W && y < H) {
+            const float2 f = flow[((size_t)n * H + y) * W + x];
+            if (isfinite(f.x) && isfinite(f.y)) {
+                x0 = fminf(x0, f.x), x1 = fmaxf(x1, f.x), y0 = fminf(y0, f.y), y1 = fmaxf(y1, f.y);
+                am = fmaxf(am, fmaxf(fabsf(f.x), fabsf(f.y)));
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        x0 = fminf(x0, __shfl_xor(x0, o)), x1 = fmaxf(x1, __shfl_xor(x1, o));
+        y0 = fminf(y0, __shfl_xor(y0, o)), y1 = fmaxf(y1, __shfl_xor(y1, o));
+        am = fmaxf(am, __shfl_xor(am, o));
+    }
+    __shared__ float wr[4][5];
+    if ((tid & 63) == 0) {
+        float* r = wr[tid >> 6];
+        r[0] = x0, r[1] = x1, r[2] = y0, r[3] = y1, r[4] = am;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        brange[blockIdx.x] = make_float4(fminf(fminf(wr[0][0], wr[1][0]), fminf(wr[2][0], wr[3][0])), fmaxf(fmaxf(wr[0][1], wr[1][1]), fmaxf(wr[2][1], wr[3][1])),
+                                         fminf(fminf(wr[0][2], wr[1][2]), fminf(wr[2][2], wr[3][2])), fmaxf(fmaxf(wr[0][3], wr[1][3]), fmaxf(wr[2][3], wr[3][3])));
+        const float a = fmaxf(fmaxf(wr[0][4], wr[1][4]), fmaxf(wr[2][4], wr[3][4]));
+        // (a plain look first: 2040 workgroups queueing on one address cost 20 us; after the first few, hardly any still raises the maximum)
+        if (a > 0.f && __float_as_uint(a) > __builtin_nontemporal_load(&smax_bits[n])) atomicMax(&smax_bits[n], __float_as_uint(a));
+    }
+}
+
+__global__ __launch_bounds__(256) void softsplat4_kernel(const Splat4Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    RSrc* const stage = (RSrc*)lds_raw;                                          // GCAP x 32 B
+    uint4* const cells = (uint4*)(lds_raw + sizeof(RSrc) * GCAP);                // RCELLS x 16 B
+    unsigned short* const scell = (unsigned short*)(cells + RCELLS);             // GCAP
+    unsigned* const sidx = (unsigned*)(scell + GCAP);                            // GCAP window indices of the sources that reach the tile
+    int* const red = (int*)(sidx + GCAP);                                        // 16 ints (window)
+    int* const flags = red + 16;                                                 // 2
+    int* const wcnt = flags + 2;                                                 // [2][GU][4 waves] classification counts, double-buffered
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int n = blockIdx.x / tiles;
+    const int trem = blockIdx.x - n * tiles;
+    const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
+    const int X0 = tx * RT, Y0 = ty * RT;
+    const long hw = (long)a.H * a.W;
+    const float4* const Is = a.in + (size_t)n * hw;
+    const float2* const Fs = a.flow + (size_t)n * hw;
+    const int pbx = tid & 15, pby = tid >> 4;
+    const int cbase = (2 * pby) * RCW + 2 * pbx;
+    v2f cur01[4], cur23[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cur01[i] = v2f{0.f, 0.f}, cur23[i] = v2f{0.f, 0.f};
+    const RWin win = render_window(a.brange + (size_t)n * tiles, __uint_as_float(a.smax[n]), 1.0f, ty, tx, a.tiles_x, a.tiles_y, a.H, a.W, red);
+    const int ww = win.x1 - win.x0, wh = win.y1 - win.y0;
+    const long total = (long)ww * wh;
+    const float inv_ww = ww > 0 ? 1.0f / (float)ww : 0.f;
+    const bool small = total < (1L << 22);      // window indices exact in fp32: the quotient by reciprocal + one fix-up
+    for (int i = tid; i < RCELLS; i += 256) cells[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < 2) flags[tid] = 0;
+    int staged = 0;
+
+    // stage + file the listed sources, gather them, clear the cells; all threads
+    auto flush = [&](int ns) {
+        __syncthreads();      // the index list (and the cleared cells) are visible
+        for (int k0 = tid; k0 < ns; k0 += 1024) {
+            float2 fv[4];
+            float4 iv[4];
+            int sxs[4], sys[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {      // 8 loads in flight per thread
+                const int k = k0 + 256 * u;
+                const unsigned i = sidx[k < ns ? k : tid];
+                int dy;
+                if (small) {
+                    dy = (int)((float)i * inv_ww);
+                    const int r = (int)i - dy * ww;
+                    dy += r >= ww ? 1 : (r < 0 ? -1 : 0);
+                } else {
+                    dy = (int)(i / (unsigned)ww);
+                }
+                const int dx = (int)i - dy * ww;
+                sxs[u] = win.x0 + dx, sys[u] = win.y0 + dy;
+                const int p = sys[u] * a.W + sxs[u];
+                fv[u] = Fs[p];
+                iv[u] = Is[p];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + 256 * u;
+                if (k >= ns) break;
+                const float2 f = fv[u];
+                const float fx = __fadd_rn((float)sxs[u], f.x), fy = __fadd_rn((float)sys[u], f.y);
+                const float x0f = floorf(fx), y0f = floorf(fy);
+                const float x1f = __fadd_rn(x0f, 1.0f), y1f = __fadd_rn(y0f, 1.0f);
+                const float bx = __fsub_rn(x1f, fx), ax = __fsub_rn(fx, x0f), by = __fsub_rn(y1f, fy), ay = __fsub_rn(fy, y0f);
+                RSrc v;
+                v.w = make_float4(__fmul_rn(bx, by), __fmul_rn(ax, by), __fmul_rn(bx, ay), __fmul_rn(ax, ay));
+                v.in = iv[u];
+                stage[k] = v;
+                const int cell = (int)(y0f - (float)(Y0 - 1)) * RCW + (int)(x0f - (float)(X0 - 1));      // in range: the classification kept only those
+                const unsigned slot = atomicAdd(&cells[cell].x, 1u);
+                if (slot < (unsigned)RK) ((unsigned short*)&cells[cell])[2 + slot] = (unsigned short)(k * (int)sizeof(RSrc));
+                if (slot >= 2u) flags[slot >= (unsigned)RK ? 1 : 0] = 1;
+                scell[k] = (unsigned short)cell;
+            }
+        }
+        __syncthreads();
+        render_gather(lds_raw, cells, scell, flags, ns, cbase, cur01, cur23);
+        __syncthreads();
+        for (int i = tid; i < RCELLS; i += 256) cells[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (tid < 2) flags[tid] = 0;
+    };
+
+    int par = 0;
+#pragma unroll 1
+    for (long c0 = 0; c0 < total; c0 += GCHUNK, par ^= 1) {
+        // ---- classify 4 sources per thread: does the source's north-west target fall on this tile's cells?
+        const long first = c0 + tid;
+        int dy = (int)(first / ww), dx = (int)(first - (long)dy * ww);
+        const int q256 = 256 / ww, r256 = 256 - q256 * ww;
+        bool ok[GU];
+        unsigned rank[GU];
+        float2 fv[GU];
+        int sxs[GU], sys[GU];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const bool in = first + 256 * u < total;
+            sxs[u] = win.x0 + dx, sys[u] = win.y0 + dy;
+            fv[u] = Fs[in ? sys[u] * a.W + sxs[u] : win.y0 * a.W + win.x0];
+            dx += r256, dy += q256;
+            if (dx >= ww) dx -= ww, dy += 1;
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const bool in = first + 256 * u < total;
+            const float fx = __fadd_rn((float)sxs[u], fv[u].x), fy = __fadd_rn((float)sys[u], fv[u].y);
+            const float lxf = floorf(fx) - (float)(X0 - 1), lyf = floorf(fy) - (float)(Y0 - 1);
+            // softsplat.py:157-158: non-finite targets never splat (fx - fx is 0 only for a finite fx)
+            ok[u] = in && (fx - fx == 0.f) && (fy - fy == 0.f) && lxf >= 0.f && lxf <= (float)RT && lyf >= 0.f && lyf <= (float)RT;
+            const unsigned long long b = __ballot(ok[u]);
+            rank[u] = (unsigned)__popcll(b & ((1ull << lane) - 1ull));
+            if (lane == 0) wcnt[par * 4 * GU + u * 4 + wave] = (int)__popcll(b);
+        }
+        __syncthreads();
+        int base[GU], sum = 0;      // raster order of a chunk: u major, then wave, then lane
+#pragma unroll
+        for (int u = 0; u < GU; ++u)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                if (w == wave) base[u] = sum;
+                sum += wcnt[par * 4 * GU + u * 4 + w];
+            }
+        if (staged + sum > GCAP) {      // uniform: the list would overflow — gather what is staged first (a chunk alone always fits)
+            flush(staged);
+            staged = 0;
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u)
+            if (ok[u]) sidx[staged + base[u] + (int)rank[u]] = (unsigned)(first + 256 * u);
+        staged += sum;
+    }
+    if (staged > 0) flush(staged);
+    // ---- the tile's 2x2 blocks out
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+        for (int pa = 0; pa < 2; ++pa) {
+            const int x = X0 + 2 * pbx + pa, y = Y0 + 2 * pby + pb;
+            if (x >= a.W || y >= a.H) continue;
+            const int i = 2 * pb + pa;
+            a.out[(size_t)n * hw + (size_t)y * a.W + x] = make_float4(cur01[i].x, cur01[i].y, cur23[i].x, cur23[i].y);
+        }
+}
+
+constexpr size_t kSplat4Lds = sizeof(RSrc) * GCAP + sizeof(uint4) * RCELLS + sizeof(unsigned short) * GCAP + sizeof(unsigned) * GCAP + sizeof(int) * (16 + 2 + 2 * 4 * GU + 14);
+
 constexpr size_t kRenderLds = sizeof(RSrc) * RCAP + sizeof(uint4) * RCELLS + sizeof(unsigned short) * RCAP + sizeof(int) * 32;
 
 // compact image plane [2][Hp*Wp][4] = (normalised r, g, b, 1) from d0's channels 2..4
@@ -458,6 +704,56 @@ __global__ void m2m_warp_img4_kernel(const float4* __restrict__ img4, const floa
     o[0] = r0, o[1] = r1, o[2] = r2;
 }
 
+// per-device workspace of the generic splat (tile ranges, max |f| per image); grows, never shrinks
+struct Splat4Ws {
+    float4* ranges = nullptr;
+    size_t n_ranges = 0;
+    unsigned* smax = nullptr;
+    size_t n_smax = 0;
+};
+static Splat4Ws g_splat4_ws[kMaxDevices];
+
+int softsplat4_launch(const float* in, const float* flow, float* out, int N, int H, int W, hipStream_t s) {
+    VFI_REQUIRE((long)H * W < (1L << 30), "softsplat: %d x %d pixels do not fit the 32-bit indices", H, W);
+    int dev = 0;
+    VFI_CHECK_HIP(hipGetDevice(&dev));
+    VFI_REQUIRE(dev >= 0 && dev < kMaxDevices, "softsplat: device index %d out of range", dev);
+    Splat4Ws& w = g_splat4_ws[dev];
+    const int tiles_x = cdiv(W, RT), tiles_y = cdiv(H, RT);
+    const size_t nt = (size_t)N * tiles_x * tiles_y;
+    if (w.n_ranges < nt) {
+        if (w.ranges) VFI_CHECK_HIP(hipFree(w.ranges));      // (synchronises; only on growth)
+        w.ranges = nullptr, w.n_ranges = 0;
+        VFI_CHECK_HIP(hipMalloc((void**)&w.ranges, sizeof(float4) * nt));
+        w.n_ranges = nt;
+    }
+    if (w.n_smax < (size_t)N) {
+        if (w.smax) VFI_CHECK_HIP(hipFree(w.smax));
+        w.smax = nullptr, w.n_smax = 0;
+        VFI_CHECK_HIP(hipMalloc((void**)&w.smax, sizeof(unsigned) * (size_t)(N < 64 ? 64 : N)));
+        w.n_smax = N < 64 ? 64 : N;
+    }
+    static std::atomic<int> attr_set[kMaxDevices];
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
+        VFI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&softsplat4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplat4Lds));
+        attr_set[dev].store(1, std::memory_order_release);
+    }
+    VFI_CHECK_HIP(hipMemsetAsync(w.smax, 0, sizeof(unsigned) * (size_t)N, s));
+    {
+        TraceScope ts("splat_blockrange", s);
+        hipLaunchKernelGGL(flow_tile_ranges_kernel, dim3((unsigned)nt), dim3(256), 0, s, (const float2*)flow, H, W, tiles_x, tiles_y, w.ranges, w.smax);
+    }
+    Splat4Args a;
+    a.in = (const float4*)in, a.flow = (const float2*)flow, a.out = (float4*)out, a.brange = w.ranges, a.smax = w.smax;
+    a.H = H, a.W = W, a.tiles_x = tiles_x, a.tiles_y = tiles_y;
+    {
+        TraceScope ts("softsplat_sum", s);
+        hipLaunchKernelGGL(softsplat4_kernel, dim3((unsigned)nt), dim3(256), kSplat4Lds, s, a);
+    }
+    VFI_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // namespace vfi
 
 using namespace vfi;
@@ -490,7 +786,8 @@ int vfi_m2m_photo_tiles(const float* d0_dev, int d0_cs, const float* r_dev, int 
                         float* e_dev, float* tile_ranges_dev, float* smax_dev, int H, int W, void* stream) {
     VFI_REQUIRE(d0_dev && r_dev && img4_dev && tf_dev && e_dev && tile_ranges_dev && smax_dev && d0_cs >= 5 && r_cs >= 9 && H > 1 && W > 1,
                 "vfi_m2m_photo_tiles: bad arguments");
-    VFI_REQUIRE((((uintptr_t)img4_dev | (uintptr_t)tile_ranges_dev) & 15) == 0 && ((uintptr_t)tf_dev & 7) == 0, "vfi_m2m_photo_tiles: unaligned buffers");
+    VFI_REQUIRE((((uintptr_t)img4_dev | (uintptr_t)tile_ranges_dev) & 15) == 0 && (((uintptr_t)tf_dev | (uintptr_t)d0_dev) & 7) == 0 && (d0_cs & 1) == 0,
+                "vfi_m2m_photo_tiles: unaligned buffers (img4 / tile ranges 16 bytes, tf / d0 8 bytes, d0_cs even)");
     float stepx, stepy, sclx, scly;
     m2m_warp_consts(H, W, stepx, stepy, sclx, scly);
     hipStream_t s = (hipStream_t)stream;

@@ -64,7 +64,7 @@ enum Option {
     kOptM2n2Px,          // pixel count from which wide direct-conv layers take the m2n2 tile (default -1 = never)
     kOptGroupedVariant,  // forced tile variant of the grouped (transposed) convolution (default -1 = heuristic)
     kOptSplitK,          // 1: split-K allowed for layer objects (default), 0: never
-    kOptSplatAtomic,     // 1: force the LDS-atomic splat kernel (default 0: list-gather kernel with the atomic kernel as overflow fallback)
+    kOptSplatAtomic,     // 1: force the LDS-atomic splat kernel, 3: staged list gather with compaction for C == 4 (default 0: list-gather kernel with the atomic kernel as overflow fallback)
     kOptSplatSpillCap,   // spill-list capacity of the list-gather splat (default -1 = built-in)
     kOptWinoXcd,         // 1: XCD-aware work order of the Winograd kernel (default), 0: plain order
     kOptDeconvWino,      // 1: ConvTranspose2d(4, 2, 1) + PixelShuffle (RIFE lastconv) as a 96-channel 3x3 layer on the Winograd kernel (default), 0: grouped direct kernel
@@ -82,6 +82,9 @@ int variant_override(const char* trace_name);      // tile variant forced for a 
 // collective kernel running beside them (a resident RCCL kernel takes whole CUs from one-workgroup-per-CU kernels, whose displaced
 // workgroups then run as a second round: +37 % while it is resident, profiles/r04_reserved_cus.txt).  A multiple of 8 (XCDs), >= 8.
 int launch_cus(int device_cus);
+
+// the 4-channel summation splat on the staged list-gather machinery of m2m_render.hip (round 6): in / out [N,H,W,4], flow [N,H,W,2]
+int softsplat4_launch(const float* in, const float* flow, float* out, int N, int H, int W, hipStream_t s);
 
 constexpr int kMaxDevices = 16;   // devices one process may drive (per-device caches are indexed by the HIP device id)
 

@@ -228,3 +228,55 @@ def test_engine_fused_equals_three_step(lib, h, w):
     finally:
         lib.vfi_test_set_option(b"m2m_fused", 1)
         eng.close()
+
+
+# ---- the generic 4-channel splat on the same machinery (softsplat4_kernel: classification + compaction) ------------------------------
+@pytest.mark.parametrize("N,H,W,kind", [(1, 96, 160, "smooth"), (2, 70, 90, "translate"), (1, 136, 240, "noise8"), (1, 64, 96, "noise1"), (1, 128, 128, "zoom"),
+                                        (1, 64, 64, "point"), (1, 200, 300, "far")])
+def test_softsplat4_vs_c_oracle_and_list_kernel(lib, N, H, W, kind):
+    """vfi_softsplat_sum, C = 4: the staged list gather with source compaction (option splat_atomic = 3: the M2M render kernel's
+    machinery as one splat) against the plain-C oracle, and against the default list kernel: bit-identical where neither takes a side
+    path (coherent fields), within summation-order noise elsewhere."""
+    g = torch.Generator().manual_seed(H * 7 + W)
+    a = torch.rand((N, H, W, 4), generator=g)
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    f = torch.empty((N, H, W, 2))
+    for n in range(N):
+        if kind == "smooth":
+            f[n, ..., 0], f[n, ..., 1] = 3.0 * torch.sin(yy / 37.0 + n) + 1.3, 2.0 * torch.cos(xx / 41.0) - 0.6
+        elif kind == "translate":
+            f[n, ..., 0], f[n, ..., 1] = 2.25 + n, -1.75
+        elif kind == "noise8":
+            f[n] = torch.randn((H, W, 2), generator=g) * 8.0
+        elif kind == "noise1":
+            f[n] = torch.randn((H, W, 2), generator=g)
+        elif kind == "zoom":
+            f[n, ..., 0], f[n, ..., 1] = (W / 2 - xx) * 0.7, (H / 2 - yy) * 0.7
+        elif kind == "point":
+            f[n, ..., 0], f[n, ..., 1] = (W / 3 + 0.37) - xx, (H / 2 + 0.21) - yy
+        elif kind == "far":
+            f[n, ..., 0], f[n, ..., 1] = 140.0 * torch.sin(yy / 60.0), -90.0 * torch.cos(xx / 80.0)
+    if kind == "noise8":
+        f[0, 3, 4, 0] = float("nan")
+        f[0, 2, 2, 1] = float("-inf")
+    ad, fd = a.cuda(), f.cuda()
+
+    def run(mode):
+        assert lib.vfi_test_set_option(b"splat_atomic", mode) == 0
+        try:
+            out = torch.full((N, H, W, 4), float("nan"), device="cuda")
+            _ck(lib.vfi_softsplat_sum(ptr(ad), ptr(fd), ptr(out), N, H, W, 4, None), "softsplat")
+            torch.cuda.synchronize()
+            return out.cpu()
+        finally:
+            lib.vfi_test_set_option(b"splat_atomic", 0)
+
+    got, old = run(3), run(0)
+    want = torch.from_numpy(M.softsplat_sum(np.ascontiguousarray(a.permute(0, 3, 1, 2).numpy()), np.ascontiguousarray(f.permute(0, 3, 1, 2).numpy()))).permute(0, 2, 3, 1)
+    tol = 2e-5 * max(1.0, float(want.abs().max()))
+    assert float((got - want).abs().max()) <= tol, describe_diff(got, want, f"softsplat4 vs oracle {kind}")
+    assert torch.equal(got, run(3)), "run-to-run determinism"
+    if kind in ("smooth", "translate", "noise1"):
+        assert torch.equal(got, old), describe_diff(got, old, f"softsplat4 vs list kernel {kind}")
+    if kind == "translate":
+        assert torch.equal(got, want), describe_diff(got, want, "uniform translation: the sequential oracle's order")

@@ -11,11 +11,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
+ge.load_package()
+from cfi_amd import _lib as _vfi_lib  # noqa: E402
+
+_vfi_lib.use_test_build()      # the A/B taps live in libvfi_hip_test.so only; one process uses one library, chosen before build() loads it
 ge.build()
 ge.load_package()
 from cfi_amd import _lib  # noqa: E402
 
-_lib.use_test_build()      # the A/B taps live in libvfi_hip_test.so only
 lib = _lib.load()
 _lib.check(lib.vfi_init(0), "init")
 

@@ -5,7 +5,7 @@
 export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 mkdir -p gpurun_out
-TAG=${1:-r05}
+TAG=${1:?usage: profile_m2m.sh <tag, e.g. r06>}
 prof() {  # name, command, rocprof args...
   local name=$1 cmd=$2; shift 2
   rm -rf gpurun_out/prof_$name

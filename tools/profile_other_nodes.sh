@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 mkdir -p gpurun_out
-TAG=${1:-r05}
+TAG=${1:?usage: profile_other_nodes.sh <tag, e.g. r06>}
 for model in gmfss ifunet ifrnet film; do
   cmd="python tools/${model}_bench.py"
   [ $model = gmfss ] && cmd="$cmd --coherent"

@@ -10,11 +10,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 
-ge.build()
 ge.load_package()
 from cfi_amd import _lib  # noqa: E402
 
+MODE = int(sys.argv[1]) if len(sys.argv) > 1 else 0      # option splat_atomic (0 default; 3 = the staged list gather as one splat): needs the test build
+if MODE:
+    _lib.use_test_build()
+ge.build()
 lib = _lib.load()
+if MODE:
+    assert lib.vfi_test_set_option(b"splat_atomic", MODE) == 0
 _lib.check(lib.vfi_init(0), "init")
 p = lambda t: C.c_void_p(t.data_ptr())
 
