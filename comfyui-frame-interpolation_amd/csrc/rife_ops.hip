@@ -973,15 +973,19 @@ template <int SP, bool HAS_PREV, int NF, int NX>
 __global__ __launch_bounds__(256) void stage_trans_quad_kernel(const float* __restrict__ Ppool, size_t pack_stride,
                                                                RifeTasks tasks, const float* __restrict__ T,
                                                                float* __restrict__ F, float* __restrict__ Xo, int Hp,
-                                                               int Wp, int tiles_x) {
+                                                               int Wp, int tiles_x, int xcd_per, int n_tiles) {
     static_assert(SP == 2 || SP == 4 || SP == 8, "quad transition: block scales 4->2, 8->4, 16->8");
+    // xcd_per > 0: XCD-aware order (workgroup x runs on XCD x % 8: XCD k takes the contiguous band of tiles [k * xcd_per, (k + 1) * xcd_per),
+    // so that the pack rows neighbouring tile rows share are read through one L2)
+    const int bid = xcd_per > 0 ? ((int)blockIdx.x & 7) * xcd_per + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+    if (bid >= n_tiles || (xcd_per > 0 && ((int)blockIdx.x >> 3) >= xcd_per)) return;
     static_assert(NX == 0 || (NX == 8 && NF == 1), "carried block features: arch 4.26 only");
     constexpr int SI = 2 * SP;          // scale of the block that produced T
     constexpr int OFF = SP / 2 - 1;     // first centre pixel of a cell
     constexpr int NV = 5 + NX;          // flow 4, mask, carried features
     const int Hs = Hp / SP, Ws = Wp / SP, Hi = Hp / SI, Wi = Wp / SI;
     const int b = blockIdx.y;
-    const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x - tile_y * tiles_x;
+    const int tile_y = bid / tiles_x, tile_x = bid - tile_y * tiles_x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ql = lane & 3;
     const float* Tb = T + (size_t)b * Hi * Wi * (NX ? 16 : 8);
     const float rs = 1.0f / (float)SI, fs = (float)SI;
@@ -1093,9 +1097,11 @@ int stage_trans_launch(const float* Ppool, size_t pack_stride, const RifeTasks& 
     TraceScope ts(s_next == 4 ? "stage_trans4" : (s_next == 2 ? "stage_trans2" : "stage_trans1"), st);   // per target scale: bench.py prices each
     if ((s_next == 2 || s_next == 4) && (stage_quad_mask() & s_next)) {
         const int qtx = cdiv(Ws, 16);
-        dim3 qgrid(qtx * cdiv(Hs, 4), B);
+        const int q_tiles = qtx * cdiv(Hs, 4);
+        const int q_per = option(kOptXcdBands) ? cdiv(q_tiles, 8) : 0;
+        dim3 qgrid(q_per ? q_per * 8 : q_tiles, B);
 #define VFI_SQ(SPV, HP, NFV) \
-    hipLaunchKernelGGL((stage_trans_quad_kernel<SPV, HP, NFV, 0>), qgrid, dim3(256), 0, st, Ppool, pack_stride, tasks, T, F, X, Hp, Wp, qtx)
+    hipLaunchKernelGGL((stage_trans_quad_kernel<SPV, HP, NFV, 0>), qgrid, dim3(256), 0, st, Ppool, pack_stride, tasks, T, F, X, Hp, Wp, qtx, q_per, q_tiles)
 #define VFI_SQ2(SPV, HP) \
     do { if (NF == 1) VFI_SQ(SPV, HP, 1); else VFI_SQ(SPV, HP, 2); } while (0)
         if (s_next == 4) {
@@ -1450,9 +1456,11 @@ int stage_trans_x_launch(const float* Ppool, size_t pack_stride, const RifeTasks
     TraceScope ts(s_next == 8 ? "stage_transx8" : (s_next == 4 ? "stage_transx4" : (s_next == 2 ? "stage_transx2" : "stage_transx1")), st);
     if (s_next >= 2 && (stage_quad_mask() & s_next)) {
         const int qtx = cdiv(Ws, 16);
-        dim3 qgrid(qtx * cdiv(Hs, 4), B);
+        const int q_tiles = qtx * cdiv(Hs, 4);
+        const int q_per = option(kOptXcdBands) ? cdiv(q_tiles, 8) : 0;
+        dim3 qgrid(q_per ? q_per * 8 : q_tiles, B);
 #define VFI_SQ(SPV, HP) \
-    hipLaunchKernelGGL((stage_trans_quad_kernel<SPV, HP, 1, 8>), qgrid, dim3(256), 0, st, Ppool, pack_stride, tasks, T, F, X, Hp, Wp, qtx)
+    hipLaunchKernelGGL((stage_trans_quad_kernel<SPV, HP, 1, 8>), qgrid, dim3(256), 0, st, Ppool, pack_stride, tasks, T, F, X, Hp, Wp, qtx, q_per, q_tiles)
 #define VFI_SQ2(SPV) \
     do { if (has_prev) VFI_SQ(SPV, true); else VFI_SQ(SPV, false); } while (0)
         if (s_next == 8) VFI_SQ2(8);
@@ -1484,9 +1492,13 @@ int stage_trans_x_launch(const float* Ppool, size_t pack_stride, const RifeTasks
 // ---------------------------------------------------------------------------------------
 __global__ void final_blend_kernel(const float* __restrict__ Ppool, size_t pack_stride, RifeTasks tasks,
                                    const float* __restrict__ T, const float* __restrict__ F, float* __restrict__ out,
-                                   float* __restrict__ Fdbg, int H, int W, int Hp, int Wp, int s, int tp) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= H * W) return;
+                                   float* __restrict__ Fdbg, int H, int W, int Hp, int Wp, int s, int tp, int xcd_per) {
+    // xcd_per > 0: XCD-aware order — workgroup x of a frame runs on XCD x % 8 (the launch's x extent is a multiple of 8), so XCD k takes the
+    // contiguous run of 256-pixel segments [k * xcd_per, (k + 1) * xcd_per): the two pack rows a bilinear tap pair touches are then read
+    // through ONE L2 instead of two (r6 PMC: 1.345x the algorithmic bytes with the plain order)
+    const int seg = xcd_per > 0 ? ((int)blockIdx.x & 7) * xcd_per + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+    const int idx = seg * blockDim.x + threadIdx.x;
+    if (idx >= H * W || (xcd_per > 0 && ((int)blockIdx.x >> 3) >= xcd_per)) return;
     const int b = blockIdx.y;
     const int X = idx % W, Y = idx / W;
     const int Hs = Hp / s, Ws = Wp / s;
@@ -1514,10 +1526,12 @@ __global__ void final_blend_kernel(const float* __restrict__ Ppool, size_t pack_
 int final_blend_launch(const float* Ppool, size_t pack_stride, const RifeTasks& tasks, int B, const float* T,
                        const float* F, float* out, float* Fdbg, int H, int W, int Hp, int Wp, int s, int tp,
                        hipStream_t st) {
-    dim3 grid(cdiv(H * W, 256), B);
+    const int segs = cdiv(H * W, 256);
+    const int xcd_per = option(kOptXcdBands) ? cdiv(segs, 8) : 0;
+    dim3 grid(xcd_per ? xcd_per * 8 : segs, B);
     TraceScope ts("final_blend", st);
     hipLaunchKernelGGL(final_blend_kernel, grid, dim3(256), 0, st, Ppool, pack_stride, tasks, T, F, out, Fdbg, H, W,
-                       Hp, Wp, s, tp);
+                       Hp, Wp, s, tp, xcd_per);
     VFI_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -70,6 +70,7 @@ enum Option {
     kOptDeconvWino,      // 1: ConvTranspose2d(4, 2, 1) + PixelShuffle (RIFE lastconv) as a 96-channel 3x3 layer on the Winograd kernel (default), 0: grouped direct kernel
     kOptEncodeBatched,   // 1: one frame-pack launch for a batch of frames where the caller offers one (default), 0: one launch per frame
     kOptWinoQuant,       // 1: layer objects leave launches of <= 2 rounds with a nearly empty last round to the direct kernel (default), 0: item count only
+    kOptXcdBands,        // 1: XCD-aware workgroup order of the RIFE gather kernels (final blend, quad transitions), 0: plain order (default: r6 A/B measured the banded order 2-5 % SLOWER, profiles/r06_xcd_bands_ab.txt)
     kOptM2mFused,        // 1: M2M render as one kernel (m2m_render.hip; default), 0: splat inputs + summation splat + combine as separate launches
     kOptWinoProbe,       // 1..4: the hot Winograd instantiation takes its cycle-ledger form (conv_wino.hip: g_wino_probe_out; default 0)
     kOptCount

@@ -25,7 +25,7 @@ g = torch.Generator(device="cpu").manual_seed(0)
 raw = torch.rand((B + 1, H, W, 3), generator=g).cuda()
 out = torch.empty((B, H, W, 3), device="cuda")
 slot0, slot1, ts = list(range(B)), list(range(1, B + 1)), [0.5] * B
-names = ("conv0a_b0", "conv0b_b0", "conv0a_b1", "conv0b_b1", "conv0a_b2", "conv0b_b2", "conv0b_b3", "trans1_conv0a", "encode_batch")
+names = ("conv0a_b0", "conv0b_b0", "conv0a_b1", "conv0b_b1", "conv0a_b2", "conv0b_b2", "conv0b_b3", "trans1_conv0a", "encode_batch", "stage_trans4", "stage_trans2", "final_blend")
 
 
 def step():
@@ -35,7 +35,11 @@ def step():
 
 ref = None
 for spec in [""] + sys.argv[1:]:
-    lib.vfi_test_variant_override(spec.encode())
+    if spec.startswith("opt:"):      # "opt:xcd_bands=0": a library A/B option instead of a variant override
+        k, v = spec[4:].split("=")
+        assert lib.vfi_test_set_option(k.encode(), int(v)) == 0
+    else:
+        lib.vfi_test_variant_override(spec.encode())
     try:
         step(); step()
         torch.cuda.synchronize()
