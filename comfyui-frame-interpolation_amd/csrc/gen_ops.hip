@@ -148,6 +148,25 @@ __global__ void axpby_kernel(const float* __restrict__ a, int a_cs, const float*
     out[p * out_cs + c] = v;
 }
 
+// the same for C % 4 == 0 with 16-byte aligned windows: one float4 per thread, 32-bit index arithmetic (the scalar form spends a 64-bit
+// division per ELEMENT: IFUNet's 73 and FILM's 40 calls per frame ran at 2.5 TB/s)
+__global__ void axpby4_kernel(const float* __restrict__ a, int a_cs, const float* __restrict__ b, int b_cs, float* __restrict__ out, int out_cs,
+                              unsigned total, unsigned q, float alpha, float beta) {
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const unsigned p = idx / q, g = idx - p * q;
+    const float4 x = *(const float4*)(a + (size_t)p * a_cs + 4 * g);
+    float4 v = make_float4(__fmul_rn(x.x, alpha), __fmul_rn(x.y, alpha), __fmul_rn(x.z, alpha), __fmul_rn(x.w, alpha));
+    if (b) {
+        const float4 y = *(const float4*)(b + (size_t)p * b_cs + 4 * g);
+        v.x = __fadd_rn(v.x, __fmul_rn(y.x, beta));
+        v.y = __fadd_rn(v.y, __fmul_rn(y.y, beta));
+        v.z = __fadd_rn(v.z, __fmul_rn(y.z, beta));
+        v.w = __fadd_rn(v.w, __fmul_rn(y.w, beta));
+    }
+    *(float4*)(out + (size_t)p * out_cs + 4 * g) = v;
+}
+
 }  // namespace vfi
 
 using namespace vfi;
@@ -502,6 +521,15 @@ int vfi_axpby(const float* a_dev, int a_cs, const float* b_dev, int b_cs, float*
               float alpha, float beta, void* stream) {
     VFI_REQUIRE(a_dev && out_dev && pixels > 0 && C > 0, "vfi_axpby: bad arguments");
     TraceScope ts("axpby", (hipStream_t)stream);
+    const bool vec = C % 4 == 0 && a_cs % 4 == 0 && out_cs % 4 == 0 && (!b_dev || b_cs % 4 == 0) &&
+                     ((((uintptr_t)a_dev | (uintptr_t)out_dev | (uintptr_t)b_dev) & 15) == 0) && pixels * (C / 4) < (int64_t)0xffffff00u;
+    if (vec) {
+        const unsigned total = (unsigned)(pixels * (C / 4));
+        hipLaunchKernelGGL(axpby4_kernel, dim3((total + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, a_dev, a_cs, b_dev, b_cs, out_dev, out_cs, total,
+                           (unsigned)(C / 4), alpha, beta);
+        VFI_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(axpby_kernel, dim3(nblk(pixels * C)), dim3(256), 0, (hipStream_t)stream, a_dev, a_cs, b_dev, b_cs, out_dev,
                        out_cs, (long)pixels, C, alpha, beta);
     VFI_CHECK_HIP(hipGetLastError());
