@@ -60,6 +60,7 @@ PROTOTYPES = {
                                     C.c_int, C.c_void_p]),
     "vfi_conv_create": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "vfi_conv_destroy": (None, [C.c_void_p]),
+    "vfi_conv_create_up2x2": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "vfi_conv_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_float, C.c_void_p]),
     "vfi_avgpool2": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -361,6 +361,9 @@ int conv_pick_variant(const ConvArgs& a, int stride, bool grouped) {
     // launches carry 1..32 tasks, by the image at a nominal 8 tasks: tile variants differ in K-chunk size, i.e. in fp32 summation
     // order, and a frame's result must not depend on how many tasks shared its launch (tests/test_gpu_rife.py: bit-equal).
     const long px = (long)(a.split_ok ? a.N : 8) * a.Hout * a.Wout;
+    // up-sample x2 + 2x2 (tap masks): the 16x8x64 tile with 16-channel chunks — 2 .. 8 K-steps per barrier where the 8-channel chunk has 1 .. 4
+    // (tools/film_variant_ab.py at 1080p, ms for FILM's three layers: m2n2 2.40, m1n2 2.26, m2n2k16 2.27, m1n2k16 2.07)
+    if (!grouped && stride == 1 && a.ntaps == 4 && a.tapmask) return kConv2Base + (a.Cin_p % 16 == 0 ? 28 : 26);
     if (!grouped && stride == 2 && a.ntaps == 4) return kConv2Base + (a.Cout_p % 64 == 0 ? 21 : 20);
     if (!grouped && stride == 1 && a.ntaps != 9) {  // 2x2 'same' / 1x1 convs (FILM): second generation only
         const bool big = px * (a.Cout_p / 32) >= 256L * 4 * n_cus_cached();
@@ -387,7 +390,7 @@ int conv_pick_variant(const ConvArgs& a, int stride, bool grouped) {
     // coarse pyramid levels of the layer objects (M2M's PWC decoders at 17x30 / 34x60: 24 .. 80 workgroups of the 64-channel tile on 256
     // CUs, each walking the whole K loop alone — 46 us for 120 -> 128 @17x30): the 32-channel N tile doubles the workgroups and halves
     // each one's serial MFMA chain; same K chunk (8), i.e. the same summation order and bits as d1_m1n2
-    if (a.split_ok && (n2 || n3) && px <= 6000) return kConv2Base + 25;   // d1_m1n1
+    if (a.split_ok && (n2 || n3) && px <= 6000) return kConv2Base + 29;   // d1_m1n1
     if (n2) {   // d1_m2n2 (16x16 px tile) / d1_m1n2 (16x8): the larger M tile re-uses each weight fragment twice as often
         // A/B option m2n2_px: pixel count from which wide layers take m2n2.  Measured on FILM / M2M at 1080p
         // (profiles/r02_film_tile_experiment.txt): 100k is the best of {never, 1.5M, 400k, 100k, 20k} by 0.6 % only — not

@@ -59,7 +59,12 @@ struct Conv2Geom {
 
 // EXT = the layer uses the extended feature set (replicate padding, per-channel PReLU / sigmoid, post affine,
 // interleaved transposed-conv store): compiled separately so the RIFE / FILM hot path carries none of its branches.
-template <int STRIDE, int TAPS, int MT, int NT, int WM, int WN, int CK, bool GROUPED, bool EXT>
+// MASKED (2x2 taps only; round 6): the layer is "nearest-neighbour up-sampling x2, then a 2x2 'same' convolution" (FILM's Fusion,
+// film_arch.py:282-292) computed on the LOW-resolution input: output parity (py, px) of the up-sampled image reads low-resolution pixels
+// (y + a, x + b), a <= py, b <= px, with the 2x2 weights summed over the taps that land on the same input pixel — 1 + 2 + 2 + 4 = 9 tap
+// blocks instead of 16, no up-sampled tensor.  The four parities are 4 * Cout output channels; an N block belongs to one parity, walks only
+// that parity's taps (a.tapmask[blockIdx.y]) and stores its pixels interleaved into the [2H, 2W] output.
+template <int STRIDE, int TAPS, int MT, int NT, int WM, int WN, int CK, bool GROUPED, bool EXT, bool MASKED = false>
 __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource / LDS-DMA builtins do not exist in the host pass
     using G = Conv2Geom<STRIDE, TAPS, MT, NT, WM, WN, CK, GROUPED>;
@@ -120,9 +125,11 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
         return __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)n * img_floats), 0, img_floats * 4, 0x00020000);
     };
     // weight DMA: per-lane source pointers of this wave's pieces (tile- and chunk-invariant part)
+    const unsigned tmask = MASKED ? a.tapmask[blockIdx.y] : 0xffffu;
     const int tapstride = cin8 * a.Cout_p * 8;
     const int c8stride = a.Cout_p * 8;
     const float* wsrc[G::NBW];
+    bool wlive[G::NBW];
 #pragma unroll
     for (int i = 0; i < G::NBW; ++i) {
         const int j = wave + 4 * i;  // piece index in LDS order [group][tap][c8][BN/32]
@@ -131,6 +138,7 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
         const int t = (j / (BN / 32) / C8) % TAPS;
         const int gg = j / (BN / 32) / C8 / TAPS;
         wsrc[i] = a.w + (size_t)(gg * TAPS + t) * tapstride + c8 * c8stride + (cob + sub * 32) * 8 + lane * 4;
+        wlive[i] = !MASKED || ((tmask >> t) & 1u);      // (wave-uniform)
     }
     auto issue = [&](const __amdgpu_buffer_rsrc_t& rsrc, const int(&avoff)[G::NAW], int chunk, int buf) {
         float* abuf = smem + buf * G::BUF_FLOATS;
@@ -146,7 +154,7 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < G::NBW; ++i) {
             const int j = wave + 4 * i;
-            if (G::NB_INSTR % 4 == 0 || j < G::NB_INSTR)
+            if ((G::NB_INSTR % 4 == 0 || j < G::NB_INSTR) && wlive[i])
                 __builtin_amdgcn_global_load_lds((glb_ptr_t)(wsrc[i] + wadv), (lds_ptr_t)(bbuf + j * 256), 16, 0, 0);
         }
     };
@@ -230,6 +238,39 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
                 for (int nt = 0; nt < NT; ++nt)
                     fb[nt] = *(const f32x4*)&sb[bbase + ((t * C8 + c8) * BN + nt * 32) * 8];
             };
+            if constexpr (MASKED) {
+                // the parity's taps only: 1, 2 or 4 of the 4 (C8 == 1: one K-step per tap); same pipelining, step list from the mask
+                static_assert(!MASKED || TAPS == 4, "masked form: 2x2 taps");
+                // (wave-uniform scalars, no indexed writes: lowest set bits of the mask in turn)
+                const unsigned m0 = tmask & 15u, m1 = m0 & (m0 - 1u), m2 = m1 & (m1 - 1u), m3 = m2 & (m2 - 1u);
+                const int tl[4] = {m0 ? __builtin_ctz(m0) : 0, m1 ? __builtin_ctz(m1) : 0, m2 ? __builtin_ctz(m2) : 0, m3 ? __builtin_ctz(m3) : 0};
+                const int ntl = __builtin_popcount(m0);
+                auto run = [&](auto NTL) {
+                    constexpr int n_ = decltype(NTL)::value * C8;      // K-steps of this chunk: the parity's taps x the chunk's 8-channel groups
+                    auto step_of = [&](int i) { return tl[i / C8] * C8 + i % C8; };
+                    frag(step_of(0), av[0], bv[0]);
+#pragma unroll
+                    for (int i = 0; i < n_; ++i) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt)
+                                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i & 1][mt][j], bv[i & 1][nt][j], acc[mt][nt], 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (j == 0 && i + 1 < n_) {
+                                frag(step_of(i + 1), av[(i + 1) & 1], bv[(i + 1) & 1]);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    }
+                };
+                if (ntl == 1) run(std::integral_constant<int, 1>{});
+                else if (ntl == 2) run(std::integral_constant<int, 2>{});
+                else run(std::integral_constant<int, 4>{});
+            } else {
             frag(0, av[0], bv[0]);
 #pragma unroll
             for (int st = 0; st < NS; ++st) {
@@ -255,6 +296,7 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
                     }
                 }
             }
+            }
             __syncthreads();  // chunk consumed by every wave; the next chunk has landed
             buf ^= 1;
         }
@@ -264,6 +306,30 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
         // LeakyReLU with a slope in [0,1] (then lrelu(v) == max(v, v*slope)), residual folded.  The generic path below
         // re-tests act / res / beta / bounds for each of the 64 values of a lane — ~4000 instructions and ~700 scalar branches
         // per tile, during which this wave feeds no MFMAs.
+        if constexpr (MASKED) {
+            // parity-interleaved store: N block -> parity g = first channel / par_cout; low-resolution pixel (oy, ox) -> (2 oy + gy, 2 ox + gx)
+            const int gpar = cob / a.par_cout, gy = gpar >> 1, gx = gpar & 1;
+            const int xstr = 2 * a.out_cs, ystr = 4 * a.Wout * a.out_cs;
+            const bool interior = Y0 + THO <= a.Hout && X0 + TWO <= a.Wout;
+            const float uslope = a.act == 1 ? a.slope : 1.0f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int co = co0 + nt * 32 + l31;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int s = wm * MT + mt;
+                    const int sx = s % SUBX, sy = s / SUBX;
+                    const int oy0 = Y0 + sy * 4, ox0 = X0 + sx * 8 + 4 * half;
+                    float* ob = outp + ((size_t)(n * 2 * a.Hout + 2 * oy0 + gy) * (2 * a.Wout) + 2 * ox0 + gx) * a.out_cs + (co - gpar * a.par_cout);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[mt][nt][r] + bs[nt];
+                        v = v > 0.f ? v : v * uslope;
+                        if (interior || (oy0 + (r >> 2) < a.Hout && ox0 + (r & 3) < a.Wout)) ob[(r >> 2) * ystr + (r & 3) * xstr] = v;
+                    }
+                }
+            }
+        } else {
         const bool nhwc = a.out_mode == 0 && !GROUPED;
         const bool inter = EXT && GROUPED && a.out_mode == 2;       // transposed conv, parity groups interleaved into NHWC
         const bool fast = a.res == nullptr && (nhwc || inter) && (a.act == 0 || a.act == 1 || (EXT && (a.act == 3 || a.act == 5))) &&
@@ -381,6 +447,7 @@ __global__ __launch_bounds__(256) void conv_mfma2_kernel(const ConvArgs a) {
                 }
             }
         }
+        }
         if (!has_next) break;
         tile = ntile;
         n = nn;
@@ -455,7 +522,7 @@ static int split_reduce(const ConvArgs& a, const float* ws, int ks, size_t slice
     return 0;
 }
 
-template <int STRIDE, int TAPS, int MT, int NT, int WM, int WN, int CK, bool GROUPED, bool EXT>
+template <int STRIDE, int TAPS, int MT, int NT, int WM, int WN, int CK, bool GROUPED, bool EXT, bool MASKED = false>
 static int launch2_e(ConvArgs a, hipStream_t s, const char* name) {
     using G = Conv2Geom<STRIDE, TAPS, MT, NT, WM, WN, CK, GROUPED>;
     a.ksplit = 0, a.split_stride = 0;      // launcher-owned fields (callers do not set them)
@@ -475,11 +542,11 @@ static int launch2_e(ConvArgs a, hipStream_t s, const char* name) {
     int occ = occ_of[dev].load(std::memory_order_acquire);
     if (!occ) {
         VFI_CHECK_HIP(hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&conv_mfma2_kernel<STRIDE, TAPS, MT, NT, WM, WN, CK, GROUPED, EXT>),
+            reinterpret_cast<const void*>(&conv_mfma2_kernel<STRIDE, TAPS, MT, NT, WM, WN, CK, GROUPED, EXT, MASKED>),
             hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
         int o = 0;
         VFI_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &o, reinterpret_cast<const void*>(&conv_mfma2_kernel<STRIDE, TAPS, MT, NT, WM, WN, CK, GROUPED, EXT>), 256,
+            &o, reinterpret_cast<const void*>(&conv_mfma2_kernel<STRIDE, TAPS, MT, NT, WM, WN, CK, GROUPED, EXT, MASKED>), 256,
             G::LDS_BYTES));
         hipDeviceProp_t p;
         VFI_CHECK_HIP(hipGetDeviceProperties(&p, dev));
@@ -495,7 +562,7 @@ static int launch2_e(ConvArgs a, hipStream_t s, const char* name) {
     // reduce + epilogue kernel; fixed summation order, so still deterministic.  Chosen so that the grid reaches ~3 workgroups
     // per slot while every split keeps >= 8 chunks (the DMA pipeline's prologue / epilogue amortised).
     int ks = 1;
-    if (!GROUPED && a.out_mode == 0 && a.split_ok && split_enabled()) {
+    if (!GROUPED && !MASKED && a.out_mode == 0 && a.split_ok && split_enabled()) {
         const int nchunks = a.Cin_p / CK;
         const long wgs = (long)T * ny, want = 3L * cus * occ;
         // ... and a K loop long enough that a fraction of it outweighs the reduce launch (~20 us): 32 chunks of a 3x3 layer
@@ -528,7 +595,7 @@ static int launch2_e(ConvArgs a, hipStream_t s, const char* name) {
         {
             TraceScope ts(name, s);
             // (the same instantiation as the unsplit launch: its dynamic-LDS attribute is the one set above; pad_replicate implies EXT)
-            hipLaunchKernelGGL((conv_mfma2_kernel<STRIDE, TAPS, MT, NT, WM, WN, CK, GROUPED, EXT>), dim3(T, ny, ks), dim3(256), G::LDS_BYTES, s, p);
+            hipLaunchKernelGGL((conv_mfma2_kernel<STRIDE, TAPS, MT, NT, WM, WN, CK, GROUPED, EXT, MASKED>), dim3(T, ny, ks), dim3(256), G::LDS_BYTES, s, p);
             VFI_CHECK_HIP(hipGetLastError());
         }
         return split_reduce(a, ws, ks, slice, s);
@@ -539,11 +606,19 @@ static int launch2_e(ConvArgs a, hipStream_t s, const char* name) {
     int gx = (launch_cus(cus) * occ) / ny;
     if (gx < 1) gx = 1;
     if (gx > T || (long)T * ny < 4L * cus * occ) gx = T;
+    if (MASKED) gx = T;      // N blocks carry 1, 2, 2 or 4 taps: one workgroup per tile, the dispatcher balances them
     dim3 grid(gx, ny);
     TraceScope ts(name, s);
-    hipLaunchKernelGGL((conv_mfma2_kernel<STRIDE, TAPS, MT, NT, WM, WN, CK, GROUPED, EXT>), grid, dim3(256), G::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((conv_mfma2_kernel<STRIDE, TAPS, MT, NT, WM, WN, CK, GROUPED, EXT, MASKED>), grid, dim3(256), G::LDS_BYTES, s, a);
     VFI_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+template <int STRIDE, int TAPS, int MT, int NT, int WM, int WN, int CK>
+static int launch2_masked(const ConvArgs& a, hipStream_t s, const char* name) {
+    VFI_REQUIRE(a.tapmask && a.par_cout > 0 && a.par_cout % (WN * NT * 32) == 0 && a.Cout_p == 4 * a.par_cout && a.act <= 1 && !a.res && !a.beta && !a.in_plane,
+                "conv2 %s: masked (up-sample x2 + 2x2) form needs 4 parity groups of a multiple of %d channels, act none / LeakyReLU", name, WN * NT * 32);
+    return launch2_e<STRIDE, TAPS, MT, NT, WM, WN, CK, false, false, true>(a, s, name);
 }
 
 template <int STRIDE, int TAPS, int MT, int NT, int WM, int WN, int CK, bool GROUPED>
@@ -581,7 +656,11 @@ static const ConvVariant kVariants2[] = {
     {"d1_m4n2", 1, 9, 4, 2, 4, 1, 8, 0},      // 54: 32x16 px x 64 ch (8 accumulators per wave)
     {"d1t1_m1n2k32", 1, 1, 1, 2, 4, 1, 32, 0},      // 55: 1x1 with 32-channel K chunks (4 K-steps per barrier instead of 1), 16x8 px x 64 ch
     {"d1t1_m2n2w22k32", 1, 1, 2, 2, 2, 2, 32, 0},   // 56: ... 16x8 px x 128 ch (wide inputs)
-    {"d1_m1n1", 1, 9, 1, 1, 4, 1, 8, 0},            // 57: 3x3, 16x8 px x 32 ch — coarse pyramid levels (r6): twice the workgroups, half the serial K loop
+    {"d1t4_m2n2_up2", 1, 4, 2, 2, 4, 1, 8, 0},      // 57: nearest x2 + 2x2 'same' on the low-resolution input, per-parity tap masks (FILM Fusion, r6)
+    {"d1t4_m1n2_up2", 1, 4, 1, 2, 4, 1, 8, 0},      // 58
+    {"d1t4_m2n2k16_up2", 1, 4, 2, 2, 4, 1, 16, 0},  // 59: ... with 16-channel chunks (2 .. 8 K-steps per barrier instead of 1 .. 4)
+    {"d1t4_m1n2k16_up2", 1, 4, 1, 2, 4, 1, 16, 0},  // 60
+    {"d1_m1n1", 1, 9, 1, 1, 4, 1, 8, 0},            // 61: 3x3, 16x8 px x 32 ch — coarse pyramid levels (r6): twice the workgroups, half the serial K loop
 };
 int conv2_num_variants() { return (int)(sizeof(kVariants2) / sizeof(kVariants2[0])); }
 const ConvVariant& conv2_variant(int i) { return kVariants2[i]; }
@@ -613,7 +692,11 @@ int conv2_launch(const ConvArgs& a, int idx, hipStream_t s, const char* nm) {
         case 22: return launch2_t<1, 9, 4, 2, 4, 1, 8, false>(a, s, nm);
         case 23: return launch2_t<1, 1, 1, 2, 4, 1, 32, false>(a, s, nm);
         case 24: return launch2_t<1, 1, 2, 2, 2, 2, 32, false>(a, s, nm);
-        case 25: return launch2_t<1, 9, 1, 1, 4, 1, 8, false>(a, s, nm);
+        case 25: return launch2_masked<1, 4, 2, 2, 4, 1, 8>(a, s, nm);
+        case 26: return launch2_masked<1, 4, 1, 2, 4, 1, 8>(a, s, nm);
+        case 27: return launch2_masked<1, 4, 2, 2, 4, 1, 16>(a, s, nm);
+        case 28: return launch2_masked<1, 4, 1, 2, 4, 1, 16>(a, s, nm);
+        case 29: return launch2_t<1, 9, 1, 1, 4, 1, 8, false>(a, s, nm);
     }
     set_error("conv2: bad variant %d", idx);
     return -3;

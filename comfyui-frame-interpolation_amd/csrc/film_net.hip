@@ -62,6 +62,7 @@ struct vfi_film {
     Layer ext[SUB][2];
     Layer pred[4][5];          // [min(level, 3)][conv]
     Layer fuse[4][3];
+    Layer fuse_up2[4];         // fuse[f][0] in its "up-sample x2 first" form (vfi_conv_create_up2x2): used where the level above is exactly half the size
     int fuse_nf[4] = {0, 0, 0, 0};
     Layer out_conv;
     int cal[FUS] = {0, 0, 0, 0, 0};
@@ -252,8 +253,18 @@ vfi_film_t* vfi_film_create(const float* const* tensors, const int64_t* numels, 
         if (f == 0) {
             const std::vector<int> m = aligned_map(feat_channels(4));
             make(net->fuse[f][0], nf, below, 2, &m, net->cal[4]);
+            if (ok) {
+                net->fuse_up2[f].cout = nf, net->fuse_up2[f].cin_phys = net->cal[4];
+                net->fuse_up2[f].h = vfi_conv_create_up2x2(tensors[k - 2], tensors[k - 1], nf, below, m.data(), net->cal[4]);
+                if (!net->fuse_up2[f].h) ok = false;
+            }
         } else {
             make(net->fuse[f][0], nf, below, 2, nullptr, 0);
+            if (ok) {
+                net->fuse_up2[f].cout = nf, net->fuse_up2[f].cin_phys = r8(below);
+                net->fuse_up2[f].h = vfi_conv_create_up2x2(tensors[k - 2], tensors[k - 1], nf, below, nullptr, r8(below));
+                if (!net->fuse_up2[f].h) ok = false;
+            }
         }
         std::vector<int> m = aligned_map(feat_channels(lvl));
         for (int c = 0; c < nf; ++c) m.push_back(net->cal[lvl] + c);
@@ -277,6 +288,7 @@ void vfi_film_destroy(vfi_film_t* net) {
         for (Layer& L : p) vfi_conv_destroy(L.h);
     for (auto& f : net->fuse)
         for (Layer& L : f) vfi_conv_destroy(L.h);
+    for (Layer& L : net->fuse_up2) vfi_conv_destroy(L.h);
     vfi_conv_destroy(net->out_conv.h);
     free_workspace(net);
     delete net;
@@ -321,9 +333,14 @@ int vfi_film_forward(vfi_film_t* net, const float* x0_dev, const float* x1_dev, 
     for (int f = 0; f < 4; ++f) {
         const int lvl = 3 - f, h = net->hw[lvl][0], w = net->hw[lvl][1], nf = net->fuse_nf[f];
         Ten *up, *t, *o;
-        if (tmp(net, "fuse_up", h, w, net_c, &up)) return -1;
-        if (vfi_upsample_nearest(cur->p, cur->c, up->p, net_c, 1, nh, nw, h, w, net_c, st)) return -1;
-        if (conv(net->fuse[f][0], *up, 0, net->al[lvl], net->cal[lvl], h, w, 0, st)) return -1;
+        if (h == 2 * nh && w == 2 * nw) {
+            // an exact x2: nearest up-sampling + the 2x2 'same' convolution as one layer on the low-resolution tensor (9 tap blocks for 16)
+            if (vfi_conv_forward(net->fuse_up2[f].h, cur->p, cur->c, net->al[lvl].p + net->cal[lvl], net->al[lvl].c, 1, nh, nw, 0, 0.2f, st)) return -1;
+        } else {
+            if (tmp(net, "fuse_up", h, w, net_c, &up)) return -1;
+            if (vfi_upsample_nearest(cur->p, cur->c, up->p, net_c, 1, nh, nw, h, w, net_c, st)) return -1;
+            if (conv(net->fuse[f][0], *up, 0, net->al[lvl], net->cal[lvl], h, w, 0, st)) return -1;
+        }
         if (tmp(net, "fuse_t", h, w, nf, &t) || tmp(net, "fuse_o", h, w, nf, &o)) return -1;
         if (conv(net->fuse[f][1], net->al[lvl], 0, *t, 0, h, w, 1, st) || conv(net->fuse[f][2], *t, 0, *o, 0, h, w, 1, st)) return -1;
         cur = o, net_c = nf, nh = h, nw = w;

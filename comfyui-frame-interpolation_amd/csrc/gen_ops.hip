@@ -183,7 +183,8 @@ struct vfi_conv {
     float* prelu3 = nullptr;
     int Cout3_p = 0;
     int Cout = 0, Cout_p = 0, Cin = 0, Cin_p = 0, kh = 0, kw = 0, taps = 0;
-    int stride = 1, pad_mode = 0, kind = 0;  // kind 0: Conv2d, 1: ConvTranspose2d(4, 2, 1)
+    int stride = 1, pad_mode = 0, kind = 0;  // kind 0: Conv2d, 1: ConvTranspose2d(4, 2, 1), 2: nearest x2 up-sampling + Conv2d(2, 'same') (vfi_conv_create_up2x2)
+    unsigned char* tapmask = nullptr;         // kind 2: taps of every 64-channel N block's parity
 };
 
 static unsigned nblk(long n) { return (unsigned)((n + 255) / 256); }
@@ -252,8 +253,62 @@ vfi_conv_t* vfi_conv_create(const float* w_oihw_host, const float* bias_host, in
     return c;
 }
 
+// F.interpolate(x, scale 2, 'nearest') followed by Conv2d(Cin, Cout, 2, padding 'same') — FILM's Fusion (film_arch.py:282-292) — as ONE
+// layer on the LOW-resolution input: 4 * Cout output channels (parity g = 2 py + px of the up-sampled image), 2x2 taps at (y + a, x + b)
+// with the weights of the original taps (a', b') that read that input pixel summed: a = (py + a') >> 1, b = (px + b') >> 1.  Parity (0,0)
+// keeps one tap, (0,1) / (1,0) two, (1,1) four — the kernel walks 9 tap blocks instead of 16 (conv_mfma2.hip, MASKED).
+vfi_conv_t* vfi_conv_create_up2x2(const float* w_oihw_host, const float* bias_host, int Cout, int Cin, const int* chan_map, int Cin_phys) {
+    if (!w_oihw_host || Cout <= 0 || Cout % 64 || Cin <= 0 || Cin_phys % 8 || Cin_phys < Cin) {
+        set_error("vfi_conv_create_up2x2: bad arguments (Cout=%d must be a multiple of 64, Cin=%d, Cin_phys=%d a multiple of 8)", Cout, Cin, Cin_phys);
+        return nullptr;
+    }
+    vfi_conv* c = new vfi_conv();
+    c->kind = 2;
+    c->Cout = Cout;
+    c->Cout_p = 4 * Cout;
+    c->Cin = Cin;
+    c->Cin_p = Cin_phys;
+    c->kh = c->kw = 2;
+    c->taps = 4;
+    const int cin8 = Cin_phys / 8;
+    std::vector<float> wp((size_t)4 * cin8 * c->Cout_p * 8, 0.f), bp(c->Cout_p, 0.f);
+    for (int g = 0; g < 4; ++g) {
+        const int py = g >> 1, px = g & 1;
+        for (int co = 0; co < Cout; ++co) {
+            bp[g * Cout + co] = bias_host ? bias_host[co] : 0.f;
+            for (int ci = 0; ci < Cin; ++ci) {
+                const int pc = chan_map ? chan_map[ci] : ci;
+                if (pc < 0 || pc >= Cin_phys) {
+                    set_error("vfi_conv_create_up2x2: chan_map[%d]=%d outside 0..%d", ci, pc, Cin_phys - 1);
+                    delete c;
+                    return nullptr;
+                }
+                for (int ta = 0; ta < 2; ++ta)
+                    for (int tb = 0; tb < 2; ++tb) {      // original tap (ta, tb) of the up-sampled image -> low-resolution tap (a, b)
+                        const int a = (py + ta) >> 1, b = (px + tb) >> 1;
+                        wp[(((size_t)(a * 2 + b) * cin8 + pc / 8) * c->Cout_p + g * Cout + co) * 8 + (pc & 7)] += w_oihw_host[((size_t)co * Cin + ci) * 4 + ta * 2 + tb];
+                    }
+            }
+        }
+    }
+    std::vector<unsigned char> mask(c->Cout_p / 64);
+    const unsigned char gmask[4] = {0x1, 0x3, 0x5, 0xf};      // taps (bit a * 2 + b) parity g can reach: a <= py, b <= px
+    for (size_t y = 0; y < mask.size(); ++y) mask[y] = gmask[(y * 64) / Cout];
+    if (hipMalloc((void**)&c->w, wp.size() * sizeof(float)) != hipSuccess || hipMalloc((void**)&c->bias, bp.size() * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&c->tapmask, mask.size()) != hipSuccess ||
+        hipMemcpy(c->w, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->bias, bp.data(), bp.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->tapmask, mask.data(), mask.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        set_error("vfi_conv_create_up2x2: device allocation/upload failed");
+        vfi_conv_destroy(c);
+        return nullptr;
+    }
+    return c;
+}
+
 void vfi_conv_destroy(vfi_conv_t* c) {
     if (!c) return;
+    if (c->tapmask) (void)hipFree(c->tapmask);
     if (c->w) (void)hipFree(c->w);
     if (c->ww) (void)hipFree(c->ww);
     if (c->bias) (void)hipFree(c->bias);
@@ -451,7 +506,15 @@ int vfi_conv_forward(const vfi_conv_t* c, const float* in_dev, int in_cs, float*
     a.split_ok = 1;
     char name[64];
     static const bool by_shape = getenv("VFI_TRACE_SHAPES") != nullptr;      // per-shape trace rows (tools/film_bench.py --shapes)
-    if (by_shape) snprintf(name, sizeof(name), "conv%dx%d_%dto%d@%dx%d", c->kh, c->kw, c->Cin_p, c->Cout, H, W);
+    if (c->kind == 2) {      // H x W is the LOW-resolution input; the output is [2H, 2W, out_cs] (vfi_conv_create_up2x2)
+        VFI_REQUIRE(act == 0 || act == 1, "vfi_conv_forward: the up-sample x2 + 2x2 layer takes act 0 / 1");
+        a.tapmask = c->tapmask;
+        a.par_cout = c->Cout;
+        a.Cout = c->Cout_p;
+        a.out_mode = 3;
+        if (by_shape) snprintf(name, sizeof(name), "up2conv2x2_%dto%d@%dx%d", c->Cin_p, c->Cout, 2 * H, 2 * W);
+        else snprintf(name, sizeof(name), "up2conv2x2");
+    } else if (by_shape) snprintf(name, sizeof(name), "conv%dx%d_%dto%d@%dx%d", c->kh, c->kw, c->Cin_p, c->Cout, H, W);
     else snprintf(name, sizeof(name), "conv%dx%d", c->kh, c->kw);
     static std::map<std::string, const char*> names;  // stable storage for trace names
     auto it = names.find(name);

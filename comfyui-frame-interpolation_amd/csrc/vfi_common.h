@@ -121,6 +121,8 @@ struct ConvArgs {
     float post_scale, post_shift;  // y = act(...) * post_scale + post_shift  (post_scale == 0 means "not set" = 1, 0)
     int split_ok;          // caller: the launcher may cut K over several workgroups (split-K; generic layer objects only — the
                            //   RIFE network keeps one kernel per layer whatever the batch, so results do not depend on batching)
+    const unsigned char* tapmask;  // 2x2 layers in the "up-sample x2 first" form (conv_mfma2.hip, MASKED): per 64-channel N block the taps (bit a * 2 + b) of
+    int par_cout;                  //   its parity; par_cout = channels per parity group (4 groups: Cout_p == 4 * par_cout), output [2 Hout, 2 Wout] interleaved
     int ksplit;            // set by the launcher: > 1 = split-K launch, blockIdx.z owns a K range and the slice
     long split_stride;     //   out + blockIdx.z * split_stride (floats) of the partial-sum workspace
 };

@@ -100,6 +100,12 @@ void vfi_conv_destroy(vfi_conv_t* conv);
  * (the FILM node's prediction.clamp(0, 1), vfi_models/film/__init__.py:39). */
 int vfi_conv_forward(const vfi_conv_t* conv, const float* in_dev, int in_cs, float* out_dev, int out_cs,
                      int N, int H, int W, int act, float slope, void* stream);
+/* F.interpolate(x, scale_factor 2, 'nearest') + Conv2d(Cin, Cout, 2, padding 'same') — the first convolution of every FILM Fusion level
+ * (film_arch.py:282-292) — as ONE layer that reads the LOW-resolution tensor (round 6): vfi_conv_forward(c, in [N,H,W,*], out [N,2H,2W,out_cs],
+ * N, H, W, act 0 | 1, slope).  The four output parities are 4 * Cout channels of a 2x2 convolution whose weights are the original taps summed
+ * per input pixel; parity (0,0) keeps 1 tap, (0,1) / (1,0) two, (1,1) four: 9 tap blocks instead of 16 and no up-sampled tensor.  Cout % 64 == 0.
+ * Only for an exact x2 (the caller falls back to vfi_upsample_nearest + vfi_conv_forward otherwise). */
+vfi_conv_t* vfi_conv_create_up2x2(const float* weight_oihw_host, const float* bias_host, int Cout, int Cin, const int* chan_map, int Cin_phys);
 
 /* F.avg_pool2d(x, 2, 2) (odd sizes floor), film_arch.py:655-674, :112-113.  C % 4 == 0. */
 int vfi_avgpool2(const float* in_dev, int in_cs, float* out_dev, int out_cs, int N, int H, int W, int C, void* stream);

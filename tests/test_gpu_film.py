@@ -72,6 +72,47 @@ def test_generic_conv_same(lib, k, cin, cout, h, w):
     assert (got - want).abs().max().item() <= tol, describe_diff(got, want, f"conv{k}x{k} {cin}->{cout}")
 
 
+@pytest.mark.parametrize("cin,cout,h,w,act,cmapped", [(128, 64, 33, 40, 0, False), (256, 128, 17, 23, 1, False), (202, 64, 9, 15, 0, True), (64, 64, 64, 96, 0, False),
+                                                    (512, 256, 20, 31, 0, False)])
+def test_up2x2_layer_equals_nearest_upsample_then_conv2x2(lib, cin, cout, h, w, act, cmapped):
+    """vfi_conv_create_up2x2 (r6): F.interpolate(x, scale_factor=2, mode='nearest') + Conv2d(2, padding='same') [+ LeakyReLU 0.2] of FILM's Fusion
+    (film_arch.py:282-292) computed on the low-resolution tensor — against torch on the host, and against this library's own two-step form."""
+    import ctypes as C
+
+    g = torch.Generator().manual_seed(cin * 3 + cout + h)
+    x = torch.rand(1, cin, h, w, generator=g) * 2 - 1
+    wt = (torch.rand(cout, cin, 2, 2, generator=g) * 2 - 1) / (cin * 4) ** 0.5
+    b = torch.rand(cout, generator=g) - 0.5
+    y = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), wt, b, padding="same")
+    want = nhwc(F.leaky_relu(y, 0.2) if act else y)
+    cphys = (cin + 7) // 8 * 8
+    cmap = [cphys - 1 - c for c in range(cin)] if cmapped else list(range(cin))
+    xin = torch.zeros(h, w, cphys + 8)
+    xin[..., 4:4 + cphys][..., cmap] = x[0].permute(1, 2, 0)
+    xd = xin.cuda()
+    cm = (C.c_int * cin)(*cmap)
+    hnd = lib.vfi_conv_create_up2x2(wt.data_ptr(), b.data_ptr(), cout, cin, cm, cphys)
+    assert hnd, "create failed"
+    out = torch.full((2 * h, 2 * w, cout + 8), float("nan"), device="cuda")
+    _ck(lib.vfi_conv_forward(hnd, xd.data_ptr() + 16, cphys + 8, out.data_ptr() + 16, cout + 8, 1, h, w, act, 0.2, None), "up2x2 forward")
+    torch.cuda.synchronize()
+    lib.vfi_conv_destroy(hnd)
+    got = out.cpu()
+    assert torch.isnan(got[..., :4]).all() and torch.isnan(got[..., 4 + cout:]).all(), "wrote outside its channel window"
+    got = got[..., 4:4 + cout][None]
+    tol = 2e-5 * max(1.0, want.abs().max().item())
+    assert (got - want).abs().max().item() <= tol, describe_diff(got, want, f"up2x2 {cin}->{cout} @{h}x{w}")
+    # the two-step form through the same library (what FILM ran until round 6)
+    h2 = lib.vfi_conv_create(wt.data_ptr(), b.data_ptr(), cout, cin, 2, 2, cm, cphys)
+    up = torch.zeros((2 * h, 2 * w, cphys), device="cuda")
+    _ck(lib.vfi_upsample_nearest(xd.data_ptr() + 16, cphys + 8, up.data_ptr(), cphys, 1, h, w, 2 * h, 2 * w, cphys, None), "upsample")
+    out2 = torch.empty((2 * h, 2 * w, cout), device="cuda")
+    _ck(lib.vfi_conv_forward(h2, up.data_ptr(), cphys, out2.data_ptr(), cout, 1, 2 * h, 2 * w, act, 0.2, None), "conv2x2")
+    torch.cuda.synchronize()
+    lib.vfi_conv_destroy(h2)
+    assert (got[0] - out2.cpu()).abs().max().item() <= tol, "up2x2 vs upsample + conv2x2 of this library"
+
+
 def test_avgpool_nearest_bilinear_axpby(lib):
     g = torch.Generator().manual_seed(3)
     x = torch.rand(1, 8, 33, 45, generator=g)
