@@ -507,7 +507,10 @@ static int split_workspace(int dev, hipStream_t s, size_t floats, int cout_p, fl
         w.z = nullptr, w.zn = 0;
         const int n = cout_p < 4096 ? 4096 : cout_p;
         VFI_CHECK_HIP(hipMalloc((void**)&w.z, n * sizeof(float)));
-        VFI_CHECK_HIP(hipMemset(w.z, 0, n * sizeof(float)));
+        // on the launch's own stream: a NULL-stream memset is not ordered against a non-blocking stream, and under load (other pair
+        // lanes keeping the device busy) it landed AFTER the first split launch had read the vector as its bias (r6: IFRNet, lane 1's
+        // first pair off by 5e-2)
+        VFI_CHECK_HIP(hipMemsetAsync(w.z, 0, n * sizeof(float), s));
         w.zn = n;
     }
     *ws = w.p, *zeros = w.z;

@@ -127,6 +127,7 @@ int ensure_workspace(vfi_m2m* m, int H, int W) {
         VFI_CHECK_HIP(hipMalloc((void**)&m->smax, 8 * sizeof(float)));
         m->owned.push_back(m->smax);
         VFI_CHECK_HIP(hipMemset(m->smax, 0, 8 * sizeof(float)));
+        VFI_CHECK_HIP(hipStreamSynchronize(nullptr));      // (the fills above are not ordered against the caller's non-blocking stream)
     }
     m->H = H, m->W = W;
     return 0;

@@ -9,6 +9,9 @@
 //   * cost volume: the 9x9 neighbourhood of `two` comes from an LDS tile with a 4-pixel halo (zero outside the
 //     image: |one - 0| is exactly the reference's out-of-bounds branch), channels accumulated in the
 //     reference's order, so the result is bit-identical to the sequential restatement.
+#include <map>
+#include <mutex>
+
 #include "vfi_common.h"
 
 #include <cstdlib>
@@ -482,7 +485,8 @@ __global__ __launch_bounds__(256) void softsplat_tail_kernel(const float* __rest
     if (__uint_as_float(ctl->absmax_bits) > (float)(SPLAT_RCAP - 1)) splat_far_pass(in, flow, out, N, H, W, C);
 }
 
-// per-device workspace of the splat (control words, block maxima, spill list); grows, never shrinks
+// workspace of the splat (control words, block maxima, spill list) per (device, stream) — r6: engines of several pair lanes splat on
+// the same device at the same time, each on its own stream; grows, never shrinks
 struct SplatWs {
     SplatCtl* ctl = nullptr;
     uint2* ovf = nullptr;
@@ -492,13 +496,14 @@ struct SplatWs {
     unsigned char* gcount = nullptr;
     size_t g_pixels = 0;
 };
-static SplatWs g_splat_ws[kMaxDevices];
-
-static int splat_ws(size_t n_blocks, size_t list_pixels, SplatWs** out) {
+static int splat_ws(hipStream_t s, size_t n_blocks, size_t list_pixels, SplatWs** out) {
     int dev = 0;
     VFI_CHECK_HIP(hipGetDevice(&dev));
     VFI_REQUIRE(dev >= 0 && dev < kMaxDevices, "splat: device index %d out of range", dev);
-    SplatWs& w = g_splat_ws[dev];
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, SplatWs> table;      // (node addresses are stable: the caller keeps the pointer)
+    std::lock_guard<std::mutex> lock(mu);
+    SplatWs& w = table[{dev, s}];
     if (!w.ctl) {
         VFI_CHECK_HIP(hipMalloc((void**)&w.ctl, sizeof(SplatCtl)));
         VFI_CHECK_HIP(hipMalloc((void**)&w.ovf, sizeof(uint2) * (size_t)SPLAT_OVF_CAP));
@@ -538,7 +543,7 @@ int softsplat_sum_launch(const float* in, const float* flow, float* out, int N, 
     const bool c4 = C == 4 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
     const size_t pixels = (size_t)N * H * W;
     VFI_REQUIRE(pixels < (1ull << 32), "softsplat: %zu pixels do not fit the 32-bit source index", pixels);
-    if (int rc = splat_ws(n_tiles, g_splat_mode == 0 && !c4 ? pixels : 0, &ws)) return rc;
+    if (int rc = splat_ws(s, n_tiles, g_splat_mode == 0 && !c4 ? pixels : 0, &ws)) return rc;
     VFI_CHECK_HIP(hipMemsetAsync(ws->ctl, 0, sizeof(SplatCtl), s));
     {
         TraceScope ts("splat_blockrange", s);

@@ -29,6 +29,9 @@
 // window follows max |tf| (any displacement), a cell with more than 6 sources is gathered by scanning the strip — slow, exact, rare.
 #include <atomic>
 
+#include <map>
+#include <mutex>
+
 #include "vfi_common.h"
 #include "m2m_warp.h"
 
@@ -710,21 +713,23 @@ __global__ void m2m_warp_img4_kernel(const float4* __restrict__ img4, const floa
     o[0] = r0, o[1] = r1, o[2] = r2;
 }
 
-// per-device workspace of the generic splat (tile ranges, max |f| per image); grows, never shrinks
+// workspace of the generic splat (tile ranges, max |f| per image) per (device, stream); grows, never shrinks
 struct Splat4Ws {
     float4* ranges = nullptr;
     size_t n_ranges = 0;
     unsigned* smax = nullptr;
     size_t n_smax = 0;
 };
-static Splat4Ws g_splat4_ws[kMaxDevices];
 
 int softsplat4_launch(const float* in, const float* flow, float* out, int N, int H, int W, hipStream_t s) {
     VFI_REQUIRE((long)H * W < (1L << 30), "softsplat: %d x %d pixels do not fit the 32-bit indices", H, W);
     int dev = 0;
     VFI_CHECK_HIP(hipGetDevice(&dev));
     VFI_REQUIRE(dev >= 0 && dev < kMaxDevices, "softsplat: device index %d out of range", dev);
-    Splat4Ws& w = g_splat4_ws[dev];
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, Splat4Ws> table;
+    std::lock_guard<std::mutex> lock(mu);
+    Splat4Ws& w = table[{dev, s}];
     const int tiles_x = cdiv(W, RT), tiles_y = cdiv(H, RT);
     const size_t nt = (size_t)N * tiles_x * tiles_y;
     if (w.n_ranges < nt) {

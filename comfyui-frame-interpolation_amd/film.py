@@ -25,6 +25,7 @@ import torch
 
 from . import _lib
 from .ckpt import cached_engine, load_file_from_github_release
+from .lanes import LaneSet, lanes_for, lanes_of
 from .dist import all_gather_frames, world
 from .film_spec import check_state_dict, film_shapes
 from .schedule import InterpolationStateList, shard_tasks
@@ -128,7 +129,10 @@ class FILM_VFI:
             multiplier: typing.SupportsInt = 2, optional_interpolation_states: InterpolationStateList = None, **kwargs):
         model_path = load_file_from_github_release(MODEL_TYPE, ckpt_name)
         # (the reference re-loads the TorchScript file on every call, film/__init__.py:74; see ckpt.cached_engine)
-        engine, cached = cached_engine(MODEL_TYPE, model_path, lambda: FilmEngine(_load_state_dict(model_path)))
+        def build():
+            sd = _load_state_dict(model_path)
+            return LaneSet(lambda: FilmEngine(sd), lanes_for("film"))
+        engine, cached = cached_engine(MODEL_TYPE, model_path, build)
         try:
             frames = frames[..., :3]
             n = len(frames)
@@ -165,31 +169,43 @@ class FILM_VFI:
             mine = pairs[lo:hi]
             order = sorted({f for i in mine for f in (i, i + 1)})       # every needed frame is uploaded once, ahead of use
             item_of = {f: k for k, f in enumerate(order)}
-            up = Uploader(frames, order, dev, torch.cuda.current_stream(dev), depth=min(4, len(order)) or 1)
-            keep, pos, held, released = [], 0, {}, 0
+            # pair lanes (lanes.py): kept pair j runs on lane j % n_lanes = its own engine on its own stream (the bisection inside a
+            # pair stays sequential on that stream); `main` only carries the bookkeeping events
+            main = torch.cuda.current_stream(dev)
+            lane, n_lanes = lanes_of(engine, len(mine))
+            up = Uploader(frames, order, dev, main, depth=min(max(4, n_lanes + 2), len(order)) or 1)
+            keep, pos, released, pending = [], 0, 0, []
             try:
                 for j in range(lo, hi):
                     i = pairs[j]
-                    for f in (i, i + 1):
-                        if f not in held:
-                            held[f] = up.get(item_of[f])
-                    res = {0: held[i], multipliers[i]: held[i + 1]}
-                    for (l, r, new) in film_schedule(multipliers[i] - 1):
-                        res[new] = engine.forward(res[l], res[r], clamp=True)
-                    for n_k, k in enumerate(sorted(res)[:-1]):
-                        if ws > 1:
-                            local[pos] = res[k]      # res[0] is the uploaded original: bit-exact round trip
-                        elif k == 0:
-                            wr.put_host(row0[j] + n_k, frames[i])
-                        else:
-                            wr.put_dev(row0[j] + n_k, res[k])
-                            keep.append(res[k])      # alive until the copy-back has read it
-                        pos += 1
-                    while released < item_of[i + 1]:     # frames before i+1 are not needed again (pairs ascend)
-                        up.release(released)
-                        held.pop(order[released], None)
-                        released += 1
+                    eng, st = lane((j - lo) % n_lanes)
+                    res = {0: up.get(item_of[i], st), multipliers[i]: up.get(item_of[i + 1], st)}
+                    with torch.cuda.stream(st):
+                        for (l, r, new) in film_schedule(multipliers[i] - 1):
+                            res[new] = eng.forward(res[l], res[r], clamp=True)
+                        for n_k, k in enumerate(sorted(res)[:-1]):
+                            if ws > 1:
+                                local[pos] = res[k]      # res[0] is the uploaded original: bit-exact round trip
+                            elif k == 0:
+                                wr.put_host(row0[j] + n_k, frames[i])
+                            else:
+                                wr.put_dev(row0[j] + n_k, res[k], st)
+                                keep.append(res[k])      # alive until the copy-back has read it
+                            pos += 1
+                        if n_lanes > 1:
+                            done = torch.cuda.Event()
+                            done.record(st)
+                            pending.append(done)
+                    if released < item_of[i + 1]:        # frames before i+1 are not needed again (pairs ascend)
+                        for ev in pending:               # ... once every lane that read them is through
+                            main.wait_event(ev)
+                        pending = []
+                        while released < item_of[i + 1]:
+                            up.release(released)
+                            released += 1
             finally:
+                for ev in pending:
+                    main.wait_event(ev)
                 up.close()
             if ws > 1:
                 allf = all_gather_frames(local, counts)

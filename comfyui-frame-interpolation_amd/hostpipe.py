@@ -280,10 +280,12 @@ class Uploader:
         """Has item i been staged and its H2D copy been enqueued?  (Non-blocking: frames packed ahead of their launch.)"""
         return self.futs[i].done()
 
-    def get(self, i):
+    def get(self, i, stream=None):
+        """Device tensor of item i, valid on ``stream`` (default: the main stream).  A second reader on another stream (pair lanes:
+        frame p+1 of pair p is frame p of pair p+1) calls get() again with its own stream."""
         with _T("main.wait_upload"):
             ev = self.futs[i].result()
-        self.main.wait_event(ev)
+        (stream if stream is not None else self.main).wait_event(ev)
         return self.dev[i % self.depth]
 
     def release(self, i):
@@ -453,10 +455,11 @@ class OutputWriter:
     def put_host(self, row, frame):
         self.futs += copy_rows_async(self.out, [row], frame[None], [0])
 
-    def put_dev(self, row, dev_frame):
-        """dev_frame [H,W,3] must stay untouched until the returned event has fired (the D2H read it)."""
+    def put_dev(self, row, dev_frame, stream=None):
+        """dev_frame [H,W,3] (written on ``stream``, default the main stream) must stay untouched until the returned event has fired
+        (the D2H read it)."""
         ready = torch.cuda.Event()
-        ready.record(self.main)
+        ready.record(stream if stream is not None else self.main)
         return self.down.push(ready, dev_frame[None], [self.out[row]])
 
     def finish(self):

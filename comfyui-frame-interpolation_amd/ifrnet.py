@@ -28,6 +28,8 @@ import torch
 
 from . import _lib
 from .ckpt import cached_engine, load_file_from_github_release
+from .lanes import LaneSet, lanes_for
+from .lanes import configure as configure_lanes
 from .ifrnet_spec import CKPT_NAMES, CONFIG, check_state_dict, decoder_io, kind_of
 from .schedule import InterpolationStateList, generic_output_plan
 
@@ -327,9 +329,13 @@ class IFRNet_VFI:
         model_path = load_file_from_github_release(MODEL_TYPE, ckpt_name)
         kind = kind_of(ckpt_name)
         # (the reference rebuilds the model on every call, ifrnet/__init__.py:42-45; see ckpt.cached_engine)
-        engine, cached = cached_engine(MODEL_TYPE + kind, model_path, lambda: IFRNetEngine(_load_state_dict(model_path), kind))
+        def build():
+            sd = _load_state_dict(model_path)
+            return LaneSet(lambda: IFRNetEngine(sd, kind), lanes_for("ifrnet"))
+        engine, cached = cached_engine(MODEL_TYPE + kind, model_path, build)
         try:
-            engine.embt = float(scale_factor)    # positional mis-binding of the reference's call, see the module docstring
+            embt = float(scale_factor)           # positional mis-binding of the reference's call, see the module docstring
+            configure_lanes(engine, lambda e: setattr(e, "embt", embt))
             plan, tasks = generic_output_plan(len(frames), multiplier, optional_interpolation_states)
             return (run_plan(engine, frames, plan, tasks, name="IFRNet VFI"),)
         finally:

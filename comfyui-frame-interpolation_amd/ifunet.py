@@ -371,8 +371,11 @@ class IFUnet_VFI:
 
         assert len(frames) >= 2, f"VFI model IFUNet requires at least 2 frames to work with, only found {frames.shape[0]}."
         model_path = load_file_from_github_release(MODEL_TYPE, ckpt_name)
-        engine = IFUNetEngine(torch.load(model_path, map_location="cpu", weights_only=False))
-        engine.scale, engine.ensemble = float(scale_factor), bool(ensemble)
+        from .lanes import LaneSet, lanes_for
+        sd = torch.load(model_path, map_location="cpu", weights_only=False)
+        engine = LaneSet(lambda: IFUNetEngine(sd), lanes_for("ifunet"))
+        sc, ens = float(scale_factor), bool(ensemble)
+        engine.configure(lambda e: (setattr(e, "scale", sc), setattr(e, "ensemble", ens)))
         try:
             plan, tasks = generic_output_plan(len(frames), multiplier, optional_interpolation_states)
             return (run_plan(engine, frames, plan, tasks, name="IFUnet VFI"),)

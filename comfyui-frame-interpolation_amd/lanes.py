@@ -1,0 +1,85 @@
+"""Pair lanes: several frame pairs of a clip in flight on one GPU, each on its own HIP stream with its own engine.
+
+The generic node loop of the reference (vfi_utils.py:149-389, film/__init__.py:63-113) walks the clip pair by pair; the pairs are
+independent.  One pair of M2M / FILM / GMFSS / IFUNet / IFRNet at 1080p is a chain of 100-1500 launches, many of them on coarse
+pyramid levels that fill a fraction of the 256 compute units (4-60 workgroups) or sit in their own pipeline latency.  A second
+and third pair on other streams fill those holes: same kernels, same launch geometry, bit-identical frames, 1.06x (FILM) to
+1.19x (IFUNet, M2M) the frames/s of one stream (tools/overlap_probe.py, profiles/r06_pair_lanes.txt).  The price is one
+workspace per lane — sized for 288 GB of HBM, not for 24.
+
+Everything a lane shares with its siblings is read-only (packed weights are per engine; the library's scratch — split-K sums,
+attention partials, splat lists — is keyed by (device, stream)).
+"""
+import os
+
+import torch
+
+# lanes per model type (VFI_PAIR_LANES=<n> overrides all of them; 1 = the single-stream loop)
+DEFAULT_LANES = {"m2m": 3, "film": 2, "gmfss": 3, "ifunet": 3, "ifrnet": 2}
+
+
+def lanes_for(model):
+    env = os.environ.get("VFI_PAIR_LANES")
+    if env:
+        return max(1, int(env))
+    return DEFAULT_LANES.get(model, 1)
+
+
+class LaneSet:
+    """K engines built from one checkpoint by ``build()``; engine i runs on stream i.  Engines beyond the first are built at first
+    use (a two-frame clip never pays for them).  Looks like an engine to the node code that owns it: ``device``, ``close()``,
+    ``release_workspace()``; attributes set through ``configure`` reach every lane."""
+
+    def __init__(self, build, k):
+        self._build, self.k = build, max(1, int(k))
+        self.engines = [build()]
+        self.device = self.engines[0].device
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)      # whatever the constructor queued (fills, uploads) is done before another stream reads it
+        self._streams = []
+        self._setup = None
+
+    def configure(self, fn):
+        """fn(engine): per-call settings of the node (IFRNet's embt, IFUNet's scale / ensemble) on every lane, present and future."""
+        self._setup = fn
+        for e in self.engines:
+            fn(e)
+
+    def lane(self, i):
+        """-> (engine, stream) of lane i < k"""
+        while len(self._streams) <= i:
+            self._streams.append(torch.cuda.Stream(self.device))
+        while len(self.engines) <= i:
+            with torch.cuda.stream(self._streams[len(self.engines)]):      # the constructor's device work is ordered with the lane's first pair
+                e = self._build()
+                if self._setup is not None:
+                    self._setup(e)
+            self.engines.append(e)
+        return self.engines[i], self._streams[i]
+
+    def release_workspace(self):
+        for e in self.engines:
+            e.release_workspace()
+
+    def close(self):
+        for e in self.engines:
+            e.close()
+        self.engines = self.engines[:0]
+
+
+def configure(engine, fn):
+    """fn(engine) on a plain engine, on every lane of a LaneSet"""
+    if isinstance(engine, LaneSet):
+        engine.configure(fn)
+    else:
+        fn(engine)
+
+
+def lanes_of(engine, n_pairs):
+    """(lane getter, lane count) for a node loop over n_pairs pairs: a LaneSet spreads them, a plain engine is one lane on the
+    current stream."""
+    if isinstance(engine, LaneSet) and engine.k > 1 and n_pairs > 1:
+        return engine.lane, min(engine.k, n_pairs)
+    eng = engine.engines[0] if isinstance(engine, LaneSet) else engine
+    main = torch.cuda.current_stream(eng.device) if eng.device.type == "cuda" else None
+    return (lambda i: (eng, main)), 1

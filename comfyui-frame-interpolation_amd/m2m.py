@@ -27,6 +27,7 @@ import torch
 
 from . import _lib
 from .ckpt import cached_engine, load_file_from_github_release
+from .lanes import LaneSet, lanes_for
 from .dist import all_gather_frames, world
 from .m2m_spec import check_state_dict, m2m_shapes
 from .schedule import InterpolationStateList, generic_output_plan, shard_tasks
@@ -155,6 +156,7 @@ def run_plan(engine, frames, plan, tasks, name="M2M VFI"):
         return out
 
     from .hostpipe import OutputWriter, Uploader
+    from .lanes import lanes_of
     main = torch.cuda.current_stream(dev)
     wr = OutputWriter(len(plan), H, W, dev)
     new_row = {}
@@ -164,34 +166,50 @@ def run_plan(engine, frames, plan, tasks, name="M2M VFI"):
         else:
             new_row[idx] = i
     mine = tasks[lo:hi]
+    # pair lanes (lanes.py): pair j runs on lane j % n_lanes = its own engine on its own stream; `main` only carries the bookkeeping
+    # events (a frame's staging slot is released on main after main has waited for every lane that read it)
+    lane, n_lanes = lanes_of(engine, len(mine))
     order = sorted({f for pair, _ in mine for f in (pair, pair + 1)})
-    up = Uploader(frames, order, dev, main, depth=min(4, len(order)) or 1)
+    up = Uploader(frames, order, dev, main, depth=min(max(4, n_lanes + 2), len(order)) or 1)
     item_of = {f: i for i, f in enumerate(order)}
     local = torch.empty((counts[rank], H, W, 3), dtype=torch.float32, device=dev)
     first_new = sum(counts[:rank])
+    pending = []          # completion events of lanes main has not waited for yet
     try:
-        pos, held, released = 0, {}, 0
-        for pair, ts in mine:
-            for f in (pair, pair + 1):
-                if f not in held:
-                    held[f] = up.get(item_of[f])
-            engine.prepare(held[pair], held[pair + 1])
-            for t in ts:
-                engine.render(t, local[pos])
-                if ws == 1:
-                    wr.put_dev(new_row[first_new + pos], local[pos])
-                pos += 1
+        pos, released = 0, 0
+        for j, (pair, ts) in enumerate(mine):
+            eng, st = lane(j % n_lanes)
+            f0, f1 = up.get(item_of[pair], st), up.get(item_of[pair + 1], st)
+            with torch.cuda.stream(st):
+                eng.prepare(f0, f1)
+                for t in ts:
+                    eng.render(t, local[pos])
+                    if ws == 1:
+                        wr.put_dev(new_row[first_new + pos], local[pos], st)
+                    pos += 1
+                if n_lanes > 1:
+                    done = torch.cuda.Event()
+                    done.record(st)
+                    pending.append(done)
             # Release only after the LAST render of the pair: some engines' prepare() keeps references to the ring-slot
             # tensors and render() re-reads them (IFRNet, IFUNet), so the `consumed` event must follow those reads.
-            while released < item_of[pair + 1]:       # frames before pair+1 are never needed again (tasks ascend)
-                up.release(released)
-                held.pop(order[released], None)
-                released += 1
+            if released < item_of[pair + 1]:          # frames before pair+1 are never needed again (tasks ascend)
+                for ev in pending:
+                    main.wait_event(ev)
+                pending = []
+                while released < item_of[pair + 1]:
+                    up.release(released)
+                    released += 1
+        for ev in pending:
+            main.wait_event(ev)
+        pending = []
         if ws > 1:
             new = all_gather_frames(local, counts)
             for k in range(new.shape[0]):
                 wr.put_dev(new_row[k], new[k])
     finally:
+        for ev in pending:      # (an error path: the staging rings go back with a `busy` event recorded on main)
+            main.wait_event(ev)
         up.close()
     return wr.finish()
 
@@ -218,7 +236,10 @@ class M2M_VFI:
         assert len(frames) >= 2, f"VFI model M2M requires at least 2 frames to work with, only found {frames.shape[0]}."
         model_path = load_file_from_github_release(MODEL_TYPE, ckpt_name)
         # (the reference rebuilds M2M_PWC on every call, m2m/__init__.py:43-46; see ckpt.cached_engine)
-        engine, cached = cached_engine(MODEL_TYPE, model_path, lambda: M2MEngine(_load_state_dict(model_path)))
+        def build():
+            sd = _load_state_dict(model_path)
+            return LaneSet(lambda: M2MEngine(sd), lanes_for("m2m"))
+        engine, cached = cached_engine(MODEL_TYPE, model_path, build)
         try:
             plan, tasks = generic_output_plan(len(frames), multiplier, optional_interpolation_states)
             return (run_plan(engine, frames, plan, tasks),)

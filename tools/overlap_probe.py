@@ -1,0 +1,96 @@
+"""Pairs of a clip are independent: throughput of K engines on K HIP streams (round robin over the pairs) vs one engine on one
+stream, 1080p, 2x.  usage: overlap_probe.py [m2m|film|gmfss|ifunet|ifrnet ...] [--k 1,2,3]"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+ge.build()
+ge.load_package()
+from cfi_amd import synth  # noqa: E402
+
+
+def make(model):
+    if model == "m2m":
+        from cfi_amd.m2m import M2MEngine
+        sd = synth.m2m_synth_state_dict(1234)
+        return lambda: M2MEngine(sd)
+    if model == "film":
+        from cfi_amd.film import FilmEngine
+        sd = synth.film_synth_state_dict(1234)
+        return lambda: FilmEngine(sd)
+    if model == "gmfss":
+        from cfi_amd.gmfss import GMFSSEngine
+        sds = synth.gmfss_coherent_state_dicts(3, "union")
+        return lambda: GMFSSEngine(sds)
+    if model == "ifunet":
+        from cfi_amd.ifunet import IFUNetEngine
+        sd = synth.ifunet_synth_state_dict(1234)
+        return lambda: IFUNetEngine(sd)
+    if model == "ifrnet":
+        from cfi_amd.ifrnet import IFRNetEngine
+        sd = synth.ifrnet_synth_state_dict("L", 1234)
+        return lambda: IFRNetEngine(sd, "L")
+    raise SystemExit("unknown model " + model)
+
+
+def step(model, eng, x0, x1, out):
+    if model == "film":
+        return eng.forward(x0, x1)
+    eng.prepare(x0, x1)
+    if model == "ifrnet":
+        eng.render(1.0, out)
+    else:
+        eng.render(0.5, out)
+    return out
+
+
+if __name__ == "__main__":
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    ks = [1, 2, 3]
+    if "--k" in sys.argv:
+        ks = [int(v) for v in sys.argv[sys.argv.index("--k") + 1].split(",")]
+        args = [a for a in args if not a[0].isdigit()]
+    H, W = 1080, 1920
+    for model in args or ["m2m"]:
+        fr = synth.texture_frames(2, H, W, seed=5) if model == "gmfss" else synth.smooth_frames(2, H, W, seed=2, shift=4.0)
+        x0, x1 = fr[0].cuda().contiguous(), fr[1].cuda().contiguous()
+        factory = make(model)
+        base = None
+        for K in ks:
+            engs = [factory() for _ in range(K)]
+            streams = [torch.cuda.Stream() for _ in range(K)]
+            outs = [torch.empty(H, W, 3, device="cuda") for _ in range(K)]
+            res = [None] * K
+            for k in range(K):
+                with torch.cuda.stream(streams[k]):
+                    for _ in range(2):
+                        res[k] = step(model, engs[k], x0, x1, outs[k])
+            torch.cuda.synchronize()
+            n = 12 if model in ("film", "gmfss") else 24
+            best = 1e9
+            for rep in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(n):
+                    k = i % K
+                    with torch.cuda.stream(streams[k]):
+                        res[k] = step(model, engs[k], x0, x1, outs[k])
+                t_issue = time.perf_counter() - t0
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / n
+                best = min(best, dt)
+            same = all(torch.equal(res[0], r) for r in res[1:])
+            base = base or best
+            print(f"{model}: K = {K}: {best * 1e3:.2f} ms per pair -> {1 / best:.1f} frames/s at 2x ({base / best:.3f}x; host issue {t_issue / n * 1e3:.2f} ms per pair; "
+                  f"identical outputs: {same}; device memory {torch.cuda.memory_allocated() / 2**30:.1f} GiB)", flush=True)
+            for e in engs:
+                if hasattr(e, "close"):
+                    e.close()
+            del engs, outs, res
+            torch.cuda.empty_cache()
