@@ -224,6 +224,43 @@ def leg_parity(got, want_fn, what, keep=None):
         return {"ok": False, "error": f"{type(e).__name__}: {e}", "what": what}
 
 
+def pair_lanes_rate(dev, build, step, model, n_pairs=12, first=None):
+    """Sustained rate of the node's pair loop with its pair lanes (comfyui-frame-interpolation_amd/lanes.py): K engines on K HIP streams, the
+    pairs of a clip round robin over them — what the node classes do for a clip of more than one pair.  step(engine, out_k) issues one
+    pair (everything the node runs per pair at multiplier 2) on the current stream.  -> {"lanes", "ms_per_pair", "frames_per_s_2x",
+    "vs_one_stream"} (never raises)."""
+    try:
+        from cfi_amd.lanes import LaneSet, lanes_for
+
+        k = lanes_for(model)
+        lanes = LaneSet(build, k, first=first)      # the caller's engine is lane 0 (and stays the caller's)
+        try:
+            pairs = [lanes.lane(i) for i in range(k)]
+
+            def run(n, width):
+                for i in range(n):
+                    eng, st = pairs[i % width]
+                    with torch.cuda.stream(st):
+                        step(eng, i % width)
+
+            rates = {}
+            for width in (1, k):
+                run(2 * width, width)
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                run(n_pairs, width)
+                torch.cuda.synchronize(dev)
+                rates[width] = (time.perf_counter() - t0) / n_pairs
+            return {"lanes": k, "ms_per_pair": round(rates[k] * 1e3, 3), "frames_per_s_2x": round(1 / rates[k], 1),
+                    "one_stream_ms_per_pair": round(rates[1] * 1e3, 3), "vs_one_stream": round(rates[1] / rates[k], 3),
+                    "what": "%d pairs round robin over %d engines on %d HIP streams (the node loop for clips of > 1 pair; frames bit-identical to one "
+                            "stream: tests/test_gpu_pair_lanes.py)" % (n_pairs, k, k)}
+        finally:
+            lanes.close()
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def other_paths(dev, H, W, parity=True):
     """FILM and M2M, device-resident, ms per interpolated frame (BASELINE.json configs[2] / configs[4]); each with a `parity` object:
     the frame of the timed call against the oracle (film_oracle / m2m_model_oracle, bit-exact vs the reference in the build container)
@@ -257,6 +294,7 @@ def other_paths(dev, H, W, parity=True):
         got = eng.forward(x0, x1).cpu()
         out["film_2x"]["parity"] = leg_parity(got, lambda: film_oracle.film_forward(film_sd, xn[0:1], xn[1:2])[0].permute(1, 2, 0),
                                               f"the timed call's frame (smooth pair seed 2, {H}x{W}, t = 0.5) vs oracle.film_oracle.film_forward on the same host tensors")
+    out["film_2x"]["pair_lanes"] = pair_lanes_rate(dev, lambda: FilmEngine(film_sd), lambda e, k: e.forward(x0, x1), "film", n_pairs=6, first=eng)
     eng.close()
     m2m_sd = synth.m2m_synth_state_dict(1234)
     eng = M2MEngine(m2m_sd)
@@ -264,6 +302,13 @@ def other_paths(dev, H, W, parity=True):
     tr = timed(lambda: eng.render(0.5), 10)
     out["m2m"] = {"prepare_ms_per_pair": round(tp * 1e3, 3), "render_ms_per_frame": round(tr * 1e3, 3),
                   "frames_per_s_2x": round(1 / (tp + tr), 1), "frames_per_s_8x": round(7 / (tp + 7 * tr), 1)}
+    m2m_outs = {}
+
+    def m2m_pair(e, k):
+        e.prepare(x0, x1)
+        m2m_outs[k] = e.render(0.5, m2m_outs.get(k))
+
+    out["m2m"]["pair_lanes"] = pair_lanes_rate(dev, lambda: M2MEngine(m2m_sd), m2m_pair, "m2m", n_pairs=24, first=eng)
     if parity:
         from oracle import m2m_model_oracle as mo
 
@@ -418,6 +463,15 @@ def other_nodes(dev, H, W):
                                       "frames_per_s_2x": round(1 / (tp + tr), 1), "conv_gflop_direct_form": {"prepare": round(fp / 1e9, 1), "render": round(frn / 1e9, 1)},
                                       "conv_tflops_direct_form": round((fp + frn) / (tp + tr) / 1e12, 1),
                                       "note": "convolution FLOP only (GMFlow's attention matmuls and the splats are not counted)"}
+        gm_sds, gm_outs = synth.gmfss_coherent_state_dicts(3, "union"), {}
+
+        def gm_pair(e, k):
+            if k not in gm_outs:
+                gm_outs[k] = torch.empty(H, W, 3, device=dev)
+            e.prepare(g0, g1)
+            e.render(0.5, gm_outs[k])
+
+        res["gmfss_fortuna_union"]["pair_lanes"] = pair_lanes_rate(dev, lambda: GMFSSEngine(gm_sds), gm_pair, "gmfss", n_pairs=9, first=eng)
         eng.close()
         del eng
     except Exception as e:  # noqa: BLE001
@@ -430,6 +484,14 @@ def other_nodes(dev, H, W):
         f = counted(eng, lambda: eng.forward(x0, x1, 0.5, out, scale=1.0, ensemble=True))
         res["ifunet"] = {"ms_per_frame": round(t * 1e3, 2), "frames_per_s": round(1 / t, 1), "ensemble": True, "conv_gflop_direct_form": round(f / 1e9, 1),
                          "conv_tflops_direct_form": round(f / t / 1e12, 1)}
+        iu_sd, iu_outs = synth.ifunet_synth_state_dict(1234), {}
+
+        def iu_pair(e, k):
+            if k not in iu_outs:
+                iu_outs[k] = torch.empty(H, W, 3, device=dev)
+            e.forward(x0, x1, 0.5, iu_outs[k], scale=1.0, ensemble=True)
+
+        res["ifunet"]["pair_lanes"] = pair_lanes_rate(dev, lambda: IFUNetEngine(iu_sd), iu_pair, "ifunet", n_pairs=9, first=eng)
         eng.close()
         del eng
     except Exception as e:  # noqa: BLE001
@@ -442,6 +504,14 @@ def other_nodes(dev, H, W):
         t = timed(lambda: eng.forward([x0], [x1], 0.5, 1.0, o4), 5)      # the node's default call (multiplier 2): working resolution 0.5, embedding 1.0
         res["ifrnet_L"] = {"ms_per_frame": round(t * 1e3, 2), "frames_per_s": round(1 / t, 1), "call": "node default (multiplier 2): working resolution x0.5",
                            "conv_tflops_direct_form": round(0.80 * (H * W) / (1080 * 1920) / t, 1), "flop_per_frame": "0.80 TFLOP @1080p (docs/design/ifrnet.md)"}
+        ir_sd, ir_outs = synth.ifrnet_synth_state_dict("L", 1234), {}
+
+        def ir_pair(e, k):
+            if k not in ir_outs:
+                ir_outs[k] = torch.empty(1, H, W, 3, device=dev)
+            e.forward([x0], [x1], 0.5, 1.0, ir_outs[k])
+
+        res["ifrnet_L"]["pair_lanes"] = pair_lanes_rate(dev, lambda: IFRNetEngine(ir_sd, "L"), ir_pair, "ifrnet", n_pairs=12, first=eng)
         eng.close()
         del eng
     except Exception as e:  # noqa: BLE001

@@ -204,6 +204,7 @@ SUPPORTED_ENV = {
     "VFI_DEVICES":        "devices one node call may use: 'current' (default) | 'all' | '0,1,2,3' (multidev.py)",
     "VFI_ALLGATHER":      "device-side all-gather of new frames: 'rccl' (default) | 'direct' (csrc/comm.hip)",
     "VFI_MODEL_CACHE":    "'0': do not keep engines between node calls (ckpt.py)",
+    "VFI_PAIR_LANES":     "frame pairs in flight per GPU in the M2M / FILM / GMFSS / IFUNet / IFRNet nodes, one engine + HIP stream each (lanes.py; default per model 2-3, 1 = one stream; frames are bit-identical)",
     "VFI_RIFE_MIN_BATCH": "smallest tasks-per-launch the RIFE node uses whatever its batch_size widget says (default 8)",
     "VFI_HOST_WORKERS":   "host copy worker threads 'upload,download,...' (hostpipe.py)",
     "VFI_HOST_THP":       "'0': no transparent-huge-page advice on the pinned staging ring (hostpipe.py)",

@@ -30,9 +30,11 @@ class LaneSet:
     use (a two-frame clip never pays for them).  Looks like an engine to the node code that owns it: ``device``, ``close()``,
     ``release_workspace()``; attributes set through ``configure`` reach every lane."""
 
-    def __init__(self, build, k):
+    def __init__(self, build, k, first=None):
+        """first: an engine the caller already owns becomes lane 0 (close() leaves it alone)"""
         self._build, self.k = build, max(1, int(k))
-        self.engines = [build()]
+        self._borrowed = first is not None
+        self.engines = [first if first is not None else build()]
         self.device = self.engines[0].device
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)      # whatever the constructor queued (fills, uploads) is done before another stream reads it
@@ -62,7 +64,7 @@ class LaneSet:
             e.release_workspace()
 
     def close(self):
-        for e in self.engines:
+        for e in self.engines[1 if self._borrowed else 0:]:
             e.close()
         self.engines = self.engines[:0]
 

@@ -141,6 +141,7 @@ def run_plan(engine, frames, plan, tasks, name="M2M VFI"):
     lo, hi = shard_tasks(tasks, rank, ws)
     counts = [sum(len(ts) for _, ts in tasks[slice(*shard_tasks(tasks, r, ws))]) for r in range(ws)]
     if dev.type != "cuda":  # stand-in engines of the CPU tests: same control flow without the device pipeline
+        engine = engine.engines[0] if isinstance(engine, LaneSet) else engine
         local = torch.empty((counts[rank], H, W, 3), dtype=torch.float32, device=dev)
         pos = 0
         for pair, ts in tasks[lo:hi]:

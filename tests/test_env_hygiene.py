@@ -19,7 +19,7 @@ POISON = {"VFI_WINO_ABLATE": "4", "VFI_WINO16_ABL": "63", "VFI_WINO_2WAVE": "1",
 
 
 def test_supported_set_is_small_and_documented():
-    assert len(_lib.SUPPORTED_ENV) <= 8
+    assert len(_lib.SUPPORTED_ENV) <= 9      # r6: + VFI_PAIR_LANES (a resource knob: frames are bit-identical for any value)
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     for name in _lib.SUPPORTED_ENV:
         assert name in doc, f"{name} is not documented in INTEGRATION.md"
