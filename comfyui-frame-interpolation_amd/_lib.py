@@ -150,6 +150,8 @@ PROTOTYPES = {
     "vfi_rife_debug_read": (C.c_int64, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64]),
     "vfi_rife_work": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vfi_memcpy_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "vfi_stream_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "vfi_stream_destroy": (C.c_int, [C.c_void_p]),
     "vfi_set_reserved_cus": (C.c_int, [C.c_int]),
     "vfi_get_reserved_cus": (C.c_int, []),
     "vfi_film_create": (C.c_void_p, [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int]),
@@ -277,6 +279,35 @@ def stream_ptr():
     import torch
 
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_own_streams = {}      # device index -> idle streams made by vfi_stream_create (kept for the life of the process, handed out exclusively)
+
+
+class OwnStream:
+    """A HIP stream made by the library for ONE owner at a time (a pair lane, an engine's graph capture), as a torch stream object.
+    torch.cuda.Stream() draws from a shared pool of 32 per device, round robin: two live engines could be handed the same stream —
+    and with it the same (device, stream)-keyed library scratch, whose addresses their captured graphs have baked in."""
+
+    def __init__(self, device):
+        import torch
+
+        self.index = torch.device(device).index or 0
+        idle = _own_streams.setdefault(self.index, [])
+        if idle:
+            self.ptr = idle.pop()
+        else:
+            out = C.c_void_p()
+            with torch.cuda.device(self.index):
+                check(load().vfi_stream_create(C.byref(out)), "vfi_stream_create")
+            self.ptr = out.value
+        self.stream = torch.cuda.ExternalStream(self.ptr, device=torch.device("cuda", self.index))
+
+    def release(self):
+        """back to the idle list (after the owner has drained it)"""
+        if self.ptr is not None:
+            _own_streams.setdefault(self.index, []).append(self.ptr)
+            self.ptr = self.stream = None
 
 
 def clock_probe_names():

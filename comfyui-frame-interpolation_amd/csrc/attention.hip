@@ -327,7 +327,8 @@ static int attention_workspace(int dev, hipStream_t s, size_t floats, float** ou
     std::lock_guard<std::mutex> lock(mu);
     Ws& w = table[{dev, s}];
     if (w.n < floats) {
-        if (w.p) VFI_CHECK_HIP(hipFree(w.p));
+        // the outgrown block is RETIRED, not freed: a captured HIP graph of the stream's owner may have its address baked in (r6), and
+        // hipFree would drain the device under the other pair lanes
         w.p = nullptr, w.n = 0;
         VFI_CHECK_HIP(hipMalloc((void**)&w.p, floats * sizeof(float)));
         w.n = floats;

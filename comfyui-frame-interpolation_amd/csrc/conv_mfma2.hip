@@ -497,14 +497,14 @@ static int split_workspace(int dev, hipStream_t s, size_t floats, int cout_p, fl
     std::lock_guard<std::mutex> lock(mu);
     Ws& w = table[{dev, s}];
     if (w.n < floats) {
-        if (w.p) VFI_CHECK_HIP(hipFree(w.p));      // (synchronises the device; only on growth)
+        // the outgrown block is RETIRED, not freed: a captured HIP graph of the stream's owner may have its address baked in (r6), and
+        // hipFree would drain the device under the other pair lanes (sizes grow a handful of times in a process)
         w.p = nullptr, w.n = 0;
         VFI_CHECK_HIP(hipMalloc((void**)&w.p, floats * sizeof(float)));
         w.n = floats;
     }
     if (w.zn < cout_p) {
-        if (w.z) VFI_CHECK_HIP(hipFree(w.z));
-        w.z = nullptr, w.zn = 0;
+        w.z = nullptr, w.zn = 0;      // (retired likewise)
         const int n = cout_p < 4096 ? 4096 : cout_p;
         VFI_CHECK_HIP(hipMalloc((void**)&w.z, n * sizeof(float)));
         // on the launch's own stream: a NULL-stream memset is not ordered against a non-blocking stream, and under load (other pair

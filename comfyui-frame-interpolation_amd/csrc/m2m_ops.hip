@@ -509,13 +509,11 @@ static int splat_ws(hipStream_t s, size_t n_blocks, size_t list_pixels, SplatWs*
         VFI_CHECK_HIP(hipMalloc((void**)&w.ovf, sizeof(uint2) * (size_t)SPLAT_OVF_CAP));
     }
     if (w.brange_n < n_blocks) {
-        if (w.brange) VFI_CHECK_HIP(hipFree(w.brange));    // (synchronises; only on growth)
+        // outgrown blocks are RETIRED, not freed: a captured HIP graph of the stream's owner may have their addresses baked in (r6)
         VFI_CHECK_HIP(hipMalloc((void**)&w.brange, sizeof(float4) * n_blocks));
         w.brange_n = n_blocks;
     }
     if (w.g_pixels < list_pixels) {
-        if (w.glist) VFI_CHECK_HIP(hipFree(w.glist));
-        if (w.gcount) VFI_CHECK_HIP(hipFree(w.gcount));
         w.glist = nullptr, w.gcount = nullptr, w.g_pixels = 0;
         VFI_CHECK_HIP(hipMalloc((void**)&w.glist, sizeof(uint2) * SPLAT_GCAP * list_pixels));     // 256 B per pixel; only the used
         VFI_CHECK_HIP(hipMalloc((void**)&w.gcount, list_pixels));                                   // entries are ever touched

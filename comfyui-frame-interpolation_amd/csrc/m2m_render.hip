@@ -733,13 +733,12 @@ int softsplat4_launch(const float* in, const float* flow, float* out, int N, int
     const int tiles_x = cdiv(W, RT), tiles_y = cdiv(H, RT);
     const size_t nt = (size_t)N * tiles_x * tiles_y;
     if (w.n_ranges < nt) {
-        if (w.ranges) VFI_CHECK_HIP(hipFree(w.ranges));      // (synchronises; only on growth)
+        // outgrown blocks are RETIRED, not freed: a captured HIP graph of the stream's owner may have their addresses baked in (r6)
         w.ranges = nullptr, w.n_ranges = 0;
         VFI_CHECK_HIP(hipMalloc((void**)&w.ranges, sizeof(float4) * nt));
         w.n_ranges = nt;
     }
     if (w.n_smax < (size_t)N) {
-        if (w.smax) VFI_CHECK_HIP(hipFree(w.smax));
         w.smax = nullptr, w.n_smax = 0;
         VFI_CHECK_HIP(hipMalloc((void**)&w.smax, sizeof(unsigned) * (size_t)(N < 64 ? 64 : N)));
         w.n_smax = N < 64 ? 64 : N;

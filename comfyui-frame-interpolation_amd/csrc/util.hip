@@ -163,6 +163,20 @@ int vfi_set_reserved_cus(int n) {
 
 int vfi_get_reserved_cus(void) { return g_reserved_cus.load(std::memory_order_relaxed); }
 
+int vfi_stream_create(void** stream_out) {
+    VFI_REQUIRE(stream_out, "vfi_stream_create: null argument");
+    hipStream_t s = nullptr;
+    VFI_CHECK_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream_out = (void*)s;
+    return 0;
+}
+
+int vfi_stream_destroy(void* stream) {
+    VFI_REQUIRE(stream, "vfi_stream_destroy: null stream");
+    VFI_CHECK_HIP(hipStreamDestroy((hipStream_t)stream));
+    return 0;
+}
+
 int vfi_memcpy_async(void* dst, const void* src, int64_t bytes, int kind, void* stream) {
     VFI_REQUIRE(dst && src && bytes >= 0 && (kind == 1 || kind == 2 || kind == 3), "vfi_memcpy_async: bad arguments (kind %d)", kind);
     if (bytes == 0) return 0;

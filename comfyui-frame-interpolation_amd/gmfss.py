@@ -297,8 +297,14 @@ class GMFSSEngine(OpsEngine):
 
     # ---- Model.reuse ------------------------------------------------------------------------------------------------
     def prepare(self, frame0, frame1):
+        assert frame1.shape == frame0.shape and frame0.shape[2] >= 3 and frame0.is_contiguous() and frame1.is_contiguous()
+        # one HIP graph per frame shape (opsengine._replayable): the ~1000 launches of Model.reuse replay without the interpreter; the
+        # record of what render() needs (tensors at the root of the pool: same addresses on every call) belongs to the graph
+        self.prepared = self._replayable(("prepare",) + tuple(frame0.shape), (frame0, frame1), (), self._prepare)
+        return self.prepared
+
+    def _prepare(self, frame0, frame1):
         H, W, Cc = frame0.shape
-        assert frame1.shape == frame0.shape and Cc >= 3 and frame0.is_contiguous() and frame1.is_contiguous()
         Hp, Wp = ((H - 1) // 64 + 1) * 64, ((W - 1) // 64 + 1) * 64
         Hh, Wh = Hp // 2, Wp // 2
         # what render() needs stays allocated (root of the pool); everything else lives in scopes and is recycled
@@ -436,6 +442,11 @@ class GMFSSEngine(OpsEngine):
     def render(self, t, out):
         P = self.prepared
         assert P is not None, "prepare() first"
+        self._replayable(("render", P["H"], P["W"], float(t)), (), (out,), lambda o: self._render(float(t), o))
+        return out
+
+    def _render(self, t, out):
+        P = self.prepared
         H, W, Hp, Wp = P["H"], P["W"], P["Hp"], P["Wp"]
         Hh, Wh = Hp // 2, Wp // 2
         t = float(t)

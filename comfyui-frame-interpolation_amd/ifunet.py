@@ -167,8 +167,14 @@ class IFUNetEngine(OpsEngine):
         s = float(self.scale if scale is None else scale)
         ens = bool(self.ensemble if ensemble is None else ensemble)
         t = float(t)
+        assert frame1.shape == frame0.shape and frame0.shape[2] >= 3 and frame0.is_contiguous() and frame1.is_contiguous()
+        # one HIP graph per (frame shape, timestep, scale, ensemble): the ~2000 launches of a call replay without the interpreter
+        self._replayable(("forward",) + tuple(frame0.shape) + (t, s, ens), (frame0, frame1), (out,),
+                         lambda f0, f1, o: self._forward(f0, f1, t, o, s, ens))
+        return out
+
+    def _forward(self, frame0, frame1, t, out, s, ens):
         H, W, Cc = frame0.shape
-        assert frame1.shape == frame0.shape and Cc >= 3 and frame0.is_contiguous() and frame1.is_contiguous()
         Hp, Wp = ((H - 1) // 64 + 1) * 64, ((W - 1) // 64 + 1) * 64
         hs, ws = self._scaled_sizes(Hp, Wp, s)
         px = Hp * Wp

@@ -49,24 +49,31 @@ class LaneSet:
 
     def lane(self, i):
         """-> (engine, stream) of lane i < k"""
+        from . import _lib
+
         while len(self._streams) <= i:
-            self._streams.append(torch.cuda.Stream(self.device))
+            self._streams.append(_lib.OwnStream(self.device))      # not torch.cuda.Stream(): its pool of 32 hands one stream to two owners
         while len(self.engines) <= i:
-            with torch.cuda.stream(self._streams[len(self.engines)]):      # the constructor's device work is ordered with the lane's first pair
+            with torch.cuda.stream(self._streams[len(self.engines)].stream):      # the constructor's device work is ordered with the lane's first pair
                 e = self._build()
                 if self._setup is not None:
                     self._setup(e)
             self.engines.append(e)
-        return self.engines[i], self._streams[i]
+        return self.engines[i], self._streams[i].stream
 
     def release_workspace(self):
         for e in self.engines:
             e.release_workspace()
 
     def close(self):
+        if self._streams and self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
         for e in self.engines[1 if self._borrowed else 0:]:
             e.close()
         self.engines = self.engines[:0]
+        for st in self._streams:
+            st.release()
+        self._streams = []
 
 
 def configure(engine, fn):

@@ -88,6 +88,12 @@ class _Pool:
 
 
 class OpsEngine:
+    # r6: a call whose launch sequence is fixed (same shapes, same scalars) is captured ONCE into a HIP graph and replayed: GMFSS issues
+    # ~1500 library calls per pair and IFUNet ~2000 through ctypes — 28-29 ms of interpreter time per pair beside 33-43 ms of device
+    # time, which left the node loop host-bound as soon as a second pair lane wanted feeding (lanes.py).  Tools that read the
+    # library's event trace or count FLOP per layer set ``use_graphs = False`` (a replay does not pass through Python).
+    use_graphs = True
+
     def __init__(self, device=None, _test_backend=None, pooled=False):
         self.be = _test_backend if _test_backend is not None else _Device(device)
         self.lib, self.device = self.be.lib, self.be.device
@@ -97,6 +103,59 @@ class OpsEngine:
         self._pool = _Pool(self.device) if pooled else None
         self._live = [{}]
         self.conv_flop = None      # set to 0 to count the direct-form FLOP of every convolution launched from here on (bench.py other_paths)
+        self._graphs, self._cap_stream = {}, None
+
+    # ---- HIP graphs -------------------------------------------------------------------------------------------------
+    def _replayable(self, key, ins, outs, fn):
+        """fn(*ins, *outs): a fixed sequence of library launches on the engine's own (address-stable) workspace, reading the device
+        tensors ``ins`` and writing ``outs``.  First call of a ``key`` (shapes and scalars of the call): the sequence runs eagerly on
+        the engine's capture stream — every lazily grown buffer behind it (pool chunks, the library's per-stream scratch) exists
+        afterwards — and is then captured on that stream with static copies of ins / outs; that call and all later ones replay the
+        graph (ins copied in, outs copied out: 3 x 25 MB of device copies beside tens of ms of kernels).  Anything that makes a
+        capture impossible leaves the key on the eager path, loudly."""
+        g = self._graphs.get(key) if self.use_graphs and self.conv_flop is None and self.device.type == "cuda" and isinstance(self.be, _Device) else False
+        if g is False:
+            return fn(*ins, *outs)
+        cur = torch.cuda.current_stream(self.device)
+        if g is None:
+            if self._cap_stream is None:
+                # the engine's own stream (never one of torch's pooled 32): the library scratch behind (device, stream) is then this
+                # engine's alone, and the addresses a graph bakes in stay valid for as long as the engine keeps the stream
+                self._cap_stream = _lib.OwnStream(self.device)
+            cs = self._cap_stream.stream
+            sin, sout = [torch.empty_like(x) for x in ins], [torch.empty_like(x) for x in outs]
+            try:
+                cs.wait_stream(cur)
+                with torch.cuda.stream(cs):
+                    for a, b in zip(sin, ins):
+                        a.copy_(b, non_blocking=True)
+                    fn(*sin, *sout)                       # warm-up: grows what has to grow, on the stream the capture will run on
+                graph = torch.cuda.CUDAGraph()
+                # thread_local: the host pipeline's worker threads (event waits, copies on their own streams) keep running meanwhile
+                with torch.cuda.graph(graph, stream=cs, capture_error_mode="thread_local"):
+                    ret = fn(*sin, *sout)                 # (its Python-side result — GMFSS' prepared-state record — belongs to the graph)
+                g = self._graphs[key] = (graph, sin, sout, ret)
+                cur.wait_stream(cs)
+            except Exception as e:  # noqa: BLE001 — keep the engine usable: this key stays eager
+                import warnings
+
+                self._graphs[key] = False
+                torch.cuda.synchronize(self.device)
+                warnings.warn(f"{type(self).__name__}: HIP graph capture of {key} failed ({type(e).__name__}: {e}); this call shape runs eagerly",
+                              RuntimeWarning, stacklevel=2)
+                return fn(*ins, *outs)
+        graph, sin, sout, ret = g
+        for a, b in zip(sin, ins):
+            a.copy_(b, non_blocking=True)
+        graph.replay()
+        for a, b in zip(outs, sout):
+            a.copy_(b, non_blocking=True)
+        return ret
+
+    def _drop_graphs(self):
+        if self._graphs and self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)      # a replay may still be in flight
+        self._graphs = {}
 
     # ---- plumbing ---------------------------------------------------------------------------------------------------
     def _c(self, name, *args):
@@ -204,8 +263,12 @@ class OpsEngine:
             self.lib.vfi_conv_destroy(h)
         self.handles = []
         self.release_workspace()
+        if getattr(self, "_cap_stream", None) is not None:
+            self._cap_stream.release()
+            self._cap_stream = None
 
     def release_workspace(self):
+        self._drop_graphs()        # they hold the addresses of this workspace
         self.scratch = {}
         if self._pool is not None:
             self._pool, self._live = _Pool(self.device), [{}]

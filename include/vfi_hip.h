@@ -487,6 +487,13 @@ int vfi_get_reserved_cus(void);
  * per-copy dispatch (which holds the interpreter lock and queries pointer attributes: 0.6-2.7 ms per call under load, measured). */
 int vfi_memcpy_async(void* dst, const void* src, int64_t bytes, int kind, void* stream);
 
+/* A HIP stream of the caller's own (hipStreamNonBlocking, on the calling thread's current device).  The nodes' pair lanes and the HIP
+ * graph captures of the op-by-op engines run on such streams: the library keys its scratch (split-K sums, attention partials, splat
+ * lists) by (device, stream), and a stream drawn from a framework's shared pool can be handed to two owners.  No reference counterpart:
+ * the reference runs everything on torch's current stream (rife/__init__.py:195-230). */
+int vfi_stream_create(void** stream_out);
+int vfi_stream_destroy(void* stream);
+
 /* Work done by one interpolate call for roofline accounting (algorithmic, per task). */
 int vfi_rife_work(vfi_rife_t* net, double* conv_flop_per_task, double* hbm_bytes_per_task);
 

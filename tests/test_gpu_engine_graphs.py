@@ -1,0 +1,97 @@
+"""-m gpu: the op-by-op engines (GMFSS Fortuna, IFUNet) replay a call of a known shape as a captured HIP graph (opsengine._replayable).
+A replay must give the eager call's bits, for several call shapes alive at once (two timesteps, two resolutions, interleaved), and a
+workspace release must drop the graphs with the addresses they baked in."""
+import pytest
+import torch
+
+from cfi_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib(hip_lib):
+    from cfi_amd import _lib
+
+    _lib.check(hip_lib.vfi_init(0), "vfi_init")
+    return hip_lib
+
+
+def _pairs(sizes, textured):
+    out = []
+    for k, (h, w) in enumerate(sizes):
+        fr = synth.texture_frames(2, h, w, seed=5 + k) if textured else synth.smooth_frames(2, h, w, seed=3 + k, shift=2.0)
+        out.append((fr[0].cuda().contiguous(), fr[1].cuda().contiguous()))
+    return out
+
+
+def test_ifunet_replay_equals_eager(lib):
+    from cfi_amd.ifunet import IFUNetEngine
+
+    sd = synth.ifunet_synth_state_dict(1234)
+    pairs = _pairs([(128, 192), (192, 256)], False)
+    calls = [(0, 0.5), (1, 0.5), (0, 0.25), (0, 0.5), (1, 0.5), (0, 0.25), (1, 0.5), (0, 0.5)]
+    eager = IFUNetEngine(sd)
+    eager.use_graphs = False
+    want = []
+    for p, t in calls:
+        o = torch.empty(pairs[p][0].shape[0], pairs[p][0].shape[1], 3, device="cuda")
+        eager.forward(pairs[p][0], pairs[p][1], t, o, scale=1.0, ensemble=True)
+        want.append(o)
+    eng = IFUNetEngine(sd)
+    try:
+        for (p, t), w in zip(calls, want):
+            o = torch.empty_like(w)
+            eng.forward(pairs[p][0], pairs[p][1], t, o, scale=1.0, ensemble=True)
+            assert torch.equal(o, w), (p, t, (o - w).abs().max().item())
+        assert len(eng._graphs) == 3 and all(eng._graphs.values()), "three call shapes, each captured"
+        eng.release_workspace()
+        assert not eng._graphs
+        o = torch.empty_like(want[0])
+        eng.forward(pairs[0][0], pairs[0][1], 0.5, o, scale=1.0, ensemble=True)      # captured again on the new workspace
+        assert torch.equal(o, want[0]) and len(eng._graphs) == 1
+    finally:
+        eng.close()
+        eager.close()
+
+
+def test_gmfss_replay_equals_eager(lib):
+    from cfi_amd.gmfss import GMFSSEngine
+
+    sds = synth.gmfss_coherent_state_dicts(3, "union")      # (random weights: the splats' atomic spill path is not run-to-run exact)
+    pairs = _pairs([(192, 256), (128, 192)], True)
+    seq = [(0, (0.5, 0.25)), (1, (0.5,)), (0, (0.25, 0.5, 0.75)), (1, (0.5,)), (0, (0.5,))]
+    eager = GMFSSEngine(sds)
+    eager.use_graphs = False
+    eng = GMFSSEngine(sds)
+    try:
+        for p, ts in seq:
+            h, w = pairs[p][0].shape[:2]
+            eager.prepare(*pairs[p])
+            eng.prepare(*pairs[p])
+            for t in ts:
+                a, b = torch.empty(h, w, 3, device="cuda"), torch.empty(h, w, 3, device="cuda")
+                eager.render(t, a)
+                eng.render(t, b)
+                assert torch.equal(a, b), (p, t, (a - b).abs().max().item())
+        assert all(eng._graphs.values()) and len(eng._graphs) == 2 + 3 + 1      # 2 prepares, 3 timesteps at the first size, 1 at the second
+    finally:
+        eng.close()
+        eager.close()
+
+
+def test_flop_counting_and_test_double_stay_eager(lib):
+    from cfi_amd.ifunet import IFUNetEngine
+
+    eng = IFUNetEngine(synth.ifunet_synth_state_dict(1234))
+    try:
+        (x0, x1), = _pairs([(128, 192)], False)
+        o = torch.empty(128, 192, 3, device="cuda")
+        eng.conv_flop = 0.0
+        eng.forward(x0, x1, 0.5, o, scale=1.0, ensemble=True)
+        assert eng.conv_flop > 0 and not eng._graphs      # bench.py's per-layer FLOP count passes through Python
+        eng.conv_flop = None
+        eng.forward(x0, x1, 0.5, o, scale=1.0, ensemble=True)
+        assert len(eng._graphs) == 1
+    finally:
+        eng.close()

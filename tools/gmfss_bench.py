@@ -53,6 +53,7 @@ if __name__ == "__main__":
         a = fl.abs().flatten()
         print(f"   flow |f|: mean {a.mean().item():.2f}, p99 {a.kthvalue(int(0.99 * a.numel())).values.item():.2f}, max {a.max().item():.2f} px", flush=True)
     print(f"   workspace: {eng.workspace_bytes() / 2**30:.2f} GiB (pooled scratch: {len(eng._pool.chunks)} chunks)", flush=True)
+    eng.use_graphs = False      # the event trace needs the launches to pass through the library call by call
     for phase in ("prepare", "render"):        # per-kernel split of each phase
         lib.vfi_trace_reset(); lib.vfi_trace_enable(1)
         if phase == "prepare":

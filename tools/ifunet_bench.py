@@ -45,6 +45,7 @@ if __name__ == "__main__":
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 3
         print(f"IFUNet 1080p ensemble={ens}: {dt * 1e3:.1f} ms/frame = {1 / dt:.1f} frames/s; device memory {torch.cuda.memory_allocated() / 2**30:.2f} GiB", flush=True)
+    eng.use_graphs = False      # the event trace needs the launches to pass through the library call by call
     lib.vfi_trace_reset(); lib.vfi_trace_enable(1)
     eng.forward(x0, x1, 0.5, out, scale=1.0, ensemble=True)
     torch.cuda.synchronize()

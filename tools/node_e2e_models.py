@@ -13,13 +13,16 @@ import __graft_entry__ as ge  # noqa: E402
 
 ge.build()
 ge.load_package()
-from cfi_amd import film, m2m, synth  # noqa: E402
+from cfi_amd import film, hostpipe, m2m, synth  # noqa: E402
 
 if __name__ == "__main__":
+    # usage: node_e2e_models.py [frames of the M2M clip] [frames of the FILM clip]   (defaults 9 / 5 = BASELINE.json configs[4] / configs[2])
+    n_m2m = int(sys.argv[1]) if len(sys.argv) > 1 else 9
+    n_film = int(sys.argv[2]) if len(sys.argv) > 2 else 5
     base = synth.smooth_frames(3, 1080, 1920, seed=1, shift=4.0)
     with tempfile.TemporaryDirectory() as td:
-        for name, mod, cls, sd, n, mults in (("M2M", m2m, "M2M_VFI", synth.m2m_synth_state_dict(1234), 9, (2, 4)),
-                                             ("FILM", film, "FILM_VFI", synth.film_synth_state_dict(1234), 5, (2,))):
+        for name, mod, cls, sd, n, mults in (("M2M", m2m, "M2M_VFI", synth.m2m_synth_state_dict(1234), n_m2m, (2, 4)),
+                                             ("FILM", film, "FILM_VFI", synth.film_synth_state_dict(1234), n_film, (2,))):
             pth = os.path.join(td, name + ".pth")
             torch.save(sd, pth)
             mod.load_file_from_github_release = lambda model_type, ckpt, p=pth: p
@@ -28,9 +31,12 @@ if __name__ == "__main__":
             node.vfi("x", frames[:2], multiplier=2)   # warm-up
             for m in mults:
                 for rep in range(2):
+                    hostpipe.stats.clear()
                     t0 = time.perf_counter()
                     res = node.vfi("x", frames, multiplier=m)
                     dt = time.perf_counter() - t0
+                    if hostpipe.PROFILE and rep == 1:      # VFI_HOST_PROFILE=1: seconds summed over worker / main-thread calls
+                        print("   host phases: " + ", ".join(f"{k} {v[0]}x {v[1] * 1e3:.1f} ms" for k, v in sorted(hostpipe.stats.items())), flush=True)
                     out = res[0]
                     del res
                     new = out.shape[0] - n

@@ -1,5 +1,7 @@
 """Pairs of a clip are independent: throughput of K engines on K HIP streams (round robin over the pairs) vs one engine on one
-stream, 1080p, 2x.  usage: overlap_probe.py [m2m|film|gmfss|ifunet|ifrnet ...] [--k 1,2,3]"""
+stream, 1080p, 2x.  usage: overlap_probe.py [m2m|film|gmfss|ifunet|ifrnet ...] [--k 1,2,3] [--node N]
+--node N: the node loop itself (m2m.run_plan: host clip of N frames in, host tensor out, PCIe and host copies included) with a LaneSet
+of K lanes, instead of the device-resident pair loop."""
 import os
 import sys
 import time
@@ -55,13 +57,38 @@ if __name__ == "__main__":
     ks = [1, 2, 3]
     if "--k" in sys.argv:
         ks = [int(v) for v in sys.argv[sys.argv.index("--k") + 1].split(",")]
-        args = [a for a in args if not a[0].isdigit()]
+    args = [a for a in args if not a[0].isdigit()]
     H, W = 1080, 1920
     for model in args or ["m2m"]:
         fr = synth.texture_frames(2, H, W, seed=5) if model == "gmfss" else synth.smooth_frames(2, H, W, seed=2, shift=4.0)
         x0, x1 = fr[0].cuda().contiguous(), fr[1].cuda().contiguous()
         factory = make(model)
         base = None
+        if "--node" in sys.argv and model != "film":
+            from cfi_amd.lanes import LaneSet
+            from cfi_amd.m2m import run_plan
+            from cfi_amd.schedule import generic_output_plan
+            n = int(sys.argv[sys.argv.index("--node") + 1])
+            clip = fr[torch.arange(n) % 2].contiguous()
+            plan, tasks = generic_output_plan(n, 2, None)
+            ref = None
+            for K in ks:
+                lanes = LaneSet(factory, K)
+                if model == "ifrnet":
+                    lanes.configure(lambda e: setattr(e, "embt", 1.0))
+                best = 1e9
+                for rep in range(3):
+                    t0 = time.perf_counter()
+                    got = run_plan(lanes, clip, plan, tasks)
+                    best = min(best, time.perf_counter() - t0)
+                ref = got if ref is None else ref
+                base = base or best
+                print(f"{model} node loop, {n} frames 1080p: K = {K}: {best * 1e3:.1f} ms -> {(n - 1) / best:.1f} interpolated frames/s ({base / best:.3f}x), "
+                      f"identical to K = {ks[0]}: {torch.equal(ref, got)}", flush=True)
+                lanes.close()
+                del lanes
+                torch.cuda.empty_cache()
+            continue
         for K in ks:
             engs = [factory() for _ in range(K)]
             streams = [torch.cuda.Stream() for _ in range(K)]
