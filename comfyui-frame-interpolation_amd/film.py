@@ -25,7 +25,7 @@ import torch
 
 from . import _lib
 from .ckpt import cached_engine, load_file_from_github_release
-from .lanes import LaneSet, lanes_for, lanes_of
+from .lanes import lane_set, lanes_of
 from .dist import all_gather_frames, world
 from .film_spec import check_state_dict, film_shapes
 from .schedule import InterpolationStateList, shard_tasks
@@ -131,7 +131,7 @@ class FILM_VFI:
         # (the reference re-loads the TorchScript file on every call, film/__init__.py:74; see ckpt.cached_engine)
         def build():
             sd = _load_state_dict(model_path)
-            return LaneSet(lambda: FilmEngine(sd), lanes_for("film"))
+            return lane_set("film", lambda: FilmEngine(sd))
         engine, cached = cached_engine(MODEL_TYPE, model_path, build)
         try:
             frames = frames[..., :3]

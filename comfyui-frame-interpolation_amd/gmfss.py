@@ -648,8 +648,8 @@ class GMFSS_Fortuna_VFI:
         if ckpt_name not in CKPTS_PATH_CONFIG:
             raise KeyError(ckpt_name)
         sds = {part: _load(load_file_from_github_release(*loc)) for part, loc in CKPTS_PATH_CONFIG[ckpt_name].items()}
-        from .lanes import LaneSet, lanes_for
-        engine = LaneSet(lambda: GMFSSEngine(sds), lanes_for("gmfss"))   # (the reference rebuilds the model on every call, gmfss_fortuna/__init__.py:129-130)
+        from .lanes import lane_set
+        engine = lane_set("gmfss", lambda: GMFSSEngine(sds))   # (the reference rebuilds the model on every call, gmfss_fortuna/__init__.py:129-130)
         try:
             plan, tasks = generic_output_plan(len(frames), multiplier, optional_interpolation_states)
             return (run_plan(engine, frames, plan, tasks, name="GMFSS Fortuna VFI"),)

@@ -28,7 +28,7 @@ import torch
 
 from . import _lib
 from .ckpt import cached_engine, load_file_from_github_release
-from .lanes import LaneSet, lanes_for
+from .lanes import lane_set
 from .lanes import configure as configure_lanes
 from .ifrnet_spec import CKPT_NAMES, CONFIG, check_state_dict, decoder_io, kind_of
 from .schedule import InterpolationStateList, generic_output_plan
@@ -331,7 +331,7 @@ class IFRNet_VFI:
         # (the reference rebuilds the model on every call, ifrnet/__init__.py:42-45; see ckpt.cached_engine)
         def build():
             sd = _load_state_dict(model_path)
-            return LaneSet(lambda: IFRNetEngine(sd, kind), lanes_for("ifrnet"))
+            return lane_set("ifrnet", lambda: IFRNetEngine(sd, kind))
         engine, cached = cached_engine(MODEL_TYPE + kind, model_path, build)
         try:
             embt = float(scale_factor)           # positional mis-binding of the reference's call, see the module docstring

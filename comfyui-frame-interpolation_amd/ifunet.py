@@ -377,9 +377,9 @@ class IFUnet_VFI:
 
         assert len(frames) >= 2, f"VFI model IFUNet requires at least 2 frames to work with, only found {frames.shape[0]}."
         model_path = load_file_from_github_release(MODEL_TYPE, ckpt_name)
-        from .lanes import LaneSet, lanes_for
+        from .lanes import lane_set
         sd = torch.load(model_path, map_location="cpu", weights_only=False)
-        engine = LaneSet(lambda: IFUNetEngine(sd), lanes_for("ifunet"))
+        engine = lane_set("ifunet", lambda: IFUNetEngine(sd))
         sc, ens = float(scale_factor), bool(ensemble)
         engine.configure(lambda e: (setattr(e, "scale", sc), setattr(e, "ensemble", ens)))
         try:

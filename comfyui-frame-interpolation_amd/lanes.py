@@ -16,6 +16,10 @@ import torch
 
 # lanes per model type (VFI_PAIR_LANES=<n> overrides all of them; 1 = the single-stream loop)
 DEFAULT_LANES = {"m2m": 3, "film": 2, "gmfss": 3, "ifunet": 3, "ifrnet": 2}
+# A lane's first pair pays for its workspace (and, GMFSS / IFUNet, for its graph capture; FILM's first forward allocates its scratch
+# call by call and holds the host for a whole pair): a lane is only opened for this many pairs of the clip (measured at 1080p:
+# FILM with 2 lanes on 12 pairs 583 vs 567 ms, M2M with 3 lanes on 8 pairs 89 vs 76 ms — tools/node_e2e_models.py)
+PAIRS_PER_LANE = {"film": 12}
 
 
 def lanes_for(model):
@@ -25,14 +29,19 @@ def lanes_for(model):
     return DEFAULT_LANES.get(model, 1)
 
 
+def lane_set(model, build):
+    """the node classes' LaneSet of a model type"""
+    return LaneSet(build, lanes_for(model), pairs_per_lane=PAIRS_PER_LANE.get(model, 2))
+
+
 class LaneSet:
     """K engines built from one checkpoint by ``build()``; engine i runs on stream i.  Engines beyond the first are built at first
     use (a two-frame clip never pays for them).  Looks like an engine to the node code that owns it: ``device``, ``close()``,
     ``release_workspace()``; attributes set through ``configure`` reach every lane."""
 
-    def __init__(self, build, k, first=None):
+    def __init__(self, build, k, first=None, pairs_per_lane=2):
         """first: an engine the caller already owns becomes lane 0 (close() leaves it alone)"""
-        self._build, self.k = build, max(1, int(k))
+        self._build, self.k, self.pairs_per_lane = build, max(1, int(k)), max(1, int(pairs_per_lane))
         self._borrowed = first is not None
         self.engines = [first if first is not None else build()]
         self.device = self.engines[0].device
@@ -87,8 +96,10 @@ def configure(engine, fn):
 def lanes_of(engine, n_pairs):
     """(lane getter, lane count) for a node loop over n_pairs pairs: a LaneSet spreads them, a plain engine is one lane on the
     current stream."""
-    if isinstance(engine, LaneSet) and engine.k > 1 and n_pairs > 1:
-        return engine.lane, min(engine.k, n_pairs)
+    if isinstance(engine, LaneSet):
+        n = min(engine.k, n_pairs // engine.pairs_per_lane)
+        if n > 1:
+            return engine.lane, n
     eng = engine.engines[0] if isinstance(engine, LaneSet) else engine
     main = torch.cuda.current_stream(eng.device) if eng.device.type == "cuda" else None
     return (lambda i: (eng, main)), 1

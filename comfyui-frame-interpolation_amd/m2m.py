@@ -27,7 +27,7 @@ import torch
 
 from . import _lib
 from .ckpt import cached_engine, load_file_from_github_release
-from .lanes import LaneSet, lanes_for
+from .lanes import LaneSet, lane_set
 from .dist import all_gather_frames, world
 from .m2m_spec import check_state_dict, m2m_shapes
 from .schedule import InterpolationStateList, generic_output_plan, shard_tasks
@@ -239,7 +239,7 @@ class M2M_VFI:
         # (the reference rebuilds M2M_PWC on every call, m2m/__init__.py:43-46; see ckpt.cached_engine)
         def build():
             sd = _load_state_dict(model_path)
-            return LaneSet(lambda: M2MEngine(sd), lanes_for("m2m"))
+            return lane_set("m2m", lambda: M2MEngine(sd))
         engine, cached = cached_engine(MODEL_TYPE, model_path, build)
         try:
             plan, tasks = generic_output_plan(len(frames), multiplier, optional_interpolation_states)

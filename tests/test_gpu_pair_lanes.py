@@ -60,13 +60,13 @@ def test_lanes_bit_identical_to_single_stream(lib, model, multiplier, states):
             single.close()
     lanes = LaneSet(build, 3)
     try:
-        assert lanes_of(lanes, 6)[1] == 3 and lanes_of(lanes, 1)[1] == 1 and lanes_of(lanes, 2)[1] == 2
+        assert lanes_of(lanes, 6)[1] == 3 and lanes_of(lanes, 1)[1] == 1 and lanes_of(lanes, 3)[1] == 1 and lanes_of(lanes, 4)[1] == 2
         for rep in range(2):      # the second call finds every lane built and its workspace warm
             got = run_plan(lanes, fr, plan, tasks)
             torch.cuda.synchronize()
             assert got.shape == want.shape
             assert torch.equal(got, want), f"{model}: lanes differ from the single-stream loop by {(got - want).abs().max().item():.3e} (call {rep})"
-        assert len(lanes.engines) == min(3, len(tasks))
+        assert len(lanes.engines) == min(3, max(1, len(tasks) // 2))
     finally:
         lanes.close()
 
@@ -79,6 +79,9 @@ def test_film_node_lanes_bit_identical(lib, tmp_path, monkeypatch):
     pth = tmp_path / "film_net_fp32.pt"
     torch.save(sd, pth)
     monkeypatch.setattr(FM, "load_file_from_github_release", lambda model_type, ck: str(pth))
+    import cfi_amd.lanes as LN
+
+    monkeypatch.setitem(LN.PAIRS_PER_LANE, "film", 1)      # (the node opens a FILM lane per 12 pairs; this clip has 4 kept ones)
     frames = synth.smooth_frames(6, 64, 80, seed=2, shift=1.5, c=4)
     outs = {}
     for k in ("1", "3"):

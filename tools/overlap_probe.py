@@ -89,6 +89,27 @@ if __name__ == "__main__":
                 del lanes
                 torch.cuda.empty_cache()
             continue
+        dma_stop = None
+        if "--dma" in sys.argv:      # pinned H2D + D2H of one frame each, back to back on two side streams, while the pairs run
+            import threading
+            hbuf = [torch.empty(H, W, 3, pin_memory=True) for _ in range(2)]
+            dbuf = [torch.empty(H, W, 3, device="cuda") for _ in range(2)]
+            s_up, s_dn = torch.cuda.Stream(), torch.cuda.Stream()
+            dma_stop = threading.Event()
+
+            def dma():
+                n = 0
+                while not dma_stop.is_set():
+                    with torch.cuda.stream(s_up):
+                        dbuf[0].copy_(hbuf[0], non_blocking=True)
+                    with torch.cuda.stream(s_dn):
+                        hbuf[1].copy_(dbuf[1], non_blocking=True)
+                    s_up.synchronize(); s_dn.synchronize()
+                    n += 1
+                    time.sleep(float(os.environ.get("DMA_GAP_MS", "5")) * 1e-3)
+                print(f"   (dma thread: {n} frame copies each way)", flush=True)
+
+            threading.Thread(target=dma, daemon=True).start()
         for K in ks:
             engs = [factory() for _ in range(K)]
             streams = [torch.cuda.Stream() for _ in range(K)]
@@ -121,3 +142,6 @@ if __name__ == "__main__":
                     e.close()
             del engs, outs, res
             torch.cuda.empty_cache()
+        if dma_stop is not None:
+            dma_stop.set()
+            time.sleep(0.05)
