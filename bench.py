@@ -294,12 +294,12 @@ def other_paths(dev, H, W, parity=True):
         got = eng.forward(x0, x1).cpu()
         out["film_2x"]["parity"] = leg_parity(got, lambda: film_oracle.film_forward(film_sd, xn[0:1], xn[1:2])[0].permute(1, 2, 0),
                                               f"the timed call's frame (smooth pair seed 2, {H}x{W}, t = 0.5) vs oracle.film_oracle.film_forward on the same host tensors")
-    out["film_2x"]["pair_lanes"] = pair_lanes_rate(dev, lambda: FilmEngine(film_sd), lambda e, k: e.forward(x0, x1), "film", n_pairs=6, first=eng)
+    out["film_2x"]["pair_lanes"] = pair_lanes_rate(dev, lambda: FilmEngine(film_sd), lambda e, k: e.forward(x0, x1), "film", n_pairs=12, first=eng)
     eng.close()
     m2m_sd = synth.m2m_synth_state_dict(1234)
     eng = M2MEngine(m2m_sd)
     tp = timed(lambda: eng.prepare(x0, x1), 5)
-    tr = timed(lambda: eng.render(0.5), 10)
+    tr = timed(lambda: eng.render(0.5), 20)
     out["m2m"] = {"prepare_ms_per_pair": round(tp * 1e3, 3), "render_ms_per_frame": round(tr * 1e3, 3),
                   "frames_per_s_2x": round(1 / (tp + tr), 1), "frames_per_s_8x": round(7 / (tp + 7 * tr), 1)}
     m2m_outs = {}
@@ -308,7 +308,7 @@ def other_paths(dev, H, W, parity=True):
         e.prepare(x0, x1)
         m2m_outs[k] = e.render(0.5, m2m_outs.get(k))
 
-    out["m2m"]["pair_lanes"] = pair_lanes_rate(dev, lambda: M2MEngine(m2m_sd), m2m_pair, "m2m", n_pairs=24, first=eng)
+    out["m2m"]["pair_lanes"] = pair_lanes_rate(dev, lambda: M2MEngine(m2m_sd), m2m_pair, "m2m", n_pairs=48, first=eng)
     if parity:
         from oracle import m2m_model_oracle as mo
 
@@ -471,7 +471,7 @@ def other_nodes(dev, H, W):
             e.prepare(g0, g1)
             e.render(0.5, gm_outs[k])
 
-        res["gmfss_fortuna_union"]["pair_lanes"] = pair_lanes_rate(dev, lambda: GMFSSEngine(gm_sds), gm_pair, "gmfss", n_pairs=9, first=eng)
+        res["gmfss_fortuna_union"]["pair_lanes"] = pair_lanes_rate(dev, lambda: GMFSSEngine(gm_sds), gm_pair, "gmfss", n_pairs=18, first=eng)
         eng.close()
         del eng
     except Exception as e:  # noqa: BLE001
@@ -491,7 +491,7 @@ def other_nodes(dev, H, W):
                 iu_outs[k] = torch.empty(H, W, 3, device=dev)
             e.forward(x0, x1, 0.5, iu_outs[k], scale=1.0, ensemble=True)
 
-        res["ifunet"]["pair_lanes"] = pair_lanes_rate(dev, lambda: IFUNetEngine(iu_sd), iu_pair, "ifunet", n_pairs=9, first=eng)
+        res["ifunet"]["pair_lanes"] = pair_lanes_rate(dev, lambda: IFUNetEngine(iu_sd), iu_pair, "ifunet", n_pairs=18, first=eng)
         eng.close()
         del eng
     except Exception as e:  # noqa: BLE001
@@ -511,7 +511,7 @@ def other_nodes(dev, H, W):
                 ir_outs[k] = torch.empty(1, H, W, 3, device=dev)
             e.forward([x0], [x1], 0.5, 1.0, ir_outs[k])
 
-        res["ifrnet_L"]["pair_lanes"] = pair_lanes_rate(dev, lambda: IFRNetEngine(ir_sd, "L"), ir_pair, "ifrnet", n_pairs=12, first=eng)
+        res["ifrnet_L"]["pair_lanes"] = pair_lanes_rate(dev, lambda: IFRNetEngine(ir_sd, "L"), ir_pair, "ifrnet", n_pairs=36, first=eng)
         eng.close()
         del eng
     except Exception as e:  # noqa: BLE001
