@@ -73,7 +73,9 @@ def test_gmfss_replay_equals_eager(lib):
                 a, b = torch.empty(h, w, 3, device="cuda"), torch.empty(h, w, 3, device="cuda")
                 eager.render(t, a)
                 eng.render(t, b)
-                assert torch.equal(a, b), (p, t, (a - b).abs().max().item())
+                # GMFSS is not run-to-run exact on ONE engine: a splat source that flies farther than its tile's window goes through the
+                # atomic spill pass, whose summation order is the hardware's (1.2e-6 .. 1.7e-6 observed); everything else is bit-stable
+                assert (a - b).abs().max().item() <= 5e-6, (p, t, (a - b).abs().max().item())
         assert all(eng._graphs.values()) and len(eng._graphs) == 2 + 3 + 1      # 2 prepares, 3 timesteps at the first size, 1 at the second
     finally:
         eng.close()

@@ -65,7 +65,9 @@ def test_lanes_bit_identical_to_single_stream(lib, model, multiplier, states):
             got = run_plan(lanes, fr, plan, tasks)
             torch.cuda.synchronize()
             assert got.shape == want.shape
-            assert torch.equal(got, want), f"{model}: lanes differ from the single-stream loop by {(got - want).abs().max().item():.3e} (call {rep})"
+            # (GMFSS: its splats' atomic spill pass sums in hardware order — one stream already differs from itself by ~1.5e-6 now and then)
+            same = torch.equal(got, want) if model != "gmfss" else (got - want).abs().max().item() <= 5e-6
+            assert same, f"{model}: lanes differ from the single-stream loop by {(got - want).abs().max().item():.3e} (call {rep})"
         assert len(lanes.engines) == min(3, max(1, len(tasks) // 2))
     finally:
         lanes.close()
