@@ -93,6 +93,7 @@ class OpsEngine:
     # time, which left the node loop host-bound as soon as a second pair lane wanted feeding (lanes.py).  Tools that read the
     # library's event trace or count FLOP per layer set ``use_graphs = False`` (a replay does not pass through Python).
     use_graphs = True
+    MAX_GRAPHS = 64
 
     def __init__(self, device=None, _test_backend=None, pooled=False):
         self.be = _test_backend if _test_backend is not None else _Device(device)
@@ -108,16 +109,21 @@ class OpsEngine:
     # ---- HIP graphs -------------------------------------------------------------------------------------------------
     def _replayable(self, key, ins, outs, fn):
         """fn(*ins, *outs): a fixed sequence of library launches on the engine's own (address-stable) workspace, reading the device
-        tensors ``ins`` and writing ``outs``.  First call of a ``key`` (shapes and scalars of the call): the sequence runs eagerly on
-        the engine's capture stream — every lazily grown buffer behind it (pool chunks, the library's per-stream scratch) exists
-        afterwards — and is then captured on that stream with static copies of ins / outs; that call and all later ones replay the
-        graph (ins copied in, outs copied out: 3 x 25 MB of device copies beside tens of ms of kernels).  Anything that makes a
+        tensors ``ins`` and writing ``outs``.  First call of a ``key`` (shapes and scalars of the call): eager, on the caller's stream.
+        Second call: the sequence runs once on the engine's capture stream — every lazily grown buffer behind THAT stream (pool
+        chunks, the library's per-stream scratch) exists afterwards — and is then captured there with static copies of ins / outs; that
+        call and all later ones replay the graph (ins copied in, outs copied out: 3 x 25 MB of device copies beside tens of ms of kernels).  Anything that makes a
         capture impossible leaves the key on the eager path, loudly."""
         g = self._graphs.get(key) if self.use_graphs and self.conv_flop is None and self.device.type == "cuda" and isinstance(self.be, _Device) else False
         if g is False:
             return fn(*ins, *outs)
         cur = torch.cuda.current_stream(self.device)
-        if g is None:
+        if g is None or g == "seen":
+            # A key is captured at its SECOND use: a call shape that occurs once (a 2-frame clip, one of 999 timesteps of a x1000 pair)
+            # must not pay for a warm-up run and a capture it will never replay; and an engine keeps at most MAX_GRAPHS of them.
+            if g is None or sum(1 for v in self._graphs.values() if isinstance(v, tuple)) >= self.MAX_GRAPHS:
+                self._graphs[key] = "seen"
+                return fn(*ins, *outs)
             if self._cap_stream is None:
                 # the engine's own stream (never one of torch's pooled 32): the library scratch behind (device, stream) is then this
                 # engine's alone, and the addresses a graph bakes in stay valid for as long as the engine keeps the stream
