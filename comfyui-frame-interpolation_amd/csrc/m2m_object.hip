@@ -57,6 +57,11 @@ struct vfi_m2m {
     float* smax = nullptr;             // [8]: max |tf_s|
     float* stats = nullptr;
     void* ws = nullptr;
+    // r6 A/B form (option m2m_side, off): the image-pyramid convolutions of the refinement network depend on the normalised frames only,
+    // not on the flow, and can run on this side stream beside the PWC flow network (fork / join by events).  Bit-identical, and measured
+    // neutral for one pair (7.00-7.04 vs 7.0-7.1 ms) and 8 % slower under three pair lanes (lanes.py already fill the coarse levels' holes)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int dech[5][2], ench[4][2];
     std::map<std::tuple<std::string, int, int, int>, Ten> scratch;
     std::vector<void*> owned;
@@ -168,6 +173,20 @@ int cube(vfi_m2m* m, hipStream_t st) {
         run(m->cube[2], m->pw, 0, m->cw, 0, 4, 0.f, st))
         return -1;
     return vfi_m2m_cube_apply(m->s3.p, 256, m->cc.p, m->ch.p, 16, m->cw.p, 16, m->enc[3].p, 768, 2, h, w, 256, st);
+}
+
+// EncDec's image pyramid (:722-735): c[l] = pyr[l](c[l-1]) written into its channel window of enc[l]; depends on the frames only
+int image_pyramid(vfi_m2m* m, hipStream_t st) {
+    const int coff[4] = {32, 64, 128, 256};   // channel offset of the image-pyramid feature c[l] inside enc[l]
+    const Ten* src = &m->d0;
+    int soff = 0;
+    for (int l = 0; l < 4; ++l) {
+        Ten* t;
+        if (tmp(m, "pa", m->ench[l][0], m->ench[l][1], 16 << l, &t)) return -1;
+        if (run(m->pyr[l][0], *src, soff, *t, 0, 3, 0.f, st) || run(m->pyr[l][1], *t, 0, m->enc[l], coff[l], 3, 0.f, st)) return -1;
+        src = &m->enc[l], soff = coff[l];
+    }
+    return 0;
 }
 
 }  // namespace
@@ -287,6 +306,12 @@ vfi_m2m_t* vfi_m2m_create(const float* const* tensors, const int64_t* numels, in
 
 void vfi_m2m_destroy(vfi_m2m_t* m) {
     if (!m) return;
+    if (m->side) {
+        (void)hipStreamSynchronize(m->side);
+        (void)hipEventDestroy(m->ev_fork);
+        (void)hipEventDestroy(m->ev_join);
+        (void)hipStreamDestroy(m->side);
+    }
     for (vfi_conv_t* c : m->all) vfi_conv_destroy(c);
     free_workspace(m);
     delete m;
@@ -307,6 +332,21 @@ int vfi_m2m_prepare(vfi_m2m_t* m, const float* frame0_dev, const float* frame1_d
     m->prepared = false;
     if (vfi_m2m_normalize(frame0_dev, frame1_dev, C, H, W, Hp, Wp, m->d0.p, 8, 2, m->stats, m->ws, 16384, st)) return -1;
     if (vfi_m2m_image4(m->d0.p, 8, m->img4.p, Hp, Wp, st)) return -1;
+    // fork: the c features (image pyramid through pyr[l][0..1], EncDec.forward :722-735) read channels 2..4 of d0 = the normalised frames,
+    // which exist now.  (Channels 0..1 and 5..7 of d0 are written later on `st` — the flow, the warped partner — while the side stream may
+    // still read the 8-channel pixels: those channels meet zero weights in pyr[0][0], on either stream.)
+    const bool forked = option(kOptM2mSide) != 0;
+    if (forked) {
+        if (!m->side) {
+            VFI_CHECK_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+            VFI_CHECK_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+            VFI_CHECK_HIP(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+        }
+        VFI_CHECK_HIP(hipEventRecord(m->ev_fork, st));
+        VFI_CHECK_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+        if (image_pyramid(m, m->side)) return -1;
+        VFI_CHECK_HIP(hipEventRecord(m->ev_join, m->side));
+    }
     // ---- flow network on half-resolution images (:936-939, bidir :521-546)
     if (resize(m->d0, 2, m->imh, 0, 3, 1.0f, st)) return -1;
     const Ten* src = &m->imh;
@@ -348,15 +388,8 @@ int vfi_m2m_prepare(vfi_m2m_t* m, const float* frame0_dev, const float* frame1_d
     }
     // ---- motion refinement (MotionRefineNet.forward :866-890, EncDec.forward :718-848)
     if (resize(m->flow[0], 0, m->d0, 0, 2, (float)RATIO, st)) return -1;
-    const int coff[4] = {32, 64, 128, 256};   // channel offset of the image-pyramid feature c[l] inside enc[l]
-    src = &m->d0;
-    int soff = 0;
-    for (int l = 0; l < 4; ++l) {
-        Ten* t;
-        if (tmp(m, "pa", m->ench[l][0], m->ench[l][1], 16 << l, &t)) return -1;
-        if (run(m->pyr[l][0], *src, soff, *t, 0, 3, 0.f, st) || run(m->pyr[l][1], *t, 0, m->enc[l], coff[l], 3, 0.f, st)) return -1;
-        src = &m->enc[l], soff = coff[l];
-    }
+    if (forked) VFI_CHECK_HIP(hipStreamWaitEvent(st, m->ev_join, 0));
+    else if (image_pyramid(m, st)) return -1;
     if (vfi_m2m_warp_image4(m->img4.p, m->d0.p, 8, m->d0.p + 5, 8, Hp, Wp, st)) return -1;
     src = &m->d0;
     const Ten* flow_src = &m->d0;

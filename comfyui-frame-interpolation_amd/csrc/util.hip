@@ -28,7 +28,7 @@ const char* get_error() { return g_err; }
 // ---- A/B options (vfi_common.h: enum Option) ---------------------------------------------------------------------------------
 static const struct { const char* name; long dflt; } kOptTable[kOptCount] = {
     {"stage_quad", 14}, {"fuse_encode", 1}, {"fuse0a", 1}, {"m2n2_px", -1}, {"grouped_variant", -1}, {"splitk", 1},
-    {"splat_atomic", 0}, {"splat_spill_cap", -1}, {"wino_xcd", 1}, {"deconv_wino", 1}, {"encode_batched", 1}, {"wino_quant", 1}, {"xcd_bands", 0}, {"m2m_fused", 1}, {"wino_probe", 0},
+    {"splat_atomic", 0}, {"splat_spill_cap", -1}, {"wino_xcd", 1}, {"deconv_wino", 1}, {"encode_batched", 1}, {"wino_quant", 1}, {"xcd_bands", 0}, {"m2m_fused", 1}, {"m2m_side", 0}, {"wino_probe", 0},
 };
 static std::atomic<long> g_opt[kOptCount];
 static std::atomic<bool> g_opt_init{false};

@@ -72,6 +72,7 @@ enum Option {
     kOptWinoQuant,       // 1: layer objects leave launches of <= 2 rounds with a nearly empty last round to the direct kernel (default), 0: item count only
     kOptXcdBands,        // 1: XCD-aware workgroup order of the RIFE gather kernels (final blend, quad transitions), 0: plain order (default: r6 A/B measured the banded order 2-5 % SLOWER, profiles/r06_xcd_bands_ab.txt)
     kOptM2mFused,        // 1: M2M render as one kernel (m2m_render.hip; default), 0: splat inputs + summation splat + combine as separate launches
+    kOptM2mSide,         // 1: M2M prepare runs the image-pyramid convolutions (EncDec's c features) on a side stream beside the PWC flow network, 0: one stream (default: r6 A/B measured the fork neutral on one pair — 7.00-7.04 vs 7.0-7.1 ms — and 8 % SLOWER under three pair lanes)
     kOptWinoProbe,       // 1..4: the hot Winograd instantiation takes its cycle-ledger form (conv_wino.hip: g_wino_probe_out; default 0)
     kOptCount
 };

@@ -230,6 +230,33 @@ def test_engine_fused_equals_three_step(lib, h, w):
         eng.close()
 
 
+@pytest.mark.parametrize("h,w", [(100, 150), (270, 480), (1080, 1920)])
+def test_prepare_side_stream_equals_one_stream(lib, h, w):
+    """r6 A/B form (option m2m_side, default off: measured neutral): prepare() forks the refinement network's image-pyramid convolutions onto
+    the object's side stream beside the PWC flow network.  Same kernels on the same tensors: the frames must be bit-identical to the one-stream order, call after call
+    (a second pair re-uses the pyramid's windows while the previous pair's up path has just overwritten them)."""
+    from cfi_amd.m2m import M2MEngine
+
+    fr = synth.smooth_frames(3, h, w, seed=3, shift=4.0)
+    x = [f.cuda().contiguous() for f in fr]
+    eng = M2MEngine(synth.m2m_synth_state_dict(1234))
+    try:
+        outs = {}
+        for mode in (1, 0, 1, 1):
+            assert lib.vfi_test_set_option(b"m2m_side", mode) == 0
+            got = []
+            for a, b in ((0, 1), (1, 2), (2, 0)):
+                eng.prepare(x[a], x[b])
+                got.append(eng.render(0.5).cpu())
+            outs.setdefault(mode, []).append(got)
+        for k in range(3):
+            assert torch.equal(outs[1][0][k], outs[0][0][k]), describe_diff(outs[1][0][k], outs[0][0][k], f"side stream vs one stream, pair {k}")
+            assert torch.equal(outs[1][0][k], outs[1][1][k]) and torch.equal(outs[1][0][k], outs[1][2][k]), "run-to-run determinism"
+    finally:
+        lib.vfi_test_set_option(b"m2m_side", 0)
+        eng.close()
+
+
 # ---- the generic 4-channel splat on the same machinery (softsplat4_kernel: classification + compaction) ------------------------------
 @pytest.mark.parametrize("N,H,W,kind", [(1, 96, 160, "smooth"), (2, 70, 90, "translate"), (1, 136, 240, "noise8"), (1, 64, 96, "noise1"), (1, 128, 128, "zoom"),
                                         (1, 64, 64, "point"), (1, 200, 300, "far")])
