@@ -152,6 +152,7 @@ PROTOTYPES = {
     "vfi_memcpy_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "vfi_stream_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "vfi_stream_destroy": (C.c_int, [C.c_void_p]),
+    "vfi_stream_spin": (C.c_int, [C.c_void_p, C.c_int]),
     "vfi_set_reserved_cus": (C.c_int, [C.c_int]),
     "vfi_get_reserved_cus": (C.c_int, []),
     "vfi_film_create": (C.c_void_p, [C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int]),
@@ -308,6 +309,58 @@ class OwnStream:
         if self.ptr is not None:
             _own_streams.setdefault(self.index, []).append(self.ptr)
             self.ptr = self.stream = None
+
+
+def streams_share_queue(a, b, spin_us=300):
+    """Do torch streams a and b (same device) run on ONE hardware queue?  The HIP runtime binds a stream to one of a handful of hardware
+    queues (4 by default) at its first use; two streams of one queue execute strictly in order — two pair lanes on them overlap nothing
+    (measured: M2M with three lanes 6.75 instead of 6.17 ms per pair whenever two of the lanes' streams had landed on one queue).
+    Probe: one spinning workgroup on each; together they take 1x the spin on different queues, 2x on the same."""
+    import time
+
+    lib = load()
+    pa, pb = C.c_void_p(a.cuda_stream), C.c_void_p(b.cuda_stream)
+    for s in (pa, pb):                      # first use binds the queue (and loads the kernel)
+        check(lib.vfi_stream_spin(s, 1), "vfi_stream_spin")
+    votes = 0
+    for _ in range(3):
+        a.synchronize(); b.synchronize()
+        t0 = time.perf_counter()
+        check(lib.vfi_stream_spin(pa, spin_us), "vfi_stream_spin")
+        check(lib.vfi_stream_spin(pb, spin_us), "vfi_stream_spin")
+        a.synchronize(); b.synchronize()
+        votes += (time.perf_counter() - t0) * 1e6 > 1.6 * spin_us
+    return votes >= 2
+
+
+def own_streams_apart(device, k, avoid=(), tries=12):
+    """k OwnStreams of `device` that pairwise do not share a hardware queue, and none of which shares one with a busy stream in `avoid`
+    (best effort: with 4 hardware queues and copy streams beside the lanes not every wish can be met — the mutual condition comes
+    first, `avoid` is dropped stream by stream from its end when the candidates run out).  Rejected candidates return to the idle list."""
+    import torch
+
+    if torch.device(device).type != "cuda" or k <= 1:
+        return [OwnStream(device) for _ in range(k)]
+    avoid = list(avoid)
+    while True:
+        chosen, rejected = [], []
+        for _ in range(tries + k):
+            if len(chosen) == k:
+                break
+            c = OwnStream(device)
+            if any(streams_share_queue(c.stream, o.stream) for o in chosen) or any(streams_share_queue(c.stream, o) for o in avoid):
+                rejected.append(c)
+            else:
+                chosen.append(c)
+        if len(chosen) == k or not avoid:
+            while len(chosen) < k:            # no luck at all: lanes that share a queue still give right frames
+                chosen.append(rejected.pop() if rejected else OwnStream(device))
+            for r in rejected:
+                r.release()
+            return chosen
+        for r in rejected + chosen:
+            r.release()
+        avoid.pop()
 
 
 def clock_probe_names():

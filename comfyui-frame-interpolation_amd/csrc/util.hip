@@ -117,6 +117,14 @@ void trace_end(hipStream_t s) {
 
 using namespace vfi;
 
+namespace vfi {
+// spins until `ticks` of s_memrealtime (100 MHz on gfx950) have passed: vfi_stream_spin
+__global__ void stream_spin_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+}  // namespace vfi
+
 extern "C" {
 
 int vfi_init(int device) {
@@ -174,6 +182,13 @@ int vfi_stream_create(void** stream_out) {
 int vfi_stream_destroy(void* stream) {
     VFI_REQUIRE(stream, "vfi_stream_destroy: null stream");
     VFI_CHECK_HIP(hipStreamDestroy((hipStream_t)stream));
+    return 0;
+}
+
+int vfi_stream_spin(void* stream, int microseconds) {
+    VFI_REQUIRE(microseconds > 0 && microseconds <= 100000, "vfi_stream_spin: %d us out of range (1 .. 100000)", microseconds);
+    hipLaunchKernelGGL(vfi::stream_spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)microseconds * 100ull);
+    VFI_CHECK_HIP(hipGetLastError());
     return 0;
 }
 

@@ -172,6 +172,9 @@ class FILM_VFI:
             # pair lanes (lanes.py): kept pair j runs on lane j % n_lanes = its own engine on its own stream (the bisection inside a
             # pair stays sequential on that stream); `main` only carries the bookkeeping events
             main = torch.cuda.current_stream(dev)
+            if hasattr(engine, "apart_from"):      # (a LaneSet) its streams stay clear of the copy streams' hardware queues where there are enough
+                from .hostpipe import _stream
+                engine.apart_from = [_stream(dev, "down"), _stream(dev, "up"), main]
             lane, n_lanes = lanes_of(engine, len(mine))
             up = Uploader(frames, order, dev, main, depth=min(max(4, n_lanes + 2), len(order)) or 1)
             keep, pos, released, pending = [], 0, 0, []

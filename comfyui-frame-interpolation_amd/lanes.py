@@ -49,6 +49,7 @@ class LaneSet:
             torch.cuda.synchronize(self.device)      # whatever the constructor queued (fills, uploads) is done before another stream reads it
         self._streams = []
         self._setup = None
+        self.apart_from = []      # torch streams that are busy beside the lanes (the node loops put their copy streams here)
 
     def configure(self, fn):
         """fn(engine): per-call settings of the node (IFRNet's embt, IFUNet's scale / ensemble) on every lane, present and future."""
@@ -60,8 +61,11 @@ class LaneSet:
         """-> (engine, stream) of lane i < k"""
         from . import _lib
 
-        while len(self._streams) <= i:
-            self._streams.append(_lib.OwnStream(self.device))      # not torch.cuda.Stream(): its pool of 32 hands one stream to two owners
+        if not self._streams:
+            # not torch.cuda.Stream(): its pool of 32 hands one stream to two owners.  All k at once, probed pairwise: streams that were
+            # bound to one hardware queue run strictly in turn (two such lanes = one), and a lane behind the copy-back stream's event
+            # waits stalls with it — `apart_from` lists the busy streams the lanes should stay clear of where the queues allow
+            self._streams = _lib.own_streams_apart(self.device, self.k, avoid=self.apart_from)
         while len(self.engines) <= i:
             with torch.cuda.stream(self._streams[len(self.engines)].stream):      # the constructor's device work is ordered with the lane's first pair
                 e = self._build()

@@ -169,6 +169,9 @@ def run_plan(engine, frames, plan, tasks, name="M2M VFI"):
     mine = tasks[lo:hi]
     # pair lanes (lanes.py): pair j runs on lane j % n_lanes = its own engine on its own stream; `main` only carries the bookkeeping
     # events (a frame's staging slot is released on main after main has waited for every lane that read it)
+    if isinstance(engine, LaneSet):      # the lanes' streams stay clear of the copy streams' hardware queues where there are enough of them
+        from .hostpipe import _stream
+        engine.apart_from = [_stream(dev, "down"), _stream(dev, "up"), main]
     lane, n_lanes = lanes_of(engine, len(mine))
     order = sorted({f for pair, _ in mine for f in (pair, pair + 1)})
     up = Uploader(frames, order, dev, main, depth=min(max(4, n_lanes + 2), len(order)) or 1)

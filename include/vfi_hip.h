@@ -493,6 +493,11 @@ int vfi_memcpy_async(void* dst, const void* src, int64_t bytes, int kind, void* 
  * the reference runs everything on torch's current stream (rife/__init__.py:195-230). */
 int vfi_stream_create(void** stream_out);
 int vfi_stream_destroy(void* stream);
+/* One workgroup that spins for `microseconds` of the device's real-time clock on `stream`: the probe with which a host finds out whether
+ * two of its streams were bound to the same hardware queue (the HIP runtime multiplexes streams onto a handful of them — 4 by default —
+ * and two streams of one queue run strictly one after the other: two pair lanes then overlap nothing).  Two spins on two streams take
+ * 1x the time on different queues and 2x on one. */
+int vfi_stream_spin(void* stream, int microseconds);
 
 /* Work done by one interpolate call for roofline accounting (algorithmic, per task). */
 int vfi_rife_work(vfi_rife_t* net, double* conv_flop_per_task, double* hbm_bytes_per_task);
