@@ -339,7 +339,7 @@ def own_streams_apart(device, k, avoid=(), tries=12):
     first, `avoid` is dropped stream by stream from its end when the candidates run out).  Rejected candidates return to the idle list."""
     import torch
 
-    if torch.device(device).type != "cuda" or k <= 1:
+    if torch.device(device).type != "cuda" or (k <= 1 and not avoid):
         return [OwnStream(device) for _ in range(k)]
     avoid = list(avoid)
     while True:

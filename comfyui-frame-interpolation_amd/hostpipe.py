@@ -117,8 +117,22 @@ def _stream(device, role):
     key = (str(device), role)
     st = _stream_cache.get(key)
     if st is None:
-        st = _stream_cache[key] = torch.cuda.Stream(device)
+        # r6: a library-made stream probed (vfi_stream_spin) to sit on another hardware queue than the compute stream and than the
+        # pipeline's other copy stream — "from a pool, round robin" left that to chance
+        from . import _lib
+
+        busy = [torch.cuda.current_stream(device)] + [v for (d, _), v in _stream_cache.items() if d == str(device)]
+        try:
+            own = _lib.own_streams_apart(device, 1, avoid=busy)[0]      # (wishes are dropped from the end when the queues run out: the compute stream last)
+            _stream_owned.append(own)
+            st = own.stream
+        except Exception:      # noqa: BLE001 — a plain pooled stream does the same work
+            st = torch.cuda.Stream(device)
+        _stream_cache[key] = st
     return st
+
+
+_stream_owned = []
 
 
 def _pool(name, n):
