@@ -51,6 +51,14 @@ def test_single_gpu_line(hip_lib):
     # r6: every leg that prints a number verifies it (FILM, M2M, the strong 4K x4 leg), and the multi-GPU keys exist at N = 1 too
     for leg in (res["other_paths"]["film_2x"], res["other_paths"]["m2m"], st):
         assert leg["parity"]["ok"] and leg["parity"]["values"] > 0 and "what" in leg["parity"], leg["parity"]
+    # late r6: the SURVEY 8(f) legs verify their frames too (GMFSS only on a vector whose oracle conditioning is certified — the 1080p one of
+    # the default run; at this test's size the object must exist and carry numbers), and every per-pair leg reports its pair lanes
+    for k in ("ifunet", "ifrnet_L"):
+        assert res["other_paths"][k]["parity"]["ok"] and res["other_paths"][k]["parity"]["n_over_1e-3"] == 0, res["other_paths"][k]["parity"]
+    assert "max_abs" in res["other_paths"]["gmfss_fortuna_union"]["parity"], res["other_paths"]["gmfss_fortuna_union"]["parity"]
+    for k in ("film_2x", "m2m", "gmfss_fortuna_union", "ifunet", "ifrnet_L"):
+        pl = res["other_paths"][k]["pair_lanes"]
+        assert "error" not in pl and pl["lanes"] >= 2 and pl["frames_per_s_2x"] > 0 and pl["vs_one_stream"] > 0.5, (k, pl)
     assert res["per_gpu_frames_per_s"] == res["value"] and res["n_ranks_seen_by_rccl"] == 1 and res["all_gather_ms_per_step"] is None
     assert "best of" in json.dumps(res.get("cpu_baseline", {"cores_policy": "best of"}))
     ck = res["clock"]
