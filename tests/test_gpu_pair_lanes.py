@@ -83,7 +83,7 @@ def test_film_node_lanes_bit_identical(lib, tmp_path, monkeypatch):
     monkeypatch.setattr(FM, "load_file_from_github_release", lambda model_type, ck: str(pth))
     import cfi_amd.lanes as LN
 
-    monkeypatch.setitem(LN.PAIRS_PER_LANE, "film", 1)      # (the node opens a FILM lane per 12 pairs; this clip has 4 kept ones)
+    monkeypatch.setitem(LN.PAIRS_PER_LANE, "film", 1)      # (the node opens a FILM lane per 24 pairs; this clip has 4 kept ones)
     frames = synth.smooth_frames(6, 64, 80, seed=2, shift=1.5, c=4)
     outs = {}
     for k in ("1", "3"):

@@ -25,7 +25,7 @@ def test_lane_count_follows_the_clip():
     ls = LN.LaneSet(FakeEngine, 3)
     assert [LN.lanes_of(ls, n)[1] for n in (1, 2, 3, 4, 5, 6, 7, 100)] == [1, 1, 1, 2, 2, 3, 3, 3]
     film = LN.LaneSet(FakeEngine, 2, pairs_per_lane=LN.PAIRS_PER_LANE["film"])
-    assert [LN.lanes_of(film, n)[1] for n in (4, 12, 23, 24, 200)] == [1, 1, 1, 2, 2]
+    assert [LN.lanes_of(film, n)[1] for n in (4, 24, 47, 48, 200)] == [1, 1, 1, 2, 2]
     one = LN.LaneSet(FakeEngine, 1)
     assert LN.lanes_of(one, 50)[1] == 1
     plain = FakeEngine()
@@ -54,4 +54,4 @@ def test_environment_override(monkeypatch):
     monkeypatch.setenv("VFI_PAIR_LANES", "1")
     assert LN.lanes_for("m2m") == 1 and LN.lane_set("gmfss", FakeEngine).k == 1
     monkeypatch.setenv("VFI_PAIR_LANES", "5")
-    assert LN.lane_set("film", FakeEngine).k == 5 and LN.lane_set("film", FakeEngine).pairs_per_lane == 12
+    assert LN.lane_set("film", FakeEngine).k == 5 and LN.lane_set("film", FakeEngine).pairs_per_lane == 24
