@@ -647,12 +647,22 @@ class GMFSS_Fortuna_VFI:
         assert len(frames) >= 2, f"VFI model GMFSS Fortuna requires at least 2 frames to work with, only found {frames.shape[0]}."
         if ckpt_name not in CKPTS_PATH_CONFIG:
             raise KeyError(ckpt_name)
-        sds = {part: _load(load_file_from_github_release(*loc)) for part, loc in CKPTS_PATH_CONFIG[ckpt_name].items()}
+        from .ckpt import cached_engine
         from .lanes import lane_set
-        engine = lane_set("gmfss", lambda: GMFSSEngine(sds))   # (the reference rebuilds the model on every call, gmfss_fortuna/__init__.py:129-130)
+        paths = {part: load_file_from_github_release(*loc) for part, loc in CKPTS_PATH_CONFIG[ckpt_name].items()}
+
+        def build():
+            sds = {part: _load(path) for part, path in paths.items()}
+            return lane_set("gmfss", lambda: GMFSSEngine(sds))
+        # (the reference rebuilds the model on every call, gmfss_fortuna/__init__.py:129-130.  Here the packed weights stay between calls —
+        # a constructor is 60-90 ms per lane — keyed by the variant and its fusion-net file; see ckpt.cached_engine)
+        engine, cached = cached_engine(MODEL_TYPE + ":" + ckpt_name, paths["fusionnet"], build)
         try:
             plan, tasks = generic_output_plan(len(frames), multiplier, optional_interpolation_states)
             return (run_plan(engine, frames, plan, tasks, name="GMFSS Fortuna VFI"),)
         finally:
             torch.cuda.synchronize(engine.device)
-            engine.close()
+            if cached:
+                engine.release_workspace()
+            else:
+                engine.close()

@@ -377,14 +377,24 @@ class IFUnet_VFI:
 
         assert len(frames) >= 2, f"VFI model IFUNet requires at least 2 frames to work with, only found {frames.shape[0]}."
         model_path = load_file_from_github_release(MODEL_TYPE, ckpt_name)
+        from .ckpt import cached_engine
+        from .lanes import configure as configure_lanes
         from .lanes import lane_set
-        sd = torch.load(model_path, map_location="cpu", weights_only=False)
-        engine = lane_set("ifunet", lambda: IFUNetEngine(sd))
+
+        def build():
+            sd = torch.load(model_path, map_location="cpu", weights_only=False)
+            return lane_set("ifunet", lambda: IFUNetEngine(sd))
+        # (the reference rebuilds the model on every call; here the packed weights stay between calls — the constructor, Winograd weight
+        # transforms of ~250 layers, is 0.4 s per lane; see ckpt.cached_engine)
+        engine, cached = cached_engine(MODEL_TYPE, model_path, build)
         sc, ens = float(scale_factor), bool(ensemble)
-        engine.configure(lambda e: (setattr(e, "scale", sc), setattr(e, "ensemble", ens)))
+        configure_lanes(engine, lambda e: (setattr(e, "scale", sc), setattr(e, "ensemble", ens)))
         try:
             plan, tasks = generic_output_plan(len(frames), multiplier, optional_interpolation_states)
             return (run_plan(engine, frames, plan, tasks, name="IFUnet VFI"),)
         finally:
             torch.cuda.synchronize(engine.device)
-            engine.close()
+            if cached:
+                engine.release_workspace()
+            else:
+                engine.close()

@@ -19,7 +19,9 @@ DEFAULT_LANES = {"m2m": 3, "film": 2, "gmfss": 3, "ifunet": 3, "ifrnet": 2}
 # A lane's first pair pays for its workspace (and, GMFSS / IFUNet, for its graph capture; FILM's first forward allocates its scratch
 # call by call and holds the host for a whole pair): a lane is only opened for this many pairs of the clip (measured at 1080p:
 # FILM with 2 lanes on 12 pairs 583 vs 567 ms and on 24 pairs 1128 vs 1122-1131 ms (the node releases and re-allocates every workspace per call), M2M with 3 lanes on 8 pairs 89 vs 76 ms — tools/node_e2e_models.py)
-PAIRS_PER_LANE = {"film": 24}
+# GMFSS / IFUNet: a lane's first two pairs of a call cost 150 / 130 ms more than steady ones (workspace fill, graph capture —
+# tools/engine_build_probe.py) against 5.5 / 5.3 ms gained per pair of the clip: two lanes from 64 pairs, three from 96.
+PAIRS_PER_LANE = {"film": 24, "gmfss": 32, "ifunet": 32}
 
 
 def lanes_for(model):
