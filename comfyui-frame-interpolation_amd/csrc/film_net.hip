@@ -69,7 +69,11 @@ struct vfi_film {
     // workspace for the current frame size
     int H = 0, W = 0;
     int hw[PYR][2];
-    Ten img[2][PYR], tw[2][PYR], flow[2][PYR], vres[PYR], vup[PYR], al[FUS];
+    Ten img[2][PYR], tw[2][PYR], flow[2][PYR], vres[2][PYR], vup[2][PYR], al[FUS];      // vres / vup: per flow direction (r6: the two run side by side)
+    // r6: image 1's feature extraction and the backward flow pyramid run on this side stream (another hardware queue) beside image 0's and
+    // the forward one: two independent halves of the network up to the fusion, each with coarse levels that fill a fraction of the device
+    hipStream_t side = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::map<std::tuple<std::string, int, int, int>, Ten> scratch;
     std::vector<float*> owned;
 };
@@ -107,7 +111,8 @@ int ensure_workspace(vfi_film* n, int H, int W) {
         for (int k = 0; k < 2; ++k) {
             if (alloc_ten(n, n->img[k][l], h, w, 8) || alloc_ten(n, n->tw[k][l], h, w, 4 + 2 * F) || alloc_ten(n, n->flow[k][l], h, w, 2)) return -1;
         }
-        if (alloc_ten(n, n->vres[l], h, w, 2) || alloc_ten(n, n->vup[l], h, w, 2)) return -1;
+        for (int d = 0; d < 2; ++d)
+            if (alloc_ten(n, n->vres[d][l], h, w, 2) || alloc_ten(n, n->vup[d][l], h, w, 2)) return -1;
         if (l < FUS && alloc_ten(n, n->al[l], h, w, n->cal[l] + (l < 4 ? FILTERS << std::min(l, 3) : 0))) return -1;
     }
     n->H = H, n->W = W;
@@ -146,7 +151,7 @@ int extract(vfi_film* n, int k, hipStream_t st) {
         for (int j = 0; j < depth; ++j) {
             const int lvl = i + j, h = n->hw[lvl][0], w = n->hw[lvl][1], c = FILTERS << j;
             Ten* mid;
-            if (tmp(n, "ext_mid", h, w, c, &mid)) return -1;
+            if (tmp(n, k ? "ext_mid1" : "ext_mid0", h, w, c, &mid)) return -1;
             if (conv(n->ext[j][0], *src, src_off, *mid, 0, h, w, 1, st)) return -1;
             int slot_off = 4;
             for (int q = 0; q < j; ++q) slot_off += FILTERS << q;    // position of sub[.][j] inside level lvl's features
@@ -154,7 +159,7 @@ int extract(vfi_film* n, int k, hipStream_t st) {
             if (j < depth - 1) {
                 const int h2 = n->hw[lvl + 1][0], w2 = n->hw[lvl + 1][1];
                 Ten* pooled;
-                if (tmp(n, "ext_pool", h2, w2, c, &pooled)) return -1;
+                if (tmp(n, k ? "ext_pool1" : "ext_pool0", h2, w2, c, &pooled)) return -1;
                 if (vfi_avgpool2(n->tw[k][lvl].p + slot_off, n->tw[k][lvl].c, pooled->p, c, 1, h, w, c, st)) return -1;
                 src = pooled, src_off = 0;
             }
@@ -176,21 +181,21 @@ int predict(vfi_film* n, int a, int b, int d, hipStream_t st) {
             if (ax(n->tw[b][l].p + 4, n->tw[b][l].c, nullptr, 0, pair.p + PO + F, pair.c, h, w, F, 1.f, 0.f, st)) return -1;
         } else {
             const int h1 = n->hw[l + 1][0], w1 = n->hw[l + 1][1];
-            if (vfi_resize_bilinear(n->flow[d][l + 1].p, 2, n->vup[l].p, 2, 1, h1, w1, h, w, 2, 2.0f, st)) return -1;
-            if (vfi_warp_film(n->tw[b][l].p + 4, n->tw[b][l].c, n->vup[l].p, 2, 1.0f, pair.p + PO + F, pair.c, 1, h, w, F, st)) return -1;
+            if (vfi_resize_bilinear(n->flow[d][l + 1].p, 2, n->vup[d][l].p, 2, 1, h1, w1, h, w, 2, 2.0f, st)) return -1;
+            if (vfi_warp_film(n->tw[b][l].p + 4, n->tw[b][l].c, n->vup[d][l].p, 2, 1.0f, pair.p + PO + F, pair.c, 1, h, w, F, st)) return -1;
         }
         const Layer* convs = n->pred[std::min(l, 3)];
         const int nf = kFlowFilters[std::min(l, 3)];
         Ten *t0, *t1, *t2;
-        if (tmp(n, "fe0", h, w, nf, &t0) || tmp(n, "fe1", h, w, nf, &t1) || tmp(n, "fe2", h, w, r8(nf / 2), &t2)) return -1;
+        if (tmp(n, d ? "fe0b" : "fe0", h, w, nf, &t0) || tmp(n, d ? "fe1b" : "fe1", h, w, nf, &t1) || tmp(n, d ? "fe2b" : "fe2", h, w, r8(nf / 2), &t2)) return -1;
         if (conv(convs[0], pair, PO, *t0, 0, h, w, 1, st) || conv(convs[1], *t0, 0, *t1, 0, h, w, 1, st) ||
             conv(convs[2], *t1, 0, *t0, 0, h, w, 1, st) || conv(convs[3], *t0, 0, *t2, 0, h, w, 1, st))
             return -1;
         if (l == PYR - 1) {
             if (conv(convs[4], *t2, 0, n->flow[d][l], 0, h, w, 0, st)) return -1;
         } else {
-            if (conv(convs[4], *t2, 0, n->vres[l], 0, h, w, 0, st)) return -1;
-            if (ax(n->vres[l].p, 2, n->vup[l].p, 2, n->flow[d][l].p, 2, h, w, 2, 1.f, 1.f, st)) return -1;   // v = v_residual + v
+            if (conv(convs[4], *t2, 0, n->vres[d][l], 0, h, w, 0, st)) return -1;
+            if (ax(n->vres[d][l].p, 2, n->vup[d][l].p, 2, n->flow[d][l].p, 2, h, w, 2, 1.f, 1.f, st)) return -1;   // v = v_residual + v
         }
     }
     return 0;
@@ -290,6 +295,11 @@ void vfi_film_destroy(vfi_film_t* net) {
         for (Layer& L : f) vfi_conv_destroy(L.h);
     for (Layer& L : net->fuse_up2) vfi_conv_destroy(L.h);
     vfi_conv_destroy(net->out_conv.h);
+    if (net->side) {
+        (void)hipStreamSynchronize(net->side);
+        for (hipEvent_t e : net->ev) (void)hipEventDestroy(e);
+        (void)hipStreamDestroy(net->side);
+    }
     free_workspace(net);
     delete net;
 }
@@ -307,15 +317,39 @@ int vfi_film_forward(vfi_film_t* net, const float* x0_dev, const float* x1_dev, 
     if (int rc = ensure_workspace(net, H, W)) return rc;
     hipStream_t st = (hipStream_t)stream;
     const float* xs[2] = {x0_dev, x1_dev};
-    for (int k = 0; k < 2; ++k) {
-        if (ax(xs[k], C, nullptr, 0, net->img[k][0].p, 8, H, W, 3, 1.f, 0.f, st)) return -1;
-        for (int l = 1; l < PYR; ++l)   // build_image_pyramid
-            if (vfi_avgpool2(net->img[k][l - 1].p, 8, net->img[k][l].p, 8, 1, net->hw[l - 1][0], net->hw[l - 1][1], 4, st)) return -1;
-        for (int l = 0; l < PYR; ++l)   // image part of the to-warp pyramids
-            if (ax(net->img[k][l].p, 8, nullptr, 0, net->tw[k][l].p, net->tw[k][l].c, net->hw[l][0], net->hw[l][1], 4, 1.f, 0.f, st)) return -1;
-        if (extract(net, k, st)) return -1;
+    // Two streams (option film_side): half k of the network — image k's pyramid and features, then the flow pyramid of direction k — runs
+    // on hs[k]; the halves meet twice: each flow estimator reads the OTHER image's features, and the fusion reads everything.
+    const bool two = option(kOptFilmSide) != 0;
+    if (two && !net->side) {
+        net->side = stream_apart_from(st);
+        VFI_REQUIRE(net->side, "vfi_film_forward: no side stream");
+        for (hipEvent_t& e : net->ev) VFI_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
-    if (predict(net, 0, 1, 0, st) || predict(net, 1, 0, 1, st)) return -1;   // forward / backward residual flow pyramids
+    hipStream_t hs[2] = {st, two ? net->side : st};
+    if (two) {
+        VFI_CHECK_HIP(hipEventRecord(net->ev[0], st));                 // the caller's frames (and the previous call's readers) are ordered on st
+        VFI_CHECK_HIP(hipStreamWaitEvent(net->side, net->ev[0], 0));
+    }
+    for (int k = 0; k < 2; ++k) {
+        hipStream_t s = hs[k];
+        if (ax(xs[k], C, nullptr, 0, net->img[k][0].p, 8, H, W, 3, 1.f, 0.f, s)) return -1;
+        for (int l = 1; l < PYR; ++l)   // build_image_pyramid
+            if (vfi_avgpool2(net->img[k][l - 1].p, 8, net->img[k][l].p, 8, 1, net->hw[l - 1][0], net->hw[l - 1][1], 4, s)) return -1;
+        for (int l = 0; l < PYR; ++l)   // image part of the to-warp pyramids
+            if (ax(net->img[k][l].p, 8, nullptr, 0, net->tw[k][l].p, net->tw[k][l].c, net->hw[l][0], net->hw[l][1], 4, 1.f, 0.f, s)) return -1;
+        if (extract(net, k, s)) return -1;
+    }
+    if (two) {      // each direction's estimator warps the partner's features into its own pyramid's slots
+        VFI_CHECK_HIP(hipEventRecord(net->ev[1], st));
+        VFI_CHECK_HIP(hipEventRecord(net->ev[2], net->side));
+        VFI_CHECK_HIP(hipStreamWaitEvent(st, net->ev[2], 0));
+        VFI_CHECK_HIP(hipStreamWaitEvent(net->side, net->ev[1], 0));
+    }
+    if (predict(net, 0, 1, 0, hs[0]) || predict(net, 1, 0, 1, hs[1])) return -1;   // forward / backward residual flow pyramids
+    if (two) {
+        VFI_CHECK_HIP(hipEventRecord(net->ev[3], net->side));
+        VFI_CHECK_HIP(hipStreamWaitEvent(st, net->ev[3], 0));
+    }
     // aligned pyramid: [warp(pyr0, 0.5*bwd) | warp(pyr1, 0.5*fwd) | 0.5*bwd | 0.5*fwd]
     for (int l = 0; l < FUS; ++l) {
         const int h = net->hw[l][0], w = net->hw[l][1], F = feat_channels(l);

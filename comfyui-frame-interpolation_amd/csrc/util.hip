@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -28,7 +29,7 @@ const char* get_error() { return g_err; }
 // ---- A/B options (vfi_common.h: enum Option) ---------------------------------------------------------------------------------
 static const struct { const char* name; long dflt; } kOptTable[kOptCount] = {
     {"stage_quad", 14}, {"fuse_encode", 1}, {"fuse0a", 1}, {"m2n2_px", -1}, {"grouped_variant", -1}, {"splitk", 1},
-    {"splat_atomic", 0}, {"splat_spill_cap", -1}, {"wino_xcd", 1}, {"deconv_wino", 1}, {"encode_batched", 1}, {"wino_quant", 1}, {"xcd_bands", 0}, {"m2m_fused", 1}, {"m2m_side", 0}, {"wino_probe", 0},
+    {"splat_atomic", 0}, {"splat_spill_cap", -1}, {"wino_xcd", 1}, {"deconv_wino", 1}, {"encode_batched", 1}, {"wino_quant", 1}, {"xcd_bands", 0}, {"m2m_fused", 1}, {"m2m_side", 0}, {"film_side", 1}, {"wino_probe", 0},
 };
 static std::atomic<long> g_opt[kOptCount];
 static std::atomic<bool> g_opt_init{false};
@@ -118,6 +119,32 @@ void trace_end(hipStream_t s) {
 using namespace vfi;
 
 namespace vfi {
+// A new stream that the HIP runtime has bound to another hardware queue than `st`.  The runtime multiplexes streams onto 4 hardware queues,
+// bound at first use; two streams of one queue run strictly in turn, so a fork onto such a stream overlaps nothing.  Decided by
+// measurement: a spinning workgroup on each (vfi_stream_spin), 1x the spin apart, 2x together.  Rejected candidates stay alive (the next
+// one is then bound elsewhere); after 8 tries the last one is used as it is (right frames, no overlap).
+hipStream_t stream_apart_from(hipStream_t st) {
+    hipStream_t c = nullptr;
+    for (int t = 0; t < 8; ++t) {
+        if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        vfi_stream_spin(c, 1);
+        vfi_stream_spin(st, 1);
+        int together = 0;
+        for (int r = 0; r < 3; ++r) {
+            (void)hipStreamSynchronize(st);
+            (void)hipStreamSynchronize(c);
+            const auto t0 = std::chrono::steady_clock::now();
+            vfi_stream_spin(st, 300);
+            vfi_stream_spin(c, 300);
+            (void)hipStreamSynchronize(st);
+            (void)hipStreamSynchronize(c);
+            together += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > 480.0;
+        }
+        if (together < 2) return c;
+    }
+    return c;
+}
+
 // spins until `ticks` of s_memrealtime (100 MHz on gfx950) have passed: vfi_stream_spin
 __global__ void stream_spin_kernel(unsigned long long ticks) {
     const unsigned long long t0 = wall_clock64();

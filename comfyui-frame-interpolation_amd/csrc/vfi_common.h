@@ -73,10 +73,13 @@ enum Option {
     kOptXcdBands,        // 1: XCD-aware workgroup order of the RIFE gather kernels (final blend, quad transitions), 0: plain order (default: r6 A/B measured the banded order 2-5 % SLOWER, profiles/r06_xcd_bands_ab.txt)
     kOptM2mFused,        // 1: M2M render as one kernel (m2m_render.hip; default), 0: splat inputs + summation splat + combine as separate launches
     kOptM2mSide,         // 1: M2M prepare runs the image-pyramid convolutions (EncDec's c features) on a side stream beside the PWC flow network, 0: one stream (default: r6 A/B measured the fork neutral on one pair — 7.00-7.04 vs 7.0-7.1 ms — and 8 % SLOWER under three pair lanes)
+    kOptFilmSide,        // 1: FILM forward runs image 1's feature extraction and the backward flow pyramid on a side stream (another hardware queue) beside image 0's / the forward one, 0: one stream
     kOptWinoProbe,       // 1..4: the hot Winograd instantiation takes its cycle-ledger form (conv_wino.hip: g_wino_probe_out; default 0)
     kOptCount
 };
 long option(Option o);
+// a new stream that the runtime has bound to another hardware queue than `st` (decided by measurement with vfi_stream_spin; util.hip)
+hipStream_t stream_apart_from(hipStream_t st);
 int option_set(const char* name, long value);      // 0, or -2 for an unknown name
 int variant_override(const char* trace_name);      // tile variant forced for a trace name (vfi_test_variant_override), -1 = none
 

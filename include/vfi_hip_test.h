@@ -38,7 +38,7 @@ int64_t vfi_test_pack_deconv3x3(const float* weight_host, const float* bias_host
 
 /* A/B options of tools/ and tests/: each selects between two CORRECT forms of a kernel or launch (csrc/vfi_common.h, enum Option):
  *   stage_quad (bit mask, default 14), fuse_encode (1), fuse0a (1), m2n2_px (-1), grouped_variant (-1), splitk (1), splat_atomic (0; 1 = LDS-atomic tile kernel, 3 = staged list gather with compaction for C == 4),
- *   splat_spill_cap (-1), wino_xcd (1), deconv_wino (1), encode_batched (1), wino_quant (1), m2m_fused (1: M2M render as one kernel), m2m_side (0; 1: M2M prepare forks its image-pyramid convolutions onto a side stream — measured neutral / slower under pair lanes), xcd_bands (0), wino_probe (0; 1..4 = the cycle-ledger forms of the hot
+ *   splat_spill_cap (-1), wino_xcd (1), deconv_wino (1), encode_batched (1), wino_quant (1), m2m_fused (1: M2M render as one kernel), m2m_side (0; 1: M2M prepare forks its image-pyramid convolutions onto a side stream — measured neutral / slower under pair lanes), film_side (1: FILM forward on two streams — image 1's feature extraction and the backward flow pyramid beside image 0's / the forward one), xcd_bands (0), wino_probe (0; 1..4 = the cycle-ledger forms of the hot
  *   Winograd instantiation: same results, s_memtime stamps summed per wave of workgroup 0).
  * The product library reads NO experiment switch from the environment and does not contain this call: the defaults are all it can run.
  * Returns 0, or -2 for an unknown name. */

@@ -210,3 +210,27 @@ def test_config2_film_1080p(engine, sd):
         want = film_oracle.film_forward(sd, x[0:1], x[1:2])[0].permute(1, 2, 0)
     got = engine.forward(fr[0].cuda().contiguous(), fr[1].cuda().contiguous()).cpu()
     assert (got - want).abs().max().item() <= 1e-3, describe_diff(got, want, "film 1080p")
+
+
+@pytest.mark.parametrize("h,w", [(64, 80), (270, 480), (1080, 1920)])
+def test_two_stream_forward_equals_one_stream(lib, sd, h, w):
+    """r6: vfi_film_forward runs image 1's feature extraction and the backward flow pyramid on the object's side stream (option film_side)
+    beside image 0's and the forward one.  Same kernels on the same tensors: bit-identical frames, call after call (the next call's side
+    work must wait for the previous call's fusion)."""
+    from cfi_amd.film import FilmEngine
+
+    fr = synth.smooth_frames(3, h, w, seed=4, shift=2.0)
+    x = [f.cuda().contiguous() for f in fr]
+    eng = FilmEngine(sd)
+    try:
+        outs = {}
+        for mode in (1, 0, 1, 1):
+            assert lib.vfi_test_set_option(b"film_side", mode) == 0
+            outs.setdefault(mode, []).append([eng.forward(x[a], x[b]).cpu() for a, b in ((0, 1), (1, 2), (2, 0), (0, 1))])
+        for k in range(4):
+            assert torch.equal(outs[1][0][k], outs[0][0][k]), describe_diff(outs[1][0][k], outs[0][0][k], f"two streams vs one, call {k}")
+            assert torch.equal(outs[1][0][k], outs[1][1][k]) and torch.equal(outs[1][0][k], outs[1][2][k]), "run-to-run determinism"
+        assert torch.equal(outs[1][0][0], outs[1][0][3]), "the same pair again"
+    finally:
+        lib.vfi_test_set_option(b"film_side", 1)
+        eng.close()
