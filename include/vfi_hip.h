@@ -134,7 +134,9 @@ typedef struct vfi_film vfi_film_t;
 vfi_film_t* vfi_film_create(const float* const* tensors, const int64_t* numels, int n_tensors);
 void vfi_film_destroy(vfi_film_t* net);
 /* out_dev [H,W,3] = Interpolator(x0, x1) for x0_dev, x1_dev [H,W,C] fp32 (C >= 3, alpha ignored); clamp != 0 applies the
- * node's prediction.clamp(0, 1) (film/__init__.py:39).  H, W >= 64.  The workspace (15 GB at 1080p) is sized on first use. */
+ * node's prediction.clamp(0, 1) (film/__init__.py:39).  H, W >= 64.  The workspace (15 GB at 1080p) is sized on first use.
+ * All work is ordered on `stream` as seen by the caller; inside, half of the network up to the fusion runs on a side stream of the
+ * object's own (forked from and joined to `stream` by events within the call: round 6, docs/design/film.md). */
 int vfi_film_forward(vfi_film_t* net, const float* x0_dev, const float* x1_dev, int C, int H, int W, float* out_dev, int clamp,
                      void* stream);
 int vfi_film_release_workspace(vfi_film_t* net);
