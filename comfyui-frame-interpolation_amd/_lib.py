@@ -159,6 +159,7 @@ PROTOTYPES = {
     "vfi_film_destroy": (None, [C.c_void_p]),
     "vfi_film_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "vfi_film_release_workspace": (C.c_int, [C.c_void_p]),
+    "vfi_film_two_streams": (C.c_int, [C.c_void_p, C.c_int]),
     "vfi_film_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_int_p, C.c_int, C.c_void_p, C.c_void_p,
                                C.POINTER(C.c_int64)]),
     "vfi_m2m_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_int_p, C.c_int, C.c_void_p, C.c_void_p,

@@ -72,6 +72,7 @@ struct vfi_film {
     Ten img[2][PYR], tw[2][PYR], flow[2][PYR], vres[2][PYR], vup[2][PYR], al[FUS];      // vres / vup: per flow direction (r6: the two run side by side)
     // r6: image 1's feature extraction and the backward flow pyramid run on this side stream (another hardware queue) beside image 0's and
     // the forward one: two independent halves of the network up to the fusion, each with coarse levels that fill a fraction of the device
+    bool two_streams = true;       // vfi_film_two_streams
     hipStream_t side = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::map<std::tuple<std::string, int, int, int>, Ten> scratch;
@@ -304,6 +305,13 @@ void vfi_film_destroy(vfi_film_t* net) {
     delete net;
 }
 
+int vfi_film_two_streams(vfi_film_t* net, int on) {
+    VFI_REQUIRE(net, "vfi_film_two_streams: null handle");
+    const int before = net->two_streams ? 1 : 0;
+    net->two_streams = on != 0;
+    return before;
+}
+
 int vfi_film_release_workspace(vfi_film_t* net) {
     VFI_REQUIRE(net, "vfi_film_release_workspace: null handle");
     VFI_CHECK_HIP(hipDeviceSynchronize());
@@ -319,7 +327,7 @@ int vfi_film_forward(vfi_film_t* net, const float* x0_dev, const float* x1_dev, 
     const float* xs[2] = {x0_dev, x1_dev};
     // Two streams (option film_side): half k of the network — image k's pyramid and features, then the flow pyramid of direction k — runs
     // on hs[k]; the halves meet twice: each flow estimator reads the OTHER image's features, and the fusion reads everything.
-    const bool two = option(kOptFilmSide) != 0;
+    const bool two = net->two_streams && option(kOptFilmSide) != 0;
     if (two && !net->side) {
         net->side = stream_apart_from(st);
         VFI_REQUIRE(net->side, "vfi_film_forward: no side stream");

@@ -140,6 +140,10 @@ void vfi_film_destroy(vfi_film_t* net);
 int vfi_film_forward(vfi_film_t* net, const float* x0_dev, const float* x1_dev, int C, int H, int W, float* out_dev, int clamp,
                      void* stream);
 int vfi_film_release_workspace(vfi_film_t* net);
+/* on != 0 (the default): vfi_film_forward forks half of the network onto the object's side stream; 0: everything on the caller's stream —
+ * what a host that already keeps several pairs in flight on streams of its own (the nodes' pair lanes) wants: four busy streams on the
+ * runtime's four hardware queues left the lanes 2 % slower than two.  Frames are bit-identical either way.  Returns the previous setting. */
+int vfi_film_two_streams(vfi_film_t* net, int on);
 
 /* The whole FILM node call for a HOST clip, replacing FILM_VFI.vfi's body, vfi_models/film/__init__.py:63-113:
  * frames_host [N,H,W,C] fp32 (C >= 3; alpha dropped) -> out_host [*n_out,H,W,3].  Per kept pair: frame_i, then the m-1 new frames

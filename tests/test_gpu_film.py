@@ -231,6 +231,9 @@ def test_two_stream_forward_equals_one_stream(lib, sd, h, w):
             assert torch.equal(outs[1][0][k], outs[0][0][k]), describe_diff(outs[1][0][k], outs[0][0][k], f"two streams vs one, call {k}")
             assert torch.equal(outs[1][0][k], outs[1][1][k]) and torch.equal(outs[1][0][k], outs[1][2][k]), "run-to-run determinism"
         assert torch.equal(outs[1][0][0], outs[1][0][3]), "the same pair again"
+        assert eng.two_streams(False) is True      # the product switch (vfi_film_two_streams): the node turns the fork off under pair lanes
+        one = eng.forward(x[0], x[1]).cpu()
+        assert eng.two_streams(True) is False and torch.equal(one, outs[1][0][0])
     finally:
         lib.vfi_test_set_option(b"film_side", 1)
         eng.close()
