@@ -245,9 +245,9 @@ def pair_lanes_rate(dev, build, step, model, n_pairs=12, first=None):
 
             rates = {}
             for width in (1, k):
-                for e, _ in pairs:      # FILM: the forward's own two-stream fork is for a lone pair (film.py does the same when lanes open)
-                    if hasattr(e, "two_streams"):
-                        e.two_streams(width == 1)
+                for e, _ in pairs:      # FILM / IFUNet: an engine's own two-stream fork is for a lone pair (lanes.tell_lone_pair in the node loops)
+                    if hasattr(e, "lone_pair"):
+                        e.lone_pair(width == 1)
                 run(2 * width, width)
                 torch.cuda.synchronize(dev)
                 t0 = time.perf_counter()
@@ -259,8 +259,8 @@ def pair_lanes_rate(dev, build, step, model, n_pairs=12, first=None):
                     "what": "%d pairs round robin over %d engines on %d HIP streams (the node loop for clips of > 1 pair; frames bit-identical to one "
                             "stream: tests/test_gpu_pair_lanes.py)" % (n_pairs, k, k)}
         finally:
-            if first is not None and hasattr(first, "two_streams"):
-                first.two_streams(True)
+            if first is not None and hasattr(first, "lone_pair"):
+                first.lone_pair(True)
             lanes.close()
     except Exception as e:  # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"}

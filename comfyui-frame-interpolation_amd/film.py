@@ -25,8 +25,7 @@ import torch
 
 from . import _lib
 from .ckpt import cached_engine, load_file_from_github_release
-from .lanes import configure as configure_lanes
-from .lanes import lane_set, lanes_of
+from .lanes import lane_set, lanes_of, tell_lone_pair
 from .dist import all_gather_frames, world
 from .film_spec import check_state_dict, film_shapes
 from .schedule import InterpolationStateList, shard_tasks
@@ -67,6 +66,8 @@ class FilmEngine:
         """vfi_film_forward forks half of the network onto the object's side stream (default) / stays on the caller's stream (what the
         node wants once several pairs are in flight on lanes of their own).  Bit-identical frames either way."""
         return bool(self.lib.vfi_film_two_streams(self.handle, int(bool(on))))
+
+    lone_pair = two_streams      # lanes.tell_lone_pair
 
     def debug_flow(self, d, level, h, w):
         """test tap: flow pyramid level of the last forward, direction d (0 forward, 1 backward) -> [h,w,2] host tensor"""
@@ -182,8 +183,7 @@ class FILM_VFI:
                 from .hostpipe import _stream
                 engine.apart_from = [_stream(dev, "down"), _stream(dev, "up"), main]
             lane, n_lanes = lanes_of(engine, len(mine))
-            # lanes already keep the device's hardware queues busy: the forward's own two-stream fork is for a lone pair (every lane, present and future)
-            configure_lanes(engine, lambda e, one=(n_lanes == 1): e.two_streams(one) if hasattr(e, "two_streams") else None)
+            tell_lone_pair(engine, n_lanes)      # the forward's own two-stream fork is for a lone pair
             up = Uploader(frames, order, dev, main, depth=min(max(4, n_lanes + 2), len(order)) or 1)
             keep, pos, released, pending = [], 0, 0, []
             try:

@@ -95,7 +95,7 @@ class IFUNetEngine(OpsEngine):
         """CBAM.forward (:499-503) -> new tensor"""
         n, h, w, c = x.shape
         stats, scale = self._t("cb_stats_" + tag, n, c, 2), self._t("cb_scale_" + tag, n, c)
-        ws = self._t("cb_ws", n * 512 * c * 3)
+        ws = self._t("cb_ws_" + tag, n * 512 * c * 3)      # (per pass: two ensemble passes of block 0 run side by side)
         self._c("vfi_channel_pool", _p(x), c, c, n, h * w, _p(stats), ws.data_ptr(), ws.numel() * 4)
         self._c("vfi_cbam_gate", _p(stats), _p(P["w1"]), _p(P["b1"]), _p(P["w2"]), _p(P["b2"]), c, P["w1"].shape[0], n, _p(scale))
         xs, comp = self._t("cb_xs_" + tag, n, h, w, c), self._t("cb_comp_" + tag, n * h * w, 2)
@@ -163,13 +163,19 @@ class IFUNetEngine(OpsEngine):
         return hs, ws
 
     # ---- IFUNetModel.forward -------------------------------------------------------------------------------------------
+    fork_stages = True      # independent stages of a call on two streams (tests A/B it; frames are bit-identical)
+
+    def lone_pair(self, on):
+        """lanes.tell_lone_pair: fork only when this is the only pair in flight"""
+        self.fork_stages = bool(on)
+
     def forward(self, frame0, frame1, t, out, scale=None, ensemble=None):
         s = float(self.scale if scale is None else scale)
         ens = bool(self.ensemble if ensemble is None else ensemble)
         t = float(t)
         assert frame1.shape == frame0.shape and frame0.shape[2] >= 3 and frame0.is_contiguous() and frame1.is_contiguous()
         # one HIP graph per (frame shape, timestep, scale, ensemble): the ~2000 launches of a call replay without the interpreter
-        self._replayable(("forward",) + tuple(frame0.shape) + (t, s, ens), (frame0, frame1), (out,),
+        self._replayable(("forward",) + tuple(frame0.shape) + (t, s, ens, self.fork_stages), (frame0, frame1), (out,),
                          lambda f0, f1, o: self._forward(f0, f1, t, o, s, ens))
         return out
 
@@ -188,7 +194,7 @@ class IFUNetEngine(OpsEngine):
                 self._c("vfi_fill_channels", _p(dst, 6), dst.shape[-1], 1, px, tt)
             flow, delta, flow2 = self._t("flow", 1, Hp, Wp, 4), self._t("delta", 1, Hp, Wp, 4), self._t("flow2", 1, Hp, Wp, 4)
 
-            def estimate(i, xin, nimg, with_flow, tag):
+            def estimate(i, xin, nimg, with_flow, tag, dst=None):
                 if s != 1.0:
                     xs = self._t(f"xs{nimg}_{tag}", 1, hs, ws, xin.shape[-1])
                     self._resize(xin, 0, xs, 0, nimg)
@@ -198,14 +204,26 @@ class IFUNetEngine(OpsEngine):
                     xs = xin
                     if with_flow:
                         self._ax(flow, 0, None, 0, xs, 13, 4)
-                self._if_block(i, self._feature_net(xs, i, tag), delta, tag)
+                self._if_block(i, self._feature_net(xs, i, tag), delta if dst is None else dst, tag)
 
             def stage(fn, *a):      # the temporaries of one stage (feature net + IFBlock, RRDBNet, a ResynNet pass) die with it
                 with self._scope():
                     return fn(*a)
 
             for i in range(3):
-                if i == 0:
+                if i == 0 and ens and self.fork_stages and self._fork()[1] is not None:
+                    # r6: block 0 takes no flow, so its two ensemble passes are independent: the swapped one runs on the side stream
+                    # (one scope holds the temporaries of both until the join)
+                    with self._scope():
+                        cur, side = self._fork()
+                        delta_b = self._t("delta_b", 1, Hp, Wp, 4)
+                        with torch.cuda.stream(side):
+                            estimate(0, x7e, 7, False, "b", delta_b)
+                        estimate(0, x7, 7, False, "a")
+                        self._join(cur, side)
+                        self._ax(delta, 0, None, 0, flow, 0, 4)
+                        self._ax(flow, 0, delta_b, 0, flow, 0, 4, 0.5, 0.5)        # (flow + flow2) / 2
+                elif i == 0:
                     stage(estimate, 0, x7, 7, False, "a")
                     self._ax(delta, 0, None, 0, flow, 0, 4)
                     if ens:
@@ -225,12 +243,20 @@ class IFUNetEngine(OpsEngine):
             stage(self._rrdbnet, x17, flow)
             deg = self._t("deg", 1, Hp, Wp, 4)
             self._c("vfi_lerp_mask", _p(x17, 7), 24, _p(x17, 10), 24, _p(mask), mask.shape[-1], _p(deg), 4, 3, px)
-            imgs, masks = [], []
-            for k in (0, 1):
-                img, m = self._t(f"rs_img_i{k}", 1, Hp, Wp, 4), self._t(f"rs_mask_i{k}", 1, Hp, Wp, 1)
-                stage(self._resyn, x17, 3 * k, deg, f"i{k}")
-                imgs.append(img)
-                masks.append(m)
+            imgs = [self._t(f"rs_img_i{k}", 1, Hp, Wp, 4) for k in (0, 1)]
+            masks = [self._t(f"rs_mask_i{k}", 1, Hp, Wp, 1) for k in (0, 1)]
+            # r6: the two ResynNet passes (image 0, image 1) are independent: the second runs on the engine's side stream beside the first.
+            # ONE scope holds the temporaries of both until the join (a scope that ended earlier would hand its blocks to the other pass).
+            with self._scope():
+                cur, side = self._fork() if self.fork_stages else (None, None)
+                if side is not None:
+                    with torch.cuda.stream(side):
+                        self._resyn(x17, 3, deg, "i1")
+                    self._resyn(x17, 0, deg, "i0")
+                    self._join(cur, side)
+                else:
+                    self._resyn(x17, 0, deg, "i0")
+                    self._resyn(x17, 3, deg, "i1")
             self._c("vfi_ifunet_blend", _p(imgs[0]), _p(imgs[1]), _p(deg), 4, _p(masks[0]), _p(masks[1]), 1, out.data_ptr(), Hp, Wp, H, W)
             return out
 
@@ -278,33 +304,34 @@ class IFUNetEngine(OpsEngine):
         """ResynNet.calflow (:139-161) for the image at channels ioff..ioff+2 of x17 -> (refined image [1,Hp,Wp,4], mask [1,Hp,Wp,1])"""
         _, Hp, Wp, _ = x17.shape
         px = Hp * Wp
-        y = self._t("rs_y_" + tag, 1, Hp, Wp, 16)          # img 3 | deg 3 | warped 3 | mask 1 | (flow 2 after the resize) | pad
+        T = lambda name, *shape: self._t(f"{name}_{tag}", *shape)      # every temporary carries the pass's tag: the two passes run side by side (r6)
+        y = T("rs_y", 1, Hp, Wp, 16)          # img 3 | deg 3 | warped 3 | mask 1 | (flow 2 after the resize) | pad
         self._ax(x17, ioff, None, 0, y, 0, 3)
         self._ax(deg, 0, None, 0, y, 3, 3)
-        flow, mask = self._t("rs_flow_" + tag, 1, Hp, Wp, 2), self._t("rs_mask_" + tag, 1, Hp, Wp, 1)
-        df, dm = self._t("rs_df", 1, Hp, Wp, 2), self._t("rs_dm", 1, Hp, Wp, 1)
+        flow, mask = T("rs_flow", 1, Hp, Wp, 2), T("rs_mask", 1, Hp, Wp, 1)
+        df, dm = T("rs_df", 1, Hp, Wp, 2), T("rs_dm", 1, Hp, Wp, 1)
         for b, sc in enumerate((4, 2, 1)):
             conv0, convblock, last = self.s_blocks[b]
             h, w = Hp // sc, Wp // sc
-            xs = self._t(f"rs_xs{b}", 1, h, w, 16)
+            xs = T(f"rs_xs{b}", 1, h, w, 16)
             self._resize(y, 0, xs, 0, 6 if b == 0 else 10)
             if b > 0:
                 self._resize(flow, 0, xs, 10, 2, 1.0 / sc)
             cur = xs
             for i, L in enumerate(conv0):
                 h, w = h // 2, w // 2
-                nxt = self._t(f"rs_c{b}_{i}", 1, h, w, L["cout"])
+                nxt = T(f"rs_c{b}_{i}", 1, h, w, L["cout"])
                 self._conv(L, cur, 0, nxt, 0)
                 cur = nxt
             feat = cur
-            p, q = self._t(f"rs_p{b}", 1, h, w, 256), self._t(f"rs_q{b}", 1, h, w, 256)
+            p, q = T(f"rs_p{b}", 1, h, w, 256), T(f"rs_q{b}", 1, h, w, 256)
             for i, L in enumerate(convblock):
                 nxt = p if i % 2 == 0 else q
                 self._conv(L, cur, 0, nxt, 0)
                 cur = nxt
             s = p if cur is q else q
             self._ax(cur, 0, feat, 0, s, 0, 256)                                # convblock(feat) + feat
-            tmp = self._t(f"rs_t{b}", 1, 2 * h, 2 * w, 8)
+            tmp = T(f"rs_t{b}", 1, 2 * h, 2 * w, 8)
             self._conv(last, s, 0, tmp, 0)
             self._resize(tmp, 0, df, 0, 2, float(sc * 4))                       # tmp[:, :2] * scale * 4 after interpolate(scale * 4)
             self._resize(tmp, 2, dm, 0, 1)
@@ -317,24 +344,24 @@ class IFUNetEngine(OpsEngine):
             self._c("vfi_warp_rife", _p(y, 0), 16, _p(flow), 2, _p(y, 6), 16, 1, Hp, Wp, 3)     # warped_img0 = warp(img0, flow)
             self._ax(mask, 0, None, 0, y, 9, 1)
         h, w = Hp // 4, Wp // 4
-        fdown = self._t("rs_fdown", 1, h, w, 2)
+        fdown = T("rs_fdown", 1, h, w, 2)
         self._resize(flow, 0, fdown, 0, 2, 0.25)
-        cat = self._t("rs_cat", 1, h, w, 64)
+        cat = T("rs_cat", 1, h, w, 64)
         for k, (c0, c1) in enumerate(self.s_ctx):           # context0(img0) warped by the down-scaled flow | context1(warped_img0)
-            src = self._t(f"rs_src{k}", 1, Hp, Wp, 8)
+            src = T(f"rs_src{k}", 1, Hp, Wp, 8)
             self._ax(y, 0 if k == 0 else 6, None, 0, src, 0, 3)
-            a, bq = self._t(f"rs_ca{k}", 1, Hp // 2, Wp // 2, 16), self._t(f"rs_cb{k}", 1, h, w, 32)
+            a, bq = T(f"rs_ca{k}", 1, Hp // 2, Wp // 2, 16), T(f"rs_cb{k}", 1, h, w, 32)
             self._conv(c0, src, 0, a, 0)
             self._conv(c1, a, 0, bq, 0)
             if k == 0:
                 self._c("vfi_warp_rife", _p(bq), 32, _p(fdown), 2, _p(cat, 0), 64, 1, h, w, 32)
             else:
                 self._ax(bq, 0, None, 0, cat, 32, 32)
-        d1, d2 = self._t("rs_d1", 1, Hp // 2, Wp // 2, 32), self._t("rs_d2", 1, Hp, Wp, 8)
+        d1, d2 = T("rs_d1", 1, Hp // 2, Wp // 2, 32), T("rs_d2", 1, Hp, Wp, 8)
         self._conv(self.s_dec[0], cat, 0, d1, 0)
         self._conv(self.s_dec[1], d1, 0, d2, 0)
         self._c("vfi_tanh_scale", _p(d2), 8, 3, px, 1.0)
-        img = self._t("rs_img_" + tag, 1, Hp, Wp, 4)
+        img = T("rs_img", 1, Hp, Wp, 4)
         self._c("vfi_add_clamp01", _p(y, 6), 16, _p(d2), 8, _p(img), 4, 3, px)
         return img, mask
 

@@ -50,12 +50,13 @@ class LaneSet:
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)      # whatever the constructor queued (fills, uploads) is done before another stream reads it
         self._streams = []
-        self._setup = None
+        self._setup = {}           # key -> fn(engine): applied to every lane, present and future (configure)
         self.apart_from = []      # torch streams that are busy beside the lanes (the node loops put their copy streams here)
 
-    def configure(self, fn):
-        """fn(engine): per-call settings of the node (IFRNet's embt, IFUNet's scale / ensemble) on every lane, present and future."""
-        self._setup = fn
+    def configure(self, fn, key="node"):
+        """fn(engine): per-call settings (the node's: IFRNet's embt, IFUNet's scale / ensemble; the loop's: lone_pair) on every lane,
+        present and future.  A later call with the same key replaces the earlier one."""
+        self._setup[key] = fn
         for e in self.engines:
             fn(e)
 
@@ -71,8 +72,8 @@ class LaneSet:
         while len(self.engines) <= i:
             with torch.cuda.stream(self._streams[len(self.engines)].stream):      # the constructor's device work is ordered with the lane's first pair
                 e = self._build()
-                if self._setup is not None:
-                    self._setup(e)
+                for fn in self._setup.values():
+                    fn(e)
             self.engines.append(e)
         return self.engines[i], self._streams[i].stream
 
@@ -91,12 +92,20 @@ class LaneSet:
         self._streams = []
 
 
-def configure(engine, fn):
+def configure(engine, fn, key="node"):
     """fn(engine) on a plain engine, on every lane of a LaneSet"""
     if isinstance(engine, LaneSet):
-        engine.configure(fn)
+        engine.configure(fn, key)
     else:
         fn(engine)
+
+
+def tell_lone_pair(engine, n_lanes):
+    """Engines that fork one pair's independent stages onto a side stream of their own (FILM's two image / flow halves, IFUNet's
+    ensemble and ResynNet passes) do so only when theirs is the only pair in flight: with pair lanes open the device's four
+    hardware queues are taken (FILM: two lanes 42.0 ms per pair without the inner fork, 42.9 with it)."""
+    one = n_lanes == 1
+    configure(engine, lambda e: e.lone_pair(one) if hasattr(e, "lone_pair") else None, key="lone_pair")
 
 
 def lanes_of(engine, n_pairs):

@@ -157,7 +157,7 @@ def run_plan(engine, frames, plan, tasks, name="M2M VFI"):
         return out
 
     from .hostpipe import OutputWriter, Uploader
-    from .lanes import lanes_of
+    from .lanes import lanes_of, tell_lone_pair
     main = torch.cuda.current_stream(dev)
     wr = OutputWriter(len(plan), H, W, dev)
     new_row = {}
@@ -173,6 +173,7 @@ def run_plan(engine, frames, plan, tasks, name="M2M VFI"):
         from .hostpipe import _stream
         engine.apart_from = [_stream(dev, "down"), _stream(dev, "up"), main]
     lane, n_lanes = lanes_of(engine, len(mine))
+    tell_lone_pair(engine, n_lanes)
     order = sorted({f for pair, _ in mine for f in (pair, pair + 1)})
     up = Uploader(frames, order, dev, main, depth=min(max(4, n_lanes + 2), len(order)) or 1)
     item_of = {f: i for i, f in enumerate(order)}

@@ -105,6 +105,7 @@ class OpsEngine:
         self._live = [{}]
         self.conv_flop = None      # set to 0 to count the direct-form FLOP of every convolution launched from here on (bench.py other_paths)
         self._graphs, self._cap_stream = {}, None
+        self._sides = {}           # hipStream_t of a caller's stream -> the OwnStream this engine forks onto beside it (_fork)
 
     # ---- HIP graphs -------------------------------------------------------------------------------------------------
     def _replayable(self, key, ins, outs, fn):
@@ -157,6 +158,26 @@ class OpsEngine:
         for a, b in zip(outs, sout):
             a.copy_(b, non_blocking=True)
         return ret
+
+    # ---- two independent stages side by side ----------------------------------------------------------------------------
+    def _fork(self):
+        """-> (current stream, side stream) with the side stream ordered after everything queued on the current one, or (None, None) where
+        there is nothing to fork onto (the CPU test double).  The side stream is the engine's own, probed onto ANOTHER hardware queue
+        than the current stream (two streams of one queue run in turn: _lib.streams_share_queue) — once per current stream: the eager
+        first call and the warm-up run in front of a graph capture do the probing, the capture itself finds the choice made."""
+        if self.device.type != "cuda" or not isinstance(self.be, _Device):
+            return None, None
+        cur = torch.cuda.current_stream(self.device)
+        own = self._sides.get(cur.cuda_stream)
+        if own is None:
+            own = self._sides[cur.cuda_stream] = _lib.own_streams_apart(self.device, 1, avoid=[cur])[0]
+        own.stream.wait_stream(cur)
+        return cur, own.stream
+
+    @staticmethod
+    def _join(cur, side):
+        if cur is not None:
+            cur.wait_stream(side)
 
     def _drop_graphs(self):
         if self._graphs and self.device.type == "cuda":
@@ -272,6 +293,9 @@ class OpsEngine:
         if getattr(self, "_cap_stream", None) is not None:
             self._cap_stream.release()
             self._cap_stream = None
+        for own in getattr(self, "_sides", {}).values():
+            own.release()
+        self._sides = {}
 
     def release_workspace(self):
         self._drop_graphs()        # they hold the addresses of this workspace

@@ -100,3 +100,31 @@ def test_flop_counting_and_test_double_stay_eager(lib):
         assert len(eng._graphs) == 1
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("use_graphs", [False, True])
+def test_ifunet_forked_stages_equal_sequential(lib, use_graphs):
+    """r6: block 0's two ensemble passes and the two ResynNet passes run side by side on the engine's side stream (IFUNetEngine.fork_stages).
+    Same kernels on per-pass temporaries: bit-identical frames, eager and replayed, ensemble on and off, call after call."""
+    from cfi_amd.ifunet import IFUNetEngine
+
+    sd = synth.ifunet_synth_state_dict(1234)
+    (x0, x1), (y0, y1) = _pairs([(192, 256), (192, 256)], False)
+    calls = [(x0, x1, 0.5, True), (y0, y1, 0.5, True), (x0, x1, 0.25, False), (x0, x1, 0.5, True), (y0, y1, 0.5, True), (x0, x1, 0.25, False)]
+    res = {}
+    for fork in (False, True):
+        eng = IFUNetEngine(sd)
+        eng.fork_stages, eng.use_graphs = fork, use_graphs
+        try:
+            outs = []
+            for a, b, t, ens in calls:
+                o = torch.empty(192, 256, 3, device="cuda")
+                eng.forward(a, b, t, o, scale=1.0, ensemble=ens)
+                outs.append(o)
+            torch.cuda.synchronize()
+            res[fork] = outs
+        finally:
+            eng.close()
+    for k, (a, b) in enumerate(zip(res[False], res[True])):
+        assert torch.equal(a, b), (k, (a - b).abs().max().item())
+    assert torch.equal(res[True][0], res[True][3]) and torch.equal(res[True][2], res[True][5])

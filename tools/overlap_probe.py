@@ -127,6 +127,9 @@ if __name__ == "__main__":
             threading.Thread(target=dma, daemon=True).start()
         for K in ks:
             engs = [factory() for _ in range(K)]
+            for e in engs:
+                if hasattr(e, "lone_pair"):
+                    e.lone_pair(K == 1)
             if "--own" in sys.argv:      # the library-made streams the node's lanes run on
                 from cfi_amd import _lib
                 t_q = time.perf_counter()
