@@ -297,9 +297,8 @@ void vfi_film_destroy(vfi_film_t* net) {
     for (Layer& L : net->fuse_up2) vfi_conv_destroy(L.h);
     vfi_conv_destroy(net->out_conv.h);
     if (net->side) {
-        (void)hipStreamSynchronize(net->side);
+        stream_give_back(net->side);      // (drained there; kept for the next object: a node that rebuilds its model per call creates no streams per call)
         for (hipEvent_t e : net->ev) (void)hipEventDestroy(e);
-        (void)hipStreamDestroy(net->side);
     }
     free_workspace(net);
     delete net;

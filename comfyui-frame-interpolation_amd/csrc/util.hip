@@ -10,6 +10,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/vfi_hip.h"
 #include "../../include/vfi_hip_test.h"
@@ -123,26 +124,59 @@ namespace vfi {
 // bound at first use; two streams of one queue run strictly in turn, so a fork onto such a stream overlaps nothing.  Decided by
 // measurement: a spinning workgroup on each (vfi_stream_spin), 1x the spin apart, 2x together.  Rejected candidates stay alive (the next
 // one is then bound elsewhere); after 8 tries the last one is used as it is (right frames, no overlap).
-hipStream_t stream_apart_from(hipStream_t st) {
-    hipStream_t c = nullptr;
-    for (int t = 0; t < 8; ++t) {
-        if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        vfi_stream_spin(c, 1);
-        vfi_stream_spin(st, 1);
-        int together = 0;
-        for (int r = 0; r < 3; ++r) {
-            (void)hipStreamSynchronize(st);
-            (void)hipStreamSynchronize(c);
-            const auto t0 = std::chrono::steady_clock::now();
-            vfi_stream_spin(st, 300);
-            vfi_stream_spin(c, 300);
-            (void)hipStreamSynchronize(st);
-            (void)hipStreamSynchronize(c);
-            together += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > 480.0;
-        }
-        if (together < 2) return c;
+static std::mutex g_side_mu;
+static std::vector<hipStream_t> g_side_idle;      // side streams nobody uses at the moment (rejected candidates, returned ones): never destroyed
+
+static bool streams_together(hipStream_t st, hipStream_t c) {
+    vfi_stream_spin(c, 1);
+    vfi_stream_spin(st, 1);
+    int together = 0;
+    for (int r = 0; r < 3; ++r) {
+        (void)hipStreamSynchronize(st);
+        (void)hipStreamSynchronize(c);
+        const auto t0 = std::chrono::steady_clock::now();
+        vfi_stream_spin(st, 300);
+        vfi_stream_spin(c, 300);
+        (void)hipStreamSynchronize(st);
+        (void)hipStreamSynchronize(c);
+        together += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > 480.0;
     }
-    return c;
+    return together >= 2;
+}
+
+hipStream_t stream_apart_from(hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::vector<hipStream_t> rejected;
+    hipStream_t found = nullptr;
+    for (int t = 0; t < 12 && !found; ++t) {
+        hipStream_t c = nullptr;
+        // idle streams of this device first (an object that is rebuilt per call must not create streams per call)
+        for (size_t i = 0; i < g_side_idle.size() && !c; ++i) {
+            int d = -1;
+            if (hipStreamGetDevice(g_side_idle[i], &d) == hipSuccess && d == dev) {
+                c = g_side_idle[i];
+                g_side_idle.erase(g_side_idle.begin() + i);
+            }
+        }
+        if (!c && hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) break;
+        if (streams_together(st, c)) rejected.push_back(c);
+        else found = c;
+    }
+    if (!found && !rejected.empty()) {      // right frames, no overlap
+        found = rejected.back();
+        rejected.pop_back();
+    }
+    for (hipStream_t r : rejected) g_side_idle.push_back(r);
+    return found;
+}
+
+void stream_give_back(hipStream_t side) {
+    if (!side) return;
+    (void)hipStreamSynchronize(side);
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    g_side_idle.push_back(side);
 }
 
 // spins until `ticks` of s_memrealtime (100 MHz on gfx950) have passed: vfi_stream_spin

@@ -80,6 +80,7 @@ enum Option {
 long option(Option o);
 // a new stream that the runtime has bound to another hardware queue than `st` (decided by measurement with vfi_stream_spin; util.hip)
 hipStream_t stream_apart_from(hipStream_t st);
+void stream_give_back(hipStream_t side);      // to the idle list stream_apart_from draws its candidates from (never destroyed)
 int option_set(const char* name, long value);      // 0, or -2 for an unknown name
 int variant_override(const char* trace_name);      // tile variant forced for a trace name (vfi_test_variant_override), -1 = none
 
