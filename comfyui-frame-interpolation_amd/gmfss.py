@@ -296,6 +296,12 @@ class GMFSSEngine(OpsEngine):
         self._ax(t, 0, pos, 0, t, 0, c)
 
     # ---- Model.reuse ------------------------------------------------------------------------------------------------
+    fork_stages = True      # union head: IFNet 4.6 beside the splats on the engine's side stream (tests A/B it)
+
+    def lone_pair(self, on):
+        """lanes.tell_lone_pair: fork only when this is the only pair in flight"""
+        self.fork_stages = bool(on)
+
     def prepare(self, frame0, frame1):
         assert frame1.shape == frame0.shape and frame0.shape[2] >= 3 and frame0.is_contiguous() and frame1.is_contiguous()
         # one HIP graph per frame shape (opsengine._replayable): the ~1000 launches of Model.reuse replay without the interpreter; the
@@ -442,7 +448,7 @@ class GMFSSEngine(OpsEngine):
     def render(self, t, out):
         P = self.prepared
         assert P is not None, "prepare() first"
-        self._replayable(("render", P["H"], P["W"], float(t)), (), (out,), lambda o: self._render(float(t), o))
+        self._replayable(("render", P["H"], P["W"], float(t), self.fork_stages), (), (out,), lambda o: self._render(float(t), o))
         return out
 
     def _render(self, t, out):
@@ -458,23 +464,38 @@ class GMFSSEngine(OpsEngine):
                 self._ax(metric, d, None, 0, zt[d:d + 1], 0, 1, tt)                  # Z_t
             g_in = [self._t("g_in0", 1, Hh, Wh, 16), self._t("g_in1", 1, Hh, Wh, 128), self._t("g_in2", 1, Hh // 2, Wh // 2, 256),
                     self._t("g_in3", 1, Hh // 4, Wh // 4, 384)]
-            for lvl in range(3):
-                s = 1 << lvl
-                h, w = Hh // s, Wh // s
-                if lvl == 0:
-                    fl, zl = ft, zt
-                else:   # F.interpolate(F_t, 1/s) * (1/s), F.interpolate(Z_t, 1/s)
-                    fl, zl = self._t(f"ft{lvl}", 2, h, w, 2), self._t(f"zt{lvl}", 2, h, w, 1)
-                    self._resize(ft, 0, fl, 0, 2, 1.0 / s)
-                    self._resize(zt, 0, zl, 0, 1)
-                c = feats[lvl].shape[-1]
-                for d in (0, 1):
-                    if lvl == 0:   # union head: (I1t, rife, I2t); base head: (img0, I1t, I2t, img1)
-                        self._splat(himg[d:d + 1], 3, zl[d:d + 1], fl[d:d + 1], g_in[0], 6 * d if self.union else 3 + 3 * d)
-                    self._splat(feats[lvl][d:d + 1], c, zl[d:d + 1], fl[d:d + 1], g_in[lvl + 1], c * d)
-            if self.union:
-                self._ifnet46(himg, t, g_in[0], 3)
+            def splats():
+                for lvl in range(3):
+                    s = 1 << lvl
+                    h, w = Hh // s, Wh // s
+                    if lvl == 0:
+                        fl, zl = ft, zt
+                    else:   # F.interpolate(F_t, 1/s) * (1/s), F.interpolate(Z_t, 1/s)
+                        fl, zl = self._t(f"ft{lvl}", 2, h, w, 2), self._t(f"zt{lvl}", 2, h, w, 1)
+                        self._resize(ft, 0, fl, 0, 2, 1.0 / s)
+                        self._resize(zt, 0, zl, 0, 1)
+                    c = feats[lvl].shape[-1]
+                    for d in (0, 1):
+                        if lvl == 0:   # union head: (I1t, rife, I2t); base head: (img0, I1t, I2t, img1)
+                            self._splat(himg[d:d + 1], 3, zl[d:d + 1], fl[d:d + 1], g_in[0], 6 * d if self.union else 3 + 3 * d)
+                        self._splat(feats[lvl][d:d + 1], c, zl[d:d + 1], fl[d:d + 1], g_in[lvl + 1], c * d)
+
+            cur, side = self._fork() if (self.union and self.fork_stages) else (None, None)
+            if side is not None:
+                # r6: the union head's IFNet 4.6 pass reads the half-resolution frames only: it runs on the engine's side stream beside the
+                # 14 splats (small, latency-bound launches); its temporaries are held until the join
+                with self._hold() as hold:
+                    with torch.cuda.stream(side):
+                        hold["active"] = True
+                        self._ifnet46(himg, t, g_in[0], 3)
+                        hold["active"] = False
+                    splats()
+                    self._join(cur, side)
             else:
+                splats()
+                if self.union:
+                    self._ifnet46(himg, t, g_in[0], 3)
+            if not self.union:
                 self._ax(himg[0:1], 0, None, 0, g_in[0], 0, 3)
                 self._ax(himg[1:2], 0, None, 0, g_in[0], 9, 3)
             y = self._gridnet(g_in)

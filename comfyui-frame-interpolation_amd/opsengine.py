@@ -103,6 +103,7 @@ class OpsEngine:
         # for in, or when dropped explicitly; un-pooled engines keep every named tensor for the life of the workspace
         self._pool = _Pool(self.device) if pooled else None
         self._live = [{}]
+        self._held = None
         self.conv_flop = None      # set to 0 to count the direct-form FLOP of every convolution launched from here on (bench.py other_paths)
         self._graphs, self._cap_stream = {}, None
         self._sides = {}           # hipStream_t of a caller's stream -> the OwnStream this engine forks onto beside it (_fork)
@@ -215,7 +216,27 @@ class OpsEngine:
             yield
         finally:
             for _, blk in self._live.pop().values():
-                self._pool.give(blk) if self._pool is not None else None
+                if self._pool is None:
+                    continue
+                if self._held is not None and self._held["active"]:
+                    self._held["blocks"].append(blk)      # a forked stage's temporaries: kept until the join (_hold)
+                else:
+                    self._pool.give(blk)
+
+    @contextlib.contextmanager
+    def _hold(self):
+        """While ``h["active"]`` is set inside the block, scopes that end keep their pool blocks; all of them go back when the block
+        ends.  For a stage forked onto the side stream: the stage on the current stream must not be handed the forked stage's
+        temporaries while the side stream still works on them (the pool recycles by program order, i.e. for ONE stream)."""
+        assert self._held is None, "holds do not nest"
+        self._held = h = {"active": False, "blocks": []}
+        try:
+            yield h
+        finally:
+            self._held = None
+            if self._pool is not None:
+                for blk in h["blocks"]:
+                    self._pool.give(blk)
 
     def _drop(self, *tensors):
         """give scratch tensors back before their scope ends (GridNet's states, dead long before the network is done)"""

@@ -128,3 +128,34 @@ def test_ifunet_forked_stages_equal_sequential(lib, use_graphs):
     for k, (a, b) in enumerate(zip(res[False], res[True])):
         assert torch.equal(a, b), (k, (a - b).abs().max().item())
     assert torch.equal(res[True][0], res[True][3]) and torch.equal(res[True][2], res[True][5])
+
+
+@pytest.mark.parametrize("use_graphs", [False, True])
+def test_gmfss_forked_ifnet_equals_sequential(lib, use_graphs):
+    """r6: the union head's IFNet 4.6 pass runs on the engine's side stream beside the splats (GMFSSEngine.fork_stages), its temporaries
+    held in the pool until the join (OpsEngine._hold).  Same kernels: the frames of the two orders agree to GMFSS' own run-to-run noise
+    (its splats' atomic spill pass, <= 5e-6; bit-identical where no source spills)."""
+    from cfi_amd.gmfss import GMFSSEngine
+
+    sds = synth.gmfss_coherent_state_dicts(3, "union")
+    pairs = _pairs([(192, 256), (128, 192)], True)
+    res = {}
+    for fork in (False, True):
+        eng = GMFSSEngine(sds)
+        eng.fork_stages, eng.use_graphs = fork, use_graphs
+        try:
+            outs = []
+            for p, ts in [(0, (0.5, 0.25)), (1, (0.5,)), (0, (0.5, 0.25)), (1, (0.5,)), (0, (0.5,))]:
+                h, w = pairs[p][0].shape[:2]
+                eng.prepare(*pairs[p])
+                for t in ts:
+                    o = torch.empty(h, w, 3, device="cuda")
+                    eng.render(t, o)
+                    outs.append(o)
+            torch.cuda.synchronize()
+            res[fork] = outs
+            assert eng._held is None
+        finally:
+            eng.close()
+    for k, (a, b) in enumerate(zip(res[False], res[True])):
+        assert (a - b).abs().max().item() <= 5e-6, (k, (a - b).abs().max().item())
