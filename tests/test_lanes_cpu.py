@@ -55,3 +55,30 @@ def test_environment_override(monkeypatch):
     assert LN.lanes_for("m2m") == 1 and LN.lane_set("gmfss", FakeEngine).k == 1
     monkeypatch.setenv("VFI_PAIR_LANES", "5")
     assert LN.lane_set("film", FakeEngine).k == 5 and LN.lane_set("film", FakeEngine).pairs_per_lane == 24
+
+
+def test_hold_keeps_a_forked_stages_blocks_until_the_join():
+    """OpsEngine._hold (the pool recycles by program order, i.e. for one stream): scopes that end while the hold is active keep their
+    blocks — a stage issued afterwards on the current stream cannot be handed them — and everything returns when the hold ends."""
+    from emu_backend import EmuBackend
+
+    from cfi_amd.opsengine import OpsEngine
+
+    eng = OpsEngine(_test_backend=EmuBackend(), pooled=True)
+    with eng._scope():
+        a = eng._t("warm", 1, 64, 64, 8)      # grows the pool's first chunk
+    free_before = [list(map(list, holes)) for holes in eng._pool.free]
+    with eng._hold() as hold:
+        hold["active"] = True
+        with eng._scope():
+            side = eng._t("side_tmp", 1, 32, 32, 8)
+        hold["active"] = False
+        with eng._scope():
+            main = eng._t("main_tmp", 1, 32, 32, 8)
+            assert main.data_ptr() != side.data_ptr(), "the held block was recycled under the forked stage"
+        assert len(hold["blocks"]) == 1
+    assert eng._held is None and [list(map(list, holes)) for holes in eng._pool.free] == free_before
+    with eng._scope():      # after the join the block is anybody's again
+        again = eng._t("later", 1, 32, 32, 8)
+        assert again.data_ptr() == side.data_ptr()
+    assert eng._fork() == (None, None)      # nothing to fork onto without a device
