@@ -478,6 +478,7 @@ class OutputWriter:
 
     def finish(self):
         self.down.close()
-        for f in self.futs:
-            f.result()
+        with _T("main.wait_out_futs"):      # pass-through copies and the first-touch sweep of the output tensor
+            for f in self.futs:
+                f.result()
         return self.out
