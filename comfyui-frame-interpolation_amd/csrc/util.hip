@@ -248,8 +248,21 @@ int vfi_stream_destroy(void* stream) {
 
 int vfi_stream_spin(void* stream, int microseconds) {
     VFI_REQUIRE(microseconds > 0 && microseconds <= 100000, "vfi_stream_spin: %d us out of range (1 .. 100000)", microseconds);
+    // launched with the stream's device current (a host thread that never chose a device probes streams of any device); restored afterwards
+    int cur = -1, sdev_i = -1;
+    if (stream) {
+        hipDevice_t sdev = 0;
+        if (hipStreamGetDevice((hipStream_t)stream, &sdev) == hipSuccess && hipGetDevice(&cur) == hipSuccess && cur != (int)sdev) {
+            sdev_i = (int)sdev;
+            VFI_CHECK_HIP(hipSetDevice(sdev_i));
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL(vfi::stream_spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)microseconds * 100ull);
-    VFI_CHECK_HIP(hipGetLastError());
+    const hipError_t le = hipGetLastError();
+    if (sdev_i >= 0 && cur >= 0) (void)hipSetDevice(cur);
+    VFI_CHECK_HIP(le);
     return 0;
 }
 
