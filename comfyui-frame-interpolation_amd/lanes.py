@@ -21,7 +21,9 @@ DEFAULT_LANES = {"m2m": 3, "film": 2, "gmfss": 3, "ifunet": 3, "ifrnet": 2}
 # FILM with 2 lanes on 12 pairs 583 vs 567 ms and on 24 pairs 1128 vs 1122-1131 ms (the node releases and re-allocates every workspace per call), M2M with 3 lanes on 8 pairs 89 vs 76 ms — tools/node_e2e_models.py)
 # GMFSS / IFUNet: a lane's first two pairs of a call cost 150 / 130 ms more than steady ones (workspace fill, graph capture —
 # tools/engine_build_probe.py) against 5.5 / 5.3 ms gained per pair of the clip: two lanes from 64 pairs, three from 96.
-PAIRS_PER_LANE = {"film": 24, "gmfss": 32, "ifunet": 32}
+# M2M / IFRNet: a lane's workspace costs ~2 ms of device time and ~6 ms of host time per call: three lanes on an 8-pair clip lost (89 vs 76 ms),
+# on a 12-pair clip they gained 6 %.
+PAIRS_PER_LANE = {"film": 24, "gmfss": 32, "ifunet": 32, "m2m": 4, "ifrnet": 4}
 
 
 def lanes_for(model):
