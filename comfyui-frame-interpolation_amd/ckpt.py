@@ -90,6 +90,32 @@ def cached_engine(model_type, path, build):
     return eng, True
 
 
+# A cached engine's WORKSPACE (activations, pooled scratch, captured graphs) normally goes back at the end of a node call: the next call
+# re-allocates it (M2M +2 ms, FILM +7 ms / 15 GB).  The op-by-op engines pay far more for it — a lane's first two pairs of a call cost
+# GMFSS 150 ms and IFUNet 130 ms over steady ones (pool chunks, graph capture; tools/engine_build_probe.py) — for 2.7-3.1 GiB per lane: on a
+# 288 GB device those stay resident between calls of the same frame shape (a new shape, or a set above the budget, releases as before).
+KEEP_WORKSPACE_BYTES = 16 << 30
+
+
+def begin_call(engine, shape):
+    """before a cached engine's node call: a kept workspace is for ONE frame shape (its root tensors are keyed by shape and would pile up)"""
+    kept = getattr(engine, "_kept_shape", None)
+    if kept is not None and kept != tuple(shape):
+        engine.release_workspace()
+    engine._kept_shape = tuple(shape)
+
+
+def end_call(engine, cached):
+    """after a node call: close an uncached engine; release a cached one's workspace unless it may stay (KEEP_WORKSPACE_BYTES)"""
+    if not cached:
+        engine.close()
+        return
+    size = engine.workspace_bytes() if hasattr(engine, "workspace_bytes") else None
+    if size is None or size > KEEP_WORKSPACE_BYTES:
+        engine.release_workspace()
+        engine._kept_shape = None
+
+
 def clear_engine_cache():
     for _, eng in _engine_cache.values():
         eng.close()

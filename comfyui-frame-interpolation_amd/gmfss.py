@@ -668,7 +668,7 @@ class GMFSS_Fortuna_VFI:
         assert len(frames) >= 2, f"VFI model GMFSS Fortuna requires at least 2 frames to work with, only found {frames.shape[0]}."
         if ckpt_name not in CKPTS_PATH_CONFIG:
             raise KeyError(ckpt_name)
-        from .ckpt import cached_engine
+        from .ckpt import begin_call, cached_engine, end_call
         from .lanes import lane_set
         paths = {part: load_file_from_github_release(*loc) for part, loc in CKPTS_PATH_CONFIG[ckpt_name].items()}
 
@@ -679,11 +679,9 @@ class GMFSS_Fortuna_VFI:
         # a constructor is 60-90 ms per lane — keyed by the variant and its fusion-net file; see ckpt.cached_engine)
         engine, cached = cached_engine(MODEL_TYPE + ":" + ckpt_name, paths["fusionnet"], build)
         try:
+            begin_call(engine, frames.shape[1:3])
             plan, tasks = generic_output_plan(len(frames), multiplier, optional_interpolation_states)
             return (run_plan(engine, frames, plan, tasks, name="GMFSS Fortuna VFI"),)
         finally:
             torch.cuda.synchronize(engine.device)
-            if cached:
-                engine.release_workspace()
-            else:
-                engine.close()
+            end_call(engine, cached)      # (the workspace and the captured graphs stay for the next call of this frame shape: ckpt.KEEP_WORKSPACE_BYTES)

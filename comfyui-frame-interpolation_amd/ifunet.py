@@ -404,7 +404,7 @@ class IFUnet_VFI:
 
         assert len(frames) >= 2, f"VFI model IFUNet requires at least 2 frames to work with, only found {frames.shape[0]}."
         model_path = load_file_from_github_release(MODEL_TYPE, ckpt_name)
-        from .ckpt import cached_engine
+        from .ckpt import begin_call, cached_engine, end_call
         from .lanes import configure as configure_lanes
         from .lanes import lane_set
 
@@ -417,11 +417,9 @@ class IFUnet_VFI:
         sc, ens = float(scale_factor), bool(ensemble)
         configure_lanes(engine, lambda e: (setattr(e, "scale", sc), setattr(e, "ensemble", ens)))
         try:
+            begin_call(engine, frames.shape[1:3])
             plan, tasks = generic_output_plan(len(frames), multiplier, optional_interpolation_states)
             return (run_plan(engine, frames, plan, tasks, name="IFUnet VFI"),)
         finally:
             torch.cuda.synchronize(engine.device)
-            if cached:
-                engine.release_workspace()
-            else:
-                engine.close()
+            end_call(engine, cached)      # (the workspace and the captured graphs stay for the next call of this frame shape: ckpt.KEEP_WORKSPACE_BYTES)

@@ -19,11 +19,12 @@ DEFAULT_LANES = {"m2m": 3, "film": 2, "gmfss": 3, "ifunet": 3, "ifrnet": 2}
 # A lane's first pair pays for its workspace (and, GMFSS / IFUNet, for its graph capture; FILM's first forward allocates its scratch
 # call by call and holds the host for a whole pair): a lane is only opened for this many pairs of the clip (measured at 1080p:
 # FILM with 2 lanes on 12 pairs 583 vs 567 ms and on 24 pairs 1128 vs 1122-1131 ms (the node releases and re-allocates every workspace per call), M2M with 3 lanes on 8 pairs 89 vs 76 ms — tools/node_e2e_models.py)
-# GMFSS / IFUNet: a lane's first two pairs of a call cost 150 / 130 ms more than steady ones (workspace fill, graph capture —
-# tools/engine_build_probe.py) against 5.5 / 5.3 ms gained per pair of the clip: two lanes from 64 pairs, three from 96.
+# GMFSS / IFUNet: a lane's first two pairs cost 150 / 130 ms more than steady ones (workspace fill, graph capture —
+# tools/engine_build_probe.py) against 5.5 / 5.3 ms gained per pair of the clip; their workspaces and graphs now stay between calls of one
+# frame shape (ckpt.end_call), so only a process's first call of a shape pays: a lane per 8 pairs.
 # M2M / IFRNet: a lane's workspace costs ~2 ms of device time and ~6 ms of host time per call: three lanes on an 8-pair clip lost (89 vs 76 ms),
 # on a 12-pair clip they gained 6 %.
-PAIRS_PER_LANE = {"film": 24, "gmfss": 32, "ifunet": 32, "m2m": 4, "ifrnet": 4}
+PAIRS_PER_LANE = {"film": 24, "gmfss": 8, "ifunet": 8, "m2m": 4, "ifrnet": 4}
 
 
 def lanes_for(model):
@@ -82,6 +83,12 @@ class LaneSet:
     def release_workspace(self):
         for e in self.engines:
             e.release_workspace()
+
+    def workspace_bytes(self):
+        """device bytes the lanes' workspaces hold, or None when an engine cannot say (ckpt.end_call then releases as before)"""
+        if not all(hasattr(e, "workspace_bytes") for e in self.engines):
+            return None
+        return sum(e.workspace_bytes() for e in self.engines)
 
     def close(self):
         if self._streams and self.device.type == "cuda":

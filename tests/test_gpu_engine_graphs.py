@@ -159,3 +159,33 @@ def test_gmfss_forked_ifnet_equals_sequential(lib, use_graphs):
             eng.close()
     for k, (a, b) in enumerate(zip(res[False], res[True])):
         assert (a - b).abs().max().item() <= 5e-6, (k, (a - b).abs().max().item())
+
+
+def test_ifunet_node_keeps_workspace_and_graphs_between_calls(lib, tmp_path, monkeypatch):
+    """r6: the IFUnet / GMFSS nodes keep their engines, workspaces and captured graphs between calls of one frame shape (ckpt.end_call:
+    a lane's first two pairs of a call cost 130-150 ms otherwise); another frame shape releases the old workspace first; the frames of
+    a repeated call are the first call's."""
+    import cfi_amd.ckpt as K
+    import cfi_amd.ifunet as M
+
+    pth = tmp_path / "IFUNet.pth"
+    torch.save(synth.ifunet_synth_state_dict(1234), pth)
+    monkeypatch.setattr(K, "load_file_from_github_release", lambda model_type, ckpt_name: str(pth))
+    K.clear_engine_cache()
+    try:
+        a = synth.smooth_frames(4, 128, 192, seed=3, shift=2.0)
+        b = synth.smooth_frames(3, 192, 256, seed=4, shift=2.0)
+        (o1,) = M.IFUnet_VFI().vfi("IFUNet.pth", a, multiplier=2)
+        lanes = K._engine_cache[M.MODEL_TYPE][1]
+        eng = lanes.engines[0]
+        assert any(isinstance(g, tuple) for g in eng._graphs.values()) and lanes.workspace_bytes() > 0 and lanes._kept_shape == (128, 192)
+        held = lanes.workspace_bytes()
+        (o2,) = M.IFUnet_VFI().vfi("IFUNet.pth", a, multiplier=2)
+        assert torch.equal(o1, o2) and K._engine_cache[M.MODEL_TYPE][1] is lanes and lanes.workspace_bytes() == held
+        (o3,) = M.IFUnet_VFI().vfi("IFUNet.pth", b, multiplier=2)
+        assert lanes._kept_shape == (192, 256) and o3.shape[1:3] == (192, 256)
+        assert all(k[1:3] == (192, 256) for k in eng._graphs if k[0] == "forward"), list(eng._graphs)
+        (o4,) = M.IFUnet_VFI().vfi("IFUNet.pth", a, multiplier=2)
+        assert torch.equal(o1, o4)
+    finally:
+        K.clear_engine_cache()
