@@ -27,7 +27,7 @@ import typing
 import torch
 
 from . import _lib
-from .ckpt import cached_engine, load_file_from_github_release
+from .ckpt import begin_call, cached_engine, end_call, load_file_from_github_release
 from .lanes import lane_set
 from .lanes import configure as configure_lanes
 from .ifrnet_spec import CKPT_NAMES, CONFIG, check_state_dict, decoder_io, kind_of
@@ -139,6 +139,9 @@ class IFRNetEngine:
         """Drop the activations; the packed weights stay on the device."""
         self.scratch = {}
         self._pair = None
+
+    def workspace_bytes(self):
+        return sum(t.numel() * t.element_size() for t in self.scratch.values())
 
     def __del__(self):
         try:
@@ -334,6 +337,7 @@ class IFRNet_VFI:
             return lane_set("ifrnet", lambda: IFRNetEngine(sd, kind))
         engine, cached = cached_engine(MODEL_TYPE + kind, model_path, build)
         try:
+            begin_call(engine, tuple(frames.shape[1:3]) + (float(scale_factor), multiplier if isinstance(multiplier, int) else -1))
             embt = float(scale_factor)           # positional mis-binding of the reference's call, see the module docstring
             configure_lanes(engine, lambda e: setattr(e, "embt", embt))
             plan, tasks = generic_output_plan(len(frames), multiplier, optional_interpolation_states)
@@ -341,6 +345,4 @@ class IFRNet_VFI:
         finally:
             if cached:
                 torch.cuda.synchronize(engine.device)
-                engine.release_workspace()
-            else:
-                engine.close()
+            end_call(engine, cached)      # (the scratch tensors stay for the next call of this frame shape: ckpt.KEEP_WORKSPACE_BYTES)
