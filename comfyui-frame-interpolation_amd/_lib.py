@@ -172,6 +172,7 @@ PROTOTYPES = {
     "vfi_m2m_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vfi_m2m_render": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "vfi_m2m_release_workspace": (C.c_int, [C.c_void_p]),
+    "vfi_m2m_workspace_bytes": (C.c_int64, [C.c_void_p]),
     "vfi_m2m_debug_read": (C.c_int64, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
     "vfi_m2m_image4": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "vfi_m2m_warp_image4": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -65,6 +65,7 @@ struct vfi_m2m {
     int dech[5][2], ench[4][2];
     std::map<std::tuple<std::string, int, int, int>, Ten> scratch;
     std::vector<void*> owned;
+    int64_t owned_bytes = 0;           // vfi_m2m_workspace_bytes (the tensors; a few KB of control words are not counted)
 };
 
 namespace {
@@ -74,6 +75,7 @@ int alloc_ten(vfi_m2m* m, Ten& t, int n, int h, int w, int c, hipStream_t st = n
     const size_t bytes = (size_t)n * h * w * c * sizeof(float);
     VFI_CHECK_HIP(hipMalloc((void**)&t.p, bytes));
     m->owned.push_back(t.p);
+    m->owned_bytes += (int64_t)bytes;
     // zero fill ordered with the forward's kernels: a NULL-stream memset is not ordered against a non-blocking side stream (torch's)
     // and could clear a lazily allocated scratch tensor AFTER its first producer ran
     VFI_CHECK_HIP(hipMemsetAsync(t.p, 0, bytes, st));
@@ -84,6 +86,7 @@ int alloc_ten(vfi_m2m* m, Ten& t, int n, int h, int w, int c, hipStream_t st = n
 void free_workspace(vfi_m2m* m) {
     for (void* p : m->owned) (void)hipFree(p);
     m->owned.clear();
+    m->owned_bytes = 0;
     m->scratch.clear();
     m->stats = nullptr;
     m->tile_ranges = m->smax = nullptr;
@@ -316,6 +319,8 @@ void vfi_m2m_destroy(vfi_m2m_t* m) {
     free_workspace(m);
     delete m;
 }
+
+int64_t vfi_m2m_workspace_bytes(vfi_m2m_t* m) { return m ? m->owned_bytes : 0; }
 
 int vfi_m2m_release_workspace(vfi_m2m_t* m) {
     VFI_REQUIRE(m, "vfi_m2m_release_workspace: null handle");

@@ -26,7 +26,7 @@ import typing
 import torch
 
 from . import _lib
-from .ckpt import cached_engine, load_file_from_github_release
+from .ckpt import cached_engine, end_call, load_file_from_github_release
 from .lanes import LaneSet, lane_set
 from .dist import all_gather_frames, world
 from .m2m_spec import check_state_dict, m2m_shapes
@@ -72,6 +72,9 @@ class M2MEngine:
         """Drop the activations; the packed weights stay on the device."""
         _lib.check(self.lib.vfi_m2m_release_workspace(self.handle), "vfi_m2m_release_workspace")
         self.hw = None
+
+    def workspace_bytes(self):
+        return int(self.lib.vfi_m2m_workspace_bytes(self.handle)) if getattr(self, "handle", None) else 0
 
     def prepare(self, frame0, frame1):
         """frame0/frame1: [H,W,C>=3] fp32 device tensors.  Runs everything that does not depend on the timestep (the frames are
@@ -251,6 +254,4 @@ class M2M_VFI:
         finally:
             if cached:
                 torch.cuda.synchronize(engine.device)
-                engine.release_workspace()
-            else:
-                engine.close()
+            end_call(engine, cached)      # (0.3 GB per lane at 1080p: stays for the next clip, ckpt.KEEP_WORKSPACE_BYTES)

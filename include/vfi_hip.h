@@ -248,6 +248,9 @@ void vfi_m2m_destroy(vfi_m2m_t* net);
 int vfi_m2m_prepare(vfi_m2m_t* net, const float* frame0_dev, const float* frame1_dev, int C, int H, int W, void* stream);
 int vfi_m2m_render(vfi_m2m_t* net, float t, float* out_dev, void* stream);
 int vfi_m2m_release_workspace(vfi_m2m_t* net);
+/* device bytes of the object's activation tensors at the moment (0 after vfi_m2m_release_workspace): what a host that keeps the
+ * object between clips weighs against re-allocating per clip (the nodes: ckpt.end_call) */
+int64_t vfi_m2m_workspace_bytes(vfi_m2m_t* net);
 
 /* The whole M2M node call for a HOST clip, replacing M2M_VFI.vfi + generic_frame_loop in timestep mode
  * (vfi_models/m2m/__init__.py:33-60, vfi_utils.py:149-389): frames_host [N,H,W,C] fp32, N >= 2 -> out_host [*n_out,H,W,3].
